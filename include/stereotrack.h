@@ -1,0 +1,240 @@
+/*
+ * stereotrack.h — C ABI of libstereotrack_hip.so (MI355X / gfx950).
+ *
+ * Drop-in boundary for the per-frame dense compute path of
+ * Superjie13/StereoTracking.  The reference has NO FFI of its own (pure Python
+ * on third-party wheels, reference setup.py:223 `ext_modules=[]`), so every
+ * entry point below cites the reference *Python* interface it replaces; the
+ * ctypes binding a maintainer would add is shown in INTEGRATION.md.
+ *
+ * Conventions
+ *   - every function returns 0 on success, a negative ST_ERR_* otherwise;
+ *     st_last_error() returns a thread-local message.  No exceptions cross
+ *     the ABI.
+ *   - all pointers named *_dev are device pointers owned by the CALLER
+ *     (PyTorch); the library owns only packed weights (freed by *_destroy).
+ *   - all work is enqueued on the caller's stream (a hipStream_t passed as
+ *     void*); no call synchronises the device or allocates on the hot path.
+ *   - activations are fp32.  Internal activation layout is NHWC
+ *     (pixel-major, channel-contiguous); the boundary tensors keep the
+ *     reference's NCHW layout.
+ */
+#ifndef STEREOTRACK_H_
+#define STEREOTRACK_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ST_VERSION 100
+
+enum {
+  ST_OK = 0,
+  ST_ERR_INVALID = -1,   /* bad argument / shape mismatch            */
+  ST_ERR_HIP = -2,       /* a HIP runtime call failed                */
+  ST_ERR_STATE = -3,     /* call order violated (e.g. not finalized) */
+  ST_ERR_WORKSPACE = -4, /* caller workspace too small               */
+  ST_ERR_NOTFOUND = -5   /* unknown parameter name                   */
+};
+
+typedef void* st_stream_t; /* hipStream_t */
+
+int st_version(void);
+const char* st_last_error(void);
+
+/* ------------------------------------------------------------------------
+ * 1. Convolution primitive (exact-fp32 MFMA implicit GEMM, NHWC).
+ *    Replaces one mmcv ConvModule = Conv2d(bias=False) + BatchNorm2d(eps) +
+ *    SiLU as built in reference
+ *    mmtrack/models/backbones/csp_darknet_disparity_v1.py:104-153
+ *    (BN already folded into wgt/bias by the caller or by st_detector_*).
+ * ---------------------------------------------------------------------- */
+typedef struct StConvDesc {
+  /* input: NHWC view, pixel (n,y,x) at in_dev[((n*Hi+y)*Wi+x)*in_ld + in_off + c] */
+  const float* in_dev;
+  int N, Hi, Wi, Cin, in_ld, in_off;
+  /* weights [CoutPad][Kpad] row-major, K index = (kh*KW+kw)*Cin + ci,
+   * Kpad = roundup(KH*KW*Cin, 32), CoutPad = roundup(Cout, 32), zero padded;
+   * bias [CoutPad] */
+  const float* wgt_dev;
+  const float* bias_dev;
+  int Cout, KH, KW, stride, pad;
+  /* outputs: channels [0,split) -> out1, [split,Cout) -> out2 (NULL if unused) */
+  float* out1_dev;
+  int out1_ld, out1_off, split;
+  float* out2_dev;
+  int out2_ld, out2_off;
+  /* optional: every channel is ALSO stored nearest-x2 upsampled (2Ho x 2Wo) */
+  float* up_dev;
+  int up_ld, up_off;
+  /* optional residual: out = (act(conv+bias) + res) * post_scale */
+  const float* res_dev;
+  int res_ld, res_off;
+  float post_scale;
+  int act; /* 0 = identity, 1 = SiLU */
+} StConvDesc;
+
+int st_conv2d_nhwc(const StConvDesc* d, st_stream_t stream);
+
+/* Pack one Conv2d weight [Cout][Cin][KH][KW] (+ optional BN, folded in fp64)
+ * into the kernel layout above.  Host function; out buffers are host memory
+ * of st_conv_packed_floats(...) / roundup(Cout,32) floats. */
+size_t st_conv_packed_floats(int Cout, int Cin, int KH, int KW);
+int st_conv_pack_weights(const float* w, const float* conv_bias, /* may be NULL */
+                         const float* bn_gamma, const float* bn_beta,
+                         const float* bn_mean, const float* bn_var, /* NULL = no BN */
+                         double bn_eps, int Cout, int Cin, int KH, int KW,
+                         float* wgt_out, float* bias_out);
+
+/* ------------------------------------------------------------------------
+ * 2. Input packing: NCHW fp32 image -> Focus (space-to-depth) NHWC 12-ch.
+ *    Replaces mmdet Focus slicing, reference
+ *    csp_darknet_disparity_v1.py:104-111 (order TL,BL,TR,BR).
+ * ---------------------------------------------------------------------- */
+int st_focus_pack(const float* img_nchw_dev, int N, int C, int H, int W,
+                  float* out_nhwc_dev, st_stream_t stream);
+
+/* SPP: out[..., 0:C]=x, [C:2C]=maxpool5, [2C:3C]=maxpool9, [3C:4C]=maxpool13
+ * (stride 1, same pad, -inf padding).  x may alias out channels [0,C).
+ * Replaces mmyolo SPPFBottleneck pooling, csp_darknet_disparity_v1.py:137-144 */
+int st_spp_pool(const float* x_dev, int x_ld, int x_off, int N, int H, int W, int C,
+                float* out_dev, int out_ld, int out_off, st_stream_t stream);
+
+/* ------------------------------------------------------------------------
+ * 3. Two-branch YOLOX detector (backbone + PAFPN + decoupled head).
+ *    Replaces YOLODetector_Disparity_V1._forward, reference
+ *    mmtrack/models/detectors/yolo_detector_disparity_v1.py:127-142
+ *    (extract_feat :77-90 -> backbone forward
+ *    csp_darknet_disparity_v1.py:155-206 -> mmyolo YOLOXPAFPN ->
+ *    YOLOXHeadModule.forward).
+ * ---------------------------------------------------------------------- */
+typedef struct StDetector StDetector;
+
+typedef struct StDetectorConfig {
+  int struct_size;      /* = sizeof(StDetectorConfig) */
+  float widen_factor;   /* 0.5 for YOLOX-s */
+  float deepen_factor;  /* 0.33 */
+  int num_classes;      /* 1 */
+  int batch;            /* N frames per forward */
+  int height, width;    /* padded input size, multiples of 32 */
+  double bn_eps;        /* 1e-3 */
+  int with_right_branch; /* also build stem+stage1 features for the right image (stereo module) */
+} StDetectorConfig;
+
+int st_detector_create(const StDetectorConfig* cfg, StDetector** out);
+int st_detector_destroy(StDetector* det);
+
+/* Parameter table, named exactly like the reference state_dict
+ * ("backbone.stem.conv.conv.weight", "backbone.disp_stage1.0.bn.running_var",
+ *  "neck.reduce_layers.2.conv.weight", "bbox_head.head_module.multi_level_conv_cls.0.bias" ...;
+ *  SURVEY.md §5 checkpoint row). */
+int st_detector_num_params(const StDetector* det);
+int st_detector_param_info(const StDetector* det, int idx, char* name, int name_cap,
+                           int64_t shape[4], int* ndim);
+int st_detector_set_param(StDetector* det, const char* name, const float* host, int64_t numel);
+/* fold BN (fp64), repack, upload.  Needs a current HIP device. */
+int st_detector_finalize(StDetector* det);
+
+size_t st_detector_workspace_bytes(const StDetector* det);
+/* head output layout: for level l (stride 8,16,32): float[N][H_l*W_l][8],
+ * channel 0 = cls logit, 1..4 = reg (x,y,w,h), 5 = obj logit, 6,7 unused;
+ * levels concatenated.  st_detector_head_floats = total float count. */
+size_t st_detector_head_floats(const StDetector* det);
+int st_detector_num_levels(const StDetector* det);
+int st_detector_level_info(const StDetector* det, int level, int* h, int* w, int* stride,
+                           size_t* float_offset);
+/* img/disp: NCHW fp32 [N][3][H][W] device pointers (the tensors
+ * TrackDataPreprocessor_Disparity_V1 produces, reference
+ * data_preprocessor_disparity_v1.py:21-84). */
+int st_detector_forward(StDetector* det, const float* img_dev, const float* disp_dev,
+                        void* workspace_dev, size_t workspace_bytes, st_stream_t stream,
+                        float* head_out_dev);
+/* Number of conv MACs one forward performs (for roofline reporting). */
+double st_detector_macs(const StDetector* det);
+/* Stereo configuration (with_right_branch=1), two phases around the cost-volume module:
+ * phase 0 = stem+stage1 features of left AND right (shared RGB-branch weights, one stacked
+ * batch of 2N; tap "stage1_rgb" = [2N][H/4][W/4][C]); phase 1 = disparity branch + fused trunk +
+ * neck + head.  With with_right_branch=0 the two phases together equal st_detector_forward. */
+int st_detector_forward_phase(StDetector* det, int phase, const float* img_dev,
+                              const float* disp_dev, const float* right_dev, void* workspace_dev,
+                              size_t workspace_bytes, st_stream_t stream, float* head_out_dev);
+/* Internal NHWC activations inside the workspace (valid after forward); name in
+ * {"stage1_rgb","stage1_fused","stage2","stage3","stage4","p3","p4","p5"}.  Pixel p, channel c
+ * is ptr[p*ld + c]. */
+int st_detector_tap(const StDetector* det, const char* name, const void* workspace_dev,
+                    const float** ptr_dev, int* N, int* C, int* H, int* W, int* ld);
+
+/* ------------------------------------------------------------------------
+ * 4. Decode + score filter + sort + NMS.
+ *    Replaces mmyolo YOLOXHead.predict_by_feat -> YOLOXBBoxCoder.decode ->
+ *    mmdet filter_scores_and_topk -> mmcv.ops.batched_nms
+ *    (un-vendored; call site reference yolo_detector_disparity_v1.py:121-122,
+ *    thresholds configs/stereo_tracking/ocsort/yolox_s_mmyolo_mot_airdrone_disp.py:42).
+ * ---------------------------------------------------------------------- */
+typedef struct StDecodeDesc {
+  int struct_size;
+  int batch;
+  int num_levels;
+  int level_h[4], level_w[4], level_stride[4];
+  size_t level_offset[4]; /* float offset of level l inside head_out */
+  float score_thr;        /* keep score > thr  */
+  float iou_thr;          /* suppress IoU > thr */
+  int max_det;            /* capacity of the out_* arrays per image */
+  float scale_x, scale_y; /* scale_factor (w,h); boxes /= scale before NMS */
+  float pad_left, pad_top;/* pad_param subtracted before scaling (0 if none) */
+  float ori_w, ori_h;     /* clamp range after NMS */
+} StDecodeDesc;
+
+size_t st_decode_nms_workspace_bytes(const StDecodeDesc* d);
+/* outputs per image n: out_boxes[n][max_det][4] (xyxy), out_scores[n][max_det],
+ * out_labels[n][max_det] (int64), out_prior_idx[n][max_det] (flat prior index,
+ * the bit-exact identity of a kept box), out_count[n] = number kept (may exceed
+ * max_det: then only the first max_det are stored). */
+int st_decode_nms(const StDecodeDesc* d, const float* head_out_dev, void* workspace_dev,
+                  size_t workspace_bytes, st_stream_t stream, float* out_boxes_dev,
+                  float* out_scores_dev, int64_t* out_labels_dev, int32_t* out_prior_idx_dev,
+                  int32_t* out_count_dev);
+
+/* ------------------------------------------------------------------------
+ * 5. Stereo cost volume -> soft-argmin disparity (NEW module named by
+ *    north_star; no reference function exists — consumer contract is
+ *    reference loading_disparity.py:129-134 and ocsort_disparity.py:115,132-134).
+ *    featL/featR: NHWC [N][Hf][Wf][C].  cost[d] = (1/C) sum_c L[x,c]*R[x-d,c]
+ *    (0 where x-d<0); disp_lowres = sum_d d*softmax_d(temperature*cost[d]).
+ *    out_cost_dev (optional) receives the materialised volume [N][Hf][Wf][D].
+ * ---------------------------------------------------------------------- */
+int st_costvolume_softargmin(const float* featL_dev, const float* featR_dev, int N, int Hf,
+                             int Wf, int C, int feat_ld, int D, float temperature,
+                             float* out_cost_dev, float* out_disp_dev, st_stream_t stream);
+/* soft-argmin only, on an (aggregated) volume [N][Hf][Wf][D] */
+int st_softargmin(const float* cost_dev, int N, int Hf, int Wf, int D, float temperature,
+                  float* out_disp_dev, st_stream_t stream);
+/* bilinear (align_corners=False) x`scale` upsample of the low-res disparity,
+ * multiplied by `scale`, cropped to (valid_h, valid_w), zero elsewhere, written
+ * replicated into the 3 channels of disp_postp NCHW [N][3][H][W]. */
+int st_disp_upsample_pack(const float* disp_lr_dev, int N, int Hf, int Wf, int scale, int H,
+                          int W, int valid_h, int valid_w, float* disp_postp_dev,
+                          st_stream_t stream);
+
+/* ------------------------------------------------------------------------
+ * 6. Per-box depth (disp2depth + extract_depth + scale), reference
+ *    mmtrack/models/mot/ocsort_disparity.py:113-175 and
+ *    mmtrack/models/trackers/utils.py:58-73.
+ *    disp: channel 0 of disp_postp, [N][H][W] with row pitch W and image pitch
+ *    img_pitch floats.  boxes [N][max_det][4], counts[N].
+ *    outputs: depth[N][max_det] (-1 = no valid depth), scale[N][max_det],
+ *    scaled_boxes[N][max_det][4].
+ * ---------------------------------------------------------------------- */
+size_t st_box_depth_workspace_bytes(int N, int max_det, int H, int W);
+int st_box_depth(const float* disp_dev, size_t img_pitch, int N, int H, int W,
+                 const float* boxes_dev, const int32_t* counts_dev, int max_det, float baseline,
+                 float focal, void* workspace_dev, size_t workspace_bytes, st_stream_t stream,
+                 float* out_depth_dev, float* out_scale_dev, float* out_scaled_boxes_dev);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* STEREOTRACK_H_ */

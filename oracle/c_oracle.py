@@ -1,0 +1,66 @@
+"""ORACLE (test infrastructure): builds oracle/st_oracle.c with gcc and binds it with ctypes.
+Only tests/, __graft_entry__ (build + smoke) and bench.py's cpu_baseline leg may import this."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+SRC = os.path.join(_HERE, 'st_oracle.c')
+OUT_DIR = os.path.join(_HERE, '_build')
+LIB = os.path.join(OUT_DIR, 'libst_oracle.so')
+
+_lib = None
+
+
+def build(force=False):
+    os.makedirs(OUT_DIR, exist_ok=True)
+    if force or not os.path.exists(LIB) or (os.path.exists(SRC) and os.path.getmtime(LIB) < os.path.getmtime(SRC)):
+        subprocess.check_call(['gcc', '-O2', '-std=c11', '-ffp-contract=off', '-fno-fast-math', '-fPIC', '-shared',
+                               '-o', LIB, SRC, '-lm'])
+    return LIB
+
+
+def load():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB):
+            build()
+        _lib = C.CDLL(LIB)
+        _lib.oracle_expf.restype = C.c_float
+        _lib.oracle_expf.argtypes = [C.c_float]
+        _lib.oracle_sigmoidf.restype = C.c_float
+        _lib.oracle_sigmoidf.argtypes = [C.c_float]
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def decode_nms(head, N, levels, score_thr, iou_thr, max_det, ori_shape, scale_factor=(1.0, 1.0), pad_param=None):
+    """head: flat float32 numpy array in the product's head_out layout; levels: [(h, w, stride, float_offset)].
+    Returns boxes (N,max_det,4), scores, labels (int64), prior_idx (int32), counts (int32)."""
+    lib = load()
+    head = np.ascontiguousarray(head, dtype=np.float32)
+    L = len(levels)
+    lh = (C.c_int * L)(*[l[0] for l in levels])
+    lw = (C.c_int * L)(*[l[1] for l in levels])
+    ls = (C.c_int * L)(*[l[2] for l in levels])
+    lo = (C.c_size_t * L)(*[l[3] for l in levels])
+    boxes = np.zeros((N, max_det, 4), np.float32)
+    scores = np.zeros((N, max_det), np.float32)
+    labels = np.zeros((N, max_det), np.int64)
+    prior = np.full((N, max_det), -1, np.int32)
+    counts = np.zeros((N,), np.int32)
+    pad_left = float(pad_param[2]) if pad_param is not None else 0.0
+    pad_top = float(pad_param[0]) if pad_param is not None else 0.0
+    f = C.c_float
+    rc = lib.oracle_decode_nms(_p(head), C.c_int(N), C.c_int(L), lh, lw, ls, lo, f(score_thr), f(iou_thr),
+                               C.c_int(max_det), f(scale_factor[0]), f(scale_factor[1]), f(pad_left), f(pad_top),
+                               f(ori_shape[1]), f(ori_shape[0]), _p(boxes), _p(scores), _p(labels), _p(prior),
+                               _p(counts))
+    if rc != 0:
+        raise RuntimeError('oracle_decode_nms failed')
+    return boxes, scores, labels, prior, counts

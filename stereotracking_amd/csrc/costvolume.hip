@@ -1,0 +1,252 @@
+// Stereo cost volume -> soft-argmin disparity (the module BASELINE.json's north_star adds; the
+// reference has no counterpart - it loads SGBM disparity PNGs, loading_disparity.py:71-134).
+// Specification = oracle/st_oracle.c (oracle_costvolume / oracle_softargmin / oracle_disp_upsample):
+//
+//   cost[n,y,x,d] = ( sum_{c=0..C-1, in order, fmaf} L[n,y,x,c] * R[n,y,x-d,c] ) / C   for x-d >= 0
+//                 = 0                                                                   otherwise
+//   disp_lr[n,y,x] = sum_d d*e_d / sum_d e_d,  e_d = exp(T*cost_d - max_d T*cost_d)
+//   disp[n,0..2,Y,X] = scale * bilinear_x`scale`(disp_lr) (align_corners=False) inside
+//                      (valid_h, valid_w), 0 outside  -> the `disp_postp` tensor the detector's
+//                      disparity branch and ocsort_disparity.py:115,132-134 consume.
+//
+// Mapping: HBM-lean VALU kernel.  One workgroup = one row segment of 64 pixels; the L tile and
+// the R tile (64 + D - 1 pixels) are read once from HBM/L2 with coalesced 16 B loads and
+// transposed into LDS as [c][x] (row length = 1 mod 32 -> conflict-free strided writes), so the
+// c-loop reads are lane-contiguous.  Lane = (disparity group dg = lane/16, pixel = lane%16): each
+// lane keeps DG = ceil(D/4) accumulators in registers; the per-pixel soft-argmin partials
+// (max, sum e, sum d*e) of the 4 disparity groups are merged with wavefront shuffles
+// (__shfl_xor 16, 32), so the D x H x W volume is only written when the caller asks for it.
+#include <algorithm>
+
+#include "st_common.h"
+
+namespace st {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float cv_expf(float x) {  // same polynomial as decode_nms.hip / oracle
+  if (x > 88.72283f) return __builtin_inff();
+  if (x < -103.0f) return 0.0f;
+  const float n = rintf(x * 1.44269504088896341f);
+  float r = fmaf(n, -0.693359375f, x);
+  r = fmaf(n, 2.12194440e-4f, r);
+  float p = 1.9875691500e-4f;
+  p = fmaf(p, r, 1.3981999507e-3f);
+  p = fmaf(p, r, 8.3334519073e-3f);
+  p = fmaf(p, r, 4.1665795894e-2f);
+  p = fmaf(p, r, 1.6666665459e-1f);
+  p = fmaf(p, r, 5.0000001201e-1f);
+  const float r2 = r * r;
+  p = fmaf(p, r2, r);
+  p = p + 1.0f;
+  return ldexpf(p, (int)n);
+}
+
+constexpr int CV_TX = 64;     // pixels per workgroup
+constexpr int CV_MAXDG = 64;  // accumulators per lane (D <= 256)
+
+template <int DG>
+__global__ __launch_bounds__(256) void costvolume_kernel(const float* __restrict__ featL,
+                                                         const float* __restrict__ featR, int Hf, int Wf,
+                                                         int C, int ld, int D, float temperature,
+                                                         int rowL, int rowR, float* __restrict__ out_cost,
+                                                         float* __restrict__ out_disp) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* Ls = smem;             // [C][rowL]
+  float* Rs = smem + C * rowL;  // [C][rowR], column j <-> x' = x0 - (D-1) + j
+  const int x0 = blockIdx.x * CV_TX;
+  const int y = blockIdx.y, n = blockIdx.z;
+  const size_t rowbase = ((size_t)n * Hf + y) * Wf;
+  const int tid = threadIdx.x;
+  const int C4 = C >> 2;
+
+  // ---- stage + transpose: coalesced float4 global reads (lanes along c), strided LDS writes
+  for (int e = tid; e < CV_TX * C4; e += 256) {
+    const int px = e / C4, c4 = e - px * C4;
+    const int x = x0 + px;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (x < Wf) v = *reinterpret_cast<const f32x4*>(featL + (rowbase + x) * ld + 4 * c4);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) Ls[(4 * c4 + k) * rowL + px] = v[k];
+  }
+  const int RW = CV_TX + D - 1;
+  for (int e = tid; e < RW * C4; e += 256) {
+    const int j = e / C4, c4 = e - j * C4;
+    const int x = x0 - (D - 1) + j;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (x >= 0 && x < Wf) v = *reinterpret_cast<const f32x4*>(featR + (rowbase + x) * ld + 4 * c4);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) Rs[(4 * c4 + k) * rowR + j] = v[k];
+  }
+  __syncthreads();
+
+  const int lane = tid & 63, wave = tid >> 6;
+  const int dg = lane >> 4;
+  const int px = wave * 16 + (lane & 15);
+  const int x = x0 + px;
+  const int d0 = dg * DG;
+  float acc[DG];
+#pragma unroll
+  for (int k = 0; k < DG; ++k) acc[k] = 0.f;
+  // Rs column of (x, d) is px + (D-1) - d; for this lane d = d0 + k
+  const float* lp = Ls + px;
+  const float* rp = Rs + px + (D - 1) - d0;
+  for (int c = 0; c < C; ++c) {
+    const float a = lp[c * rowL];
+    const float* rr = rp + c * rowR;
+#pragma unroll
+    for (int k = 0; k < DG; ++k) acc[k] = fmaf(a, rr[-k], acc[k]);  // rr[-k] is >= Rs row start while d0+k < D
+  }
+  const float fC = (float)C;
+  float m = -__builtin_inff();
+#pragma unroll
+  for (int k = 0; k < DG; ++k) {
+    const int d = d0 + k;
+    float cst = acc[k] / fC;
+    if (x - d < 0) cst = 0.f;
+    acc[k] = cst;
+    if (d < D) m = fmaxf(m, temperature * cst);
+  }
+  if (out_cost && x < Wf) {
+    float* oc = out_cost + (rowbase + x) * (size_t)D + d0;
+#pragma unroll
+    for (int k = 0; k < DG; ++k)
+      if (d0 + k < D) oc[k] = acc[k];
+  }
+  // soft-argmin: merge (max, sum e, sum d*e) over the 4 disparity groups with shuffles
+  m = fmaxf(m, __shfl_xor(m, 16));
+  m = fmaxf(m, __shfl_xor(m, 32));
+  float s = 0.f, t = 0.f;
+#pragma unroll
+  for (int k = 0; k < DG; ++k) {
+    const int d = d0 + k;
+    if (d < D) {
+      const float e = cv_expf(temperature * acc[k] - m);
+      s += e;
+      t = fmaf((float)d, e, t);
+    }
+  }
+  s += __shfl_xor(s, 16); t += __shfl_xor(t, 16);
+  s += __shfl_xor(s, 32); t += __shfl_xor(t, 32);
+  if (dg == 0 && x < Wf && out_disp) out_disp[rowbase + x] = t / s;
+}
+
+__global__ __launch_bounds__(256) void softargmin_kernel(const float* __restrict__ cost, long long npix, int D,
+                                                         float temperature, float* __restrict__ out_disp) {
+  for (long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x; p < npix;
+       p += (long long)gridDim.x * blockDim.x) {
+    const float* c = cost + p * D;
+    float m = -__builtin_inff();
+    for (int d = 0; d < D; ++d) m = fmaxf(m, temperature * c[d]);
+    float s = 0.f, t = 0.f;
+    for (int d = 0; d < D; ++d) {
+      const float e = cv_expf(temperature * c[d] - m);
+      s += e;
+      t = fmaf((float)d, e, t);
+    }
+    out_disp[p] = t / s;
+  }
+}
+
+// bilinear x`scale` (align_corners=False, PyTorch area_pixel_compute_source_index), times scale,
+// zero outside (valid_h, valid_w), replicated to 3 channels NCHW.
+__global__ __launch_bounds__(256) void disp_upsample_pack_kernel(const float* __restrict__ lr, int N, int Hf, int Wf,
+                                                                 int scale, int H, int W, int valid_h, int valid_w,
+                                                                 float* __restrict__ out) {
+  const long long total = (long long)N * H * W;
+  const float inv = 1.0f / (float)scale;
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (long long)gridDim.x * blockDim.x) {
+    const int X = (int)(idx % W);
+    const long long t = idx / W;
+    const int Y = (int)(t % H);
+    const int n = (int)(t / H);
+    float v = 0.f;
+    if (Y < valid_h && X < valid_w) {
+      float sy = ((float)Y + 0.5f) * inv - 0.5f;
+      float sx = ((float)X + 0.5f) * inv - 0.5f;
+      sy = sy < 0.f ? 0.f : sy;
+      sx = sx < 0.f ? 0.f : sx;
+      const int y0 = min((int)sy, Hf - 1), x0 = min((int)sx, Wf - 1);
+      const int y1 = min(y0 + 1, Hf - 1), x1 = min(x0 + 1, Wf - 1);
+      const float ly = sy - (float)y0, lx = sx - (float)x0;
+      const float hy = 1.0f - ly, hx = 1.0f - lx;
+      const float* b = lr + (size_t)n * Hf * Wf;
+      const float v00 = b[(size_t)y0 * Wf + x0], v01 = b[(size_t)y0 * Wf + x1];
+      const float v10 = b[(size_t)y1 * Wf + x0], v11 = b[(size_t)y1 * Wf + x1];
+      v = (hy * (hx * v00 + lx * v01) + ly * (hx * v10 + lx * v11)) * (float)scale;
+    }
+    const size_t plane = (size_t)H * W;
+    float* o = out + (size_t)n * 3 * plane + (size_t)Y * W + X;
+    o[0] = v;
+    o[plane] = v;
+    o[2 * plane] = v;
+  }
+}
+
+static int row_len(int n) { return ((n + 30) / 32) * 32 + 1; }  // >= n, = 1 mod 32
+
+}  // namespace st
+
+extern "C" int st_costvolume_softargmin(const float* featL_dev, const float* featR_dev, int N, int Hf, int Wf,
+                                        int C, int feat_ld, int D, float temperature, float* out_cost_dev,
+                                        float* out_disp_dev, st_stream_t stream_) {
+  using namespace st;
+  ST_REQUIRE(featL_dev && featR_dev && (out_cost_dev || out_disp_dev), "st_costvolume_softargmin: null pointer");
+  ST_REQUIRE(N > 0 && Hf > 0 && Wf > 0 && C > 0 && C % 4 == 0 && feat_ld % 4 == 0 && feat_ld >= C,
+             "st_costvolume_softargmin: C and feat_ld must be positive multiples of 4");
+  ST_REQUIRE(D > 0 && D <= 4 * CV_MAXDG, "st_costvolume_softargmin: D must be in [1, %d]", 4 * CV_MAXDG);
+  ST_REQUIRE(Hf <= 65535 && N <= 65535, "st_costvolume_softargmin: grid too large");
+  const int rowL = row_len(CV_TX), rowR = row_len(CV_TX + D - 1);
+  const size_t lds = (size_t)C * (rowL + rowR) * sizeof(float);
+  ST_REQUIRE(lds <= 160 * 1024, "st_costvolume_softargmin: C=%d, D=%d needs %zu B of LDS (> 160 KiB)", C, D, lds);
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  const dim3 grid((Wf + CV_TX - 1) / CV_TX, Hf, N), block(256);
+  const int DG = (D + 3) / 4;
+#define ST_CV_LAUNCH(DGV)                                                                                      \
+  do {                                                                                                         \
+    auto kern = costvolume_kernel<DGV>;                                                                        \
+    ST_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                                      \
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                   \
+    hipLaunchKernelGGL(kern, grid, block, lds, stream, featL_dev, featR_dev, Hf, Wf, C, feat_ld, D,            \
+                       temperature, rowL, rowR, out_cost_dev, out_disp_dev);                                   \
+  } while (0)
+  if (DG <= 4) ST_CV_LAUNCH(4);
+  else if (DG <= 8) ST_CV_LAUNCH(8);
+  else if (DG <= 12) ST_CV_LAUNCH(12);
+  else if (DG <= 16) ST_CV_LAUNCH(16);
+  else if (DG <= 24) ST_CV_LAUNCH(24);
+  else if (DG <= 32) ST_CV_LAUNCH(32);
+  else if (DG <= 48) ST_CV_LAUNCH(48);
+  else ST_CV_LAUNCH(64);
+#undef ST_CV_LAUNCH
+  ST_CHECK_HIP(hipGetLastError());
+  return ST_OK;
+}
+
+extern "C" int st_softargmin(const float* cost_dev, int N, int Hf, int Wf, int D, float temperature,
+                             float* out_disp_dev, st_stream_t stream_) {
+  using namespace st;
+  ST_REQUIRE(cost_dev && out_disp_dev && N > 0 && Hf > 0 && Wf > 0 && D > 0, "st_softargmin: bad argument");
+  const long long npix = (long long)N * Hf * Wf;
+  const int blocks = (int)std::min<long long>((npix + 255) / 256, 256 * 8);
+  hipLaunchKernelGGL(softargmin_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream_), cost_dev,
+                     npix, D, temperature, out_disp_dev);
+  ST_CHECK_HIP(hipGetLastError());
+  return ST_OK;
+}
+
+extern "C" int st_disp_upsample_pack(const float* disp_lr_dev, int N, int Hf, int Wf, int scale, int H, int W,
+                                     int valid_h, int valid_w, float* disp_postp_dev, st_stream_t stream_) {
+  using namespace st;
+  ST_REQUIRE(disp_lr_dev && disp_postp_dev, "st_disp_upsample_pack: null pointer");
+  ST_REQUIRE(N > 0 && Hf > 0 && Wf > 0 && scale > 0 && H == Hf * scale && W == Wf * scale,
+             "st_disp_upsample_pack: output must be exactly scale x the low-res map");
+  ST_REQUIRE(valid_h >= 0 && valid_h <= H && valid_w >= 0 && valid_w <= W, "st_disp_upsample_pack: bad valid region");
+  const long long total = (long long)N * H * W;
+  const int blocks = (int)std::min<long long>((total + 255) / 256, 256 * 16);
+  hipLaunchKernelGGL(disp_upsample_pack_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream_),
+                     disp_lr_dev, N, Hf, Wf, scale, H, W, valid_h, valid_w, disp_postp_dev);
+  ST_CHECK_HIP(hipGetLastError());
+  return ST_OK;
+}

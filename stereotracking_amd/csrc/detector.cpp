@@ -1,0 +1,576 @@
+// Graph builder + executor for the two-branch YOLOX-s detector
+// (CSPDarknet RGB/disparity branches -> PAFPN -> decoupled head).
+//
+// Restates, as a static launch plan of fused HIP convolutions, what the reference builds
+// from Python modules:
+//   backbone  mmtrack/models/backbones/csp_darknet_disparity_v1.py:71-206
+//             (+ base class det_backbone/base_backbone_disparity_mmyolo.py:76-119)
+//   detector  mmtrack/models/detectors/yolo_detector_disparity_v1.py:77-142
+//   neck/head mmyolo 0.2.0 YOLOXPAFPN / YOLOXHeadModule (un-vendored),
+//             configured at configs/_base_/yolox_s_8x8_mmyolo.py:30-51.
+// Parameter names are the reference state_dict keys so checkpoints load unchanged.
+//
+// Fusions (each line = ONE conv launch):
+//   * ConvModule = conv + folded BN + SiLU
+//   * CSPLayer main_conv + short_conv (same input)      -> one conv, split store
+//   * bottleneck residual add                            -> epilogue
+//   * channel concat (CSP, PAFPN)                        -> channel-offset stores into the cat buffer
+//   * PAFPN nearest x2 upsample                          -> replicated epilogue store
+//   * branch average (rgb + disp)/2                      -> epilogue of disp_stage1's final conv
+//   * head cls-tower conv0 + reg-tower conv0             -> one conv, split store
+//   * head conv_reg + conv_obj                           -> one conv
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <vector>
+
+#include "st_common.h"
+
+namespace st {
+
+int conv2d_launch(const StConvDesc& d, hipStream_t stream, int force_variant);
+int focus_pack_launch(const float* img, int N, int C, int H, int W, float* out, hipStream_t stream);
+int spp_pool_launch(const float* x, int x_ld, int x_off, int N, int H, int W, int C, float* out,
+                    int out_ld, int out_off, hipStream_t stream);
+
+namespace {
+
+int make_divisible(double x, double widen) { return (int)std::ceil(x * widen / 8.0) * 8; }
+int make_round(int n, double deepen) {
+  if (n <= 1) return n;
+  // python round() = banker's rounding; x.5 never occurs for the shipped factors but keep it exact
+  const double v = n * deepen;
+  double r = std::nearbyint(v);
+  return std::max((int)r, 1);
+}
+
+struct Param {
+  std::string name;
+  std::vector<int64_t> shape;
+  std::vector<float> data;
+  bool set = false;
+  int64_t numel() const {
+    int64_t n = 1;
+    for (auto s : shape) n *= s;
+    return n;
+  }
+};
+
+struct ConvSrc {
+  std::string conv_prefix;  // "<p>.conv" for ConvModule, "<p>" for a bare Conv2d
+  std::string bn_prefix;    // "" = no BN
+  bool has_bias;
+  int cout;
+};
+
+struct PackedConv {
+  std::vector<ConvSrc> srcs;
+  int cin = 0, k = 1, cout = 0;
+  size_t wgt_off = 0, bias_off = 0;  // float offsets inside the packed weight arena
+};
+
+constexpr int BUF_HEAD = -2;   // caller's head_out buffer
+constexpr int BUF_NONE = -1;
+
+struct TRef {  // a channel slice of an NHWC buffer
+  int buf = BUF_NONE;
+  int N = 0, H = 0, W = 0, C = 0;
+  int ld = 0, off = 0;
+  size_t base = 0;  // extra float offset inside the buffer (head levels)
+  bool valid() const { return buf != BUF_NONE; }
+  TRef slice(int o, int c) const {
+    TRef t = *this;
+    t.off = off + o;
+    t.C = c;
+    return t;
+  }
+};
+
+struct Op {
+  enum Type { FOCUS, CONV, SPP } type;
+  // FOCUS: src input index (0 = img/left, 1 = disp, 2 = right), dst tensor, dst batch offset
+  int focus_input = 0;
+  int focus_batch_off = 0;
+  // CONV
+  int pc = -1;
+  TRef in, out1, out2, up, res;
+  int split = 0, stride = 1, pad = 0, act = 1;
+  float post_scale = 1.f;
+  // SPP uses in (x) and out1 (cat buffer, x lives in its first C channels)
+  int phase = 0;
+};
+
+}  // namespace
+
+}  // namespace st
+
+using namespace st;
+
+struct StDetector {
+  StDetectorConfig cfg{};
+  std::vector<Param> params;
+  std::map<std::string, int> pindex;
+  std::vector<PackedConv> convs;
+  std::vector<Op> ops;
+  std::vector<size_t> buf_off;  // float offsets of workspace buffers
+  size_t ws_floats = 0;
+  size_t wgt_floats = 0;
+  float* wgt_dev = nullptr;
+  bool finalized = false;
+  double macs = 0.0;
+  // head
+  int n_levels = 3;
+  int lvl_h[3]{}, lvl_w[3]{}, lvl_stride[3]{};
+  size_t lvl_off[3]{};
+  size_t head_floats = 0;
+  std::map<std::string, TRef> taps;
+  int cur_phase = 0;
+
+  // ---- building blocks -------------------------------------------------------------------
+  int add_param(const std::string& name, std::vector<int64_t> shape) {
+    Param p;
+    p.name = name;
+    p.shape = std::move(shape);
+    params.push_back(std::move(p));
+    pindex[name] = (int)params.size() - 1;
+    return (int)params.size() - 1;
+  }
+  void declare_convmodule(const std::string& p, int cin, int cout, int k) {
+    if (pindex.count(p + ".conv.weight")) return;  // shared weights (right branch)
+    add_param(p + ".conv.weight", {cout, cin, k, k});
+    add_param(p + ".bn.weight", {cout});
+    add_param(p + ".bn.bias", {cout});
+    add_param(p + ".bn.running_mean", {cout});
+    add_param(p + ".bn.running_var", {cout});
+  }
+  void declare_conv2d(const std::string& p, int cin, int cout, int k) {
+    add_param(p + ".weight", {cout, cin, k, k});
+    add_param(p + ".bias", {cout});
+  }
+  int new_buf(int N, int H, int W, int ld) {
+    buf_off.push_back(ws_floats);
+    ws_floats += (size_t)N * H * W * ld;
+    ws_floats = (ws_floats + 63) & ~(size_t)63;  // 256 B alignment
+    return (int)buf_off.size() - 1;
+  }
+  TRef new_tensor(int N, int H, int W, int C) {
+    TRef t;
+    t.buf = new_buf(N, H, W, C);
+    t.N = N; t.H = H; t.W = W; t.C = C; t.ld = C; t.off = 0;
+    return t;
+  }
+  // ConvModule(s) sharing one input, fused along Cout
+  int packed_convmodules(const std::vector<std::string>& prefixes, int cin, const std::vector<int>& couts, int k) {
+    // reuse when the same single prefix was packed before (right branch shares weights)
+    PackedConv pc;
+    pc.cin = cin; pc.k = k;
+    for (size_t i = 0; i < prefixes.size(); ++i) {
+      declare_convmodule(prefixes[i], cin, couts[i], k);
+      pc.srcs.push_back({prefixes[i] + ".conv", prefixes[i] + ".bn", false, couts[i]});
+      pc.cout += couts[i];
+    }
+    convs.push_back(pc);
+    return (int)convs.size() - 1;
+  }
+  int packed_conv2d(const std::vector<std::string>& prefixes, int cin, const std::vector<int>& couts) {
+    PackedConv pc;
+    pc.cin = cin; pc.k = 1;
+    for (size_t i = 0; i < prefixes.size(); ++i) {
+      declare_conv2d(prefixes[i], cin, couts[i], 1);
+      pc.srcs.push_back({prefixes[i], "", true, couts[i]});
+      pc.cout += couts[i];
+    }
+    convs.push_back(pc);
+    return (int)convs.size() - 1;
+  }
+  void op_conv(int pc, const TRef& in, int stride, const TRef& out1, int split = -1,
+               const TRef& out2 = TRef(), const TRef& up = TRef(), const TRef& res = TRef(),
+               float post_scale = 1.f, int act = 1) {
+    Op o;
+    o.type = Op::CONV;
+    o.pc = pc; o.in = in; o.out1 = out1; o.out2 = out2; o.up = up; o.res = res;
+    o.split = split < 0 ? convs[pc].cout : split;
+    o.stride = stride; o.pad = convs[pc].k / 2; o.act = act; o.post_scale = post_scale;
+    o.phase = cur_phase;
+    ops.push_back(o);
+    const int Ho = (in.H + 2 * o.pad - convs[pc].k) / stride + 1;
+    const int Wo = (in.W + 2 * o.pad - convs[pc].k) / stride + 1;
+    macs += (double)in.N * Ho * Wo * convs[pc].k * convs[pc].k * convs[pc].cin * convs[pc].cout;
+  }
+  // ConvModule helper: allocates the output unless `out` is given
+  TRef convmodule(const std::string& p, const TRef& in, int cout, int k, int stride, TRef out = TRef()) {
+    const int pc = packed_convmodules({p}, in.C, {cout}, k);
+    if (!out.valid()) {
+      const int pad = k / 2;
+      out = new_tensor(in.N, (in.H + 2 * pad - k) / stride + 1, (in.W + 2 * pad - k) / stride + 1, cout);
+    }
+    op_conv(pc, in, stride, out);
+    return out;
+  }
+  // mmdet CSPLayer(cin, cout, n, add_identity), expand_ratio 0.5.  `out` = destination slice of
+  // final_conv; res/post_scale/up decorate the final conv's epilogue.
+  TRef csp_layer(const std::string& p, const TRef& x, int cout, int nblocks, bool identity,
+                 TRef out = TRef(), const TRef& res = TRef(), float post_scale = 1.f,
+                 const TRef& up = TRef()) {
+    const int mid = cout / 2;
+    TRef cat = new_tensor(x.N, x.H, x.W, 2 * mid);
+    TRef mainb = new_tensor(x.N, x.H, x.W, mid);
+    const int pc = packed_convmodules({p + ".main_conv", p + ".short_conv"}, x.C, {mid, mid}, 1);
+    op_conv(pc, x, 1, mainb, mid, cat.slice(mid, mid));
+    TRef tmp = new_tensor(x.N, x.H, x.W, mid);
+    for (int b = 0; b < nblocks; ++b) {
+      const std::string bp = p + ".blocks." + std::to_string(b);
+      const int pc1 = packed_convmodules({bp + ".conv1"}, mid, {mid}, 1);
+      op_conv(pc1, mainb, 1, tmp);
+      const int pc2 = packed_convmodules({bp + ".conv2"}, mid, {mid}, 3);
+      const bool last = b == nblocks - 1;
+      op_conv(pc2, tmp, 1, last ? cat.slice(0, mid) : mainb, -1, TRef(), TRef(),
+              identity ? mainb : TRef(), 1.f);
+    }
+    if (!out.valid()) out = new_tensor(x.N, x.H, x.W, cout);
+    const int pcf = packed_convmodules({p + ".final_conv"}, 2 * mid, {cout}, 1);
+    op_conv(pcf, cat, 1, out, -1, TRef(), up, res, post_scale);
+    return out;
+  }
+
+  int build();
+};
+
+int StDetector::build() {
+  const double w = cfg.widen_factor, dpt = cfg.deepen_factor;
+  const int N = cfg.batch, H = cfg.height, W = cfg.width;
+  const bool stereo = cfg.with_right_branch != 0;
+  const int c1 = make_divisible(64, w), c2 = make_divisible(128, w), c3 = make_divisible(256, w),
+            c4 = make_divisible(512, w), c5 = make_divisible(1024, w);
+  const int n1 = make_round(3, dpt), n2 = make_round(9, dpt), n3 = make_round(9, dpt),
+            n4 = make_round(3, dpt), nn = make_round(3, dpt);
+  const int H2 = H / 2, W2 = W / 2, H4 = H / 4, W4 = W / 4, H8 = H / 8, W8 = W / 8, H16 = H / 16,
+            W16 = W / 16, H32 = H / 32, W32 = W / 32;
+  (void)H4; (void)W4;
+
+  // neck concat buffers first: backbone stage outputs are stored straight into them
+  TRef catTD0 = new_tensor(N, H16, W16, 2 * c4);  // [up(r2) | C4]
+  TRef catTD1 = new_tensor(N, H8, W8, 2 * c3);    // [up(t2) | C3]
+  TRef catBU0 = new_tensor(N, H16, W16, 2 * c3);  // [down(P3') | t2]
+  TRef catBU1 = new_tensor(N, H32, W32, 2 * c4);  // [down(P4') | r2]
+
+  // ---- phase 0: RGB branch stem + stage1 (left, and right when stereo: same weights, batch 2N)
+  cur_phase = 0;
+  const int NB = stereo ? 2 * N : N;
+  TRef packed_rgb = new_tensor(NB, H2, W2, 12);
+  {
+    Op f; f.type = Op::FOCUS; f.focus_input = 0; f.out1 = packed_rgb; f.focus_batch_off = 0; f.phase = 0;
+    ops.push_back(f);
+    if (stereo) {
+      Op g = f; g.focus_input = 2; g.focus_batch_off = N;
+      ops.push_back(g);
+    }
+  }
+  TRef stem = convmodule("backbone.stem.conv", packed_rgb, c1, 3, 1);
+  TRef s1c = convmodule("backbone.stage1.0", stem, c2, 3, 2);
+  TRef s1 = csp_layer("backbone.stage1.1", s1c, c2, n1, true);
+  taps["stage1_rgb"] = s1;
+
+  // ---- phase 1: disparity branch + everything after the fusion
+  cur_phase = 1;
+  TRef s1_left = s1;
+  s1_left.N = N;  // first N images of the stacked batch
+  TRef packed_disp = new_tensor(N, H2, W2, 12);
+  {
+    Op f; f.type = Op::FOCUS; f.focus_input = 1; f.out1 = packed_disp; f.focus_batch_off = 0; f.phase = 1;
+    ops.push_back(f);
+  }
+  TRef dstem = convmodule("backbone.disp_stem.conv", packed_disp, c1, 3, 1);
+  TRef d1c = convmodule("backbone.disp_stage1.0", dstem, c2, 3, 2);
+  // y = (o_stem + o_disp_stem) / 2   (csp_darknet_disparity_v1.py:184)
+  TRef y = csp_layer("backbone.disp_stage1.1", d1c, c2, n1, true, TRef(), s1_left, 0.5f);
+  taps["stage1_fused"] = y;
+
+  TRef s2c = convmodule("backbone.stage2.0", y, c3, 3, 2);
+  TRef C3 = csp_layer("backbone.stage2.1", s2c, c3, n2, true, catTD1.slice(c3, c3));
+  taps["stage2"] = C3;
+  TRef s3c = convmodule("backbone.stage3.0", C3, c4, 3, 2);
+  TRef C4 = csp_layer("backbone.stage3.1", s3c, c4, n3, true, catTD0.slice(c4, c4));
+  taps["stage3"] = C4;
+  TRef s4c = convmodule("backbone.stage4.0", C4, c5, 3, 2);
+  // SPPFBottleneck(c5, c5, kernel_sizes=(5,9,13)): conv1 c5->c5/2, cat 4x, conv2 2*c5->c5
+  TRef sppcat = new_tensor(N, H32, W32, 2 * c5);
+  convmodule("backbone.stage4.1.conv1", s4c, c5 / 2, 1, 1, sppcat.slice(0, c5 / 2));
+  {
+    Op o; o.type = Op::SPP; o.in = sppcat.slice(0, c5 / 2); o.out1 = sppcat; o.phase = 1;
+    ops.push_back(o);
+  }
+  TRef spp = convmodule("backbone.stage4.1.conv2", sppcat, c5, 1, 1);
+  TRef C5 = csp_layer("backbone.stage4.2", spp, c5, n4, false);
+  taps["stage4"] = C5;
+
+  // ---- neck: YOLOXPAFPN(in=[c3,c4,c5], out=c3)
+  const int outc = make_divisible(256, w);
+  {
+    // r2 = reduce_layers.2 : c5 -> c4, stored into catBU1[c4:] and x2-upsampled into catTD0[:c4]
+    const int pc = packed_convmodules({"neck.reduce_layers.2"}, c5, {c4}, 1);
+    op_conv(pc, C5, 1, catBU1.slice(c4, c4), -1, TRef(), catTD0.slice(0, c4));
+  }
+  // top_down_layers.0 = Sequential(CSP(2*c4 -> c4), ConvModule(c4 -> c3, 1))
+  TRef td0 = csp_layer("neck.top_down_layers.0.0", catTD0, c4, nn, false);
+  {
+    const int pc = packed_convmodules({"neck.top_down_layers.0.1"}, c4, {c3}, 1);
+    op_conv(pc, td0, 1, catBU0.slice(c3, c3), -1, TRef(), catTD1.slice(0, c3));  // t2
+  }
+  TRef P3 = csp_layer("neck.top_down_layers.1", catTD1, c3, nn, false);
+  taps["p3_inner"] = P3;
+  convmodule("neck.downsample_layers.0", P3, c3, 3, 2, catBU0.slice(0, c3));
+  TRef P4 = csp_layer("neck.bottom_up_layers.0", catBU0, c4, nn, false);
+  convmodule("neck.downsample_layers.1", P4, c4, 3, 2, catBU1.slice(0, c4));
+  TRef P5 = csp_layer("neck.bottom_up_layers.1", catBU1, c5, nn, false);
+  TRef F[3];
+  F[0] = convmodule("neck.out_layers.0", P3, outc, 1, 1);
+  F[1] = convmodule("neck.out_layers.1", P4, outc, 1, 1);
+  F[2] = convmodule("neck.out_layers.2", P5, outc, 1, 1);
+  taps["p3"] = F[0]; taps["p4"] = F[1]; taps["p5"] = F[2];
+
+  // ---- head: YOLOXHeadModule(in=outc, feat=outc, stacked_convs=2)
+  const int feat = make_divisible(256, w);
+  const int nc = cfg.num_classes;
+  ST_REQUIRE(nc >= 1 && nc + 5 <= 8, "detector: num_classes must be in [1,3] (head row = 8 floats)");
+  const std::string hp = "bbox_head.head_module.";
+  head_floats = 0;
+  for (int l = 0; l < 3; ++l) {
+    lvl_h[l] = F[l].H; lvl_w[l] = F[l].W; lvl_stride[l] = 8 << l;
+    lvl_off[l] = head_floats;
+    head_floats += (size_t)N * F[l].H * F[l].W * 8;
+  }
+  for (int l = 0; l < 3; ++l) {
+    const std::string ls = std::to_string(l);
+    TRef t0 = new_tensor(N, F[l].H, F[l].W, 2 * feat);  // [cls_feat0 | reg_feat0]
+    const int pc0 = packed_convmodules({hp + "multi_level_cls_convs." + ls + ".0",
+                                        hp + "multi_level_reg_convs." + ls + ".0"},
+                                       outc, {feat, feat}, 3);
+    op_conv(pc0, F[l], 1, t0);
+    TRef clsf = convmodule(hp + "multi_level_cls_convs." + ls + ".1", t0.slice(0, feat), feat, 3, 1);
+    TRef regf = convmodule(hp + "multi_level_reg_convs." + ls + ".1", t0.slice(feat, feat), feat, 3, 1);
+    TRef ho;
+    ho.buf = BUF_HEAD; ho.N = N; ho.H = F[l].H; ho.W = F[l].W; ho.ld = 8; ho.base = lvl_off[l];
+    const int pcc = packed_conv2d({hp + "multi_level_conv_cls." + ls}, feat, {nc});
+    op_conv(pcc, clsf, 1, ho.slice(0, nc), -1, TRef(), TRef(), TRef(), 1.f, /*act=*/0);
+    const int pcr = packed_conv2d({hp + "multi_level_conv_reg." + ls, hp + "multi_level_conv_obj." + ls},
+                                  feat, {4, 1});
+    op_conv(pcr, regf, 1, ho.slice(nc, 5), -1, TRef(), TRef(), TRef(), 1.f, /*act=*/0);
+  }
+
+  // packed weight arena layout
+  wgt_floats = 0;
+  for (auto& pc : convs) {
+    pc.wgt_off = wgt_floats;
+    wgt_floats += (size_t)round_up(pc.cout, 32) * round_up(pc.k * pc.k * pc.cin, 32);
+    pc.bias_off = wgt_floats;
+    wgt_floats += round_up(pc.cout, 32);
+    wgt_floats = (wgt_floats + 63) & ~(size_t)63;
+  }
+  return ST_OK;
+}
+
+extern "C" int st_detector_create(const StDetectorConfig* cfg, StDetector** out) {
+  if (!cfg || !out) return set_error(ST_ERR_INVALID, "st_detector_create: null argument");
+  ST_REQUIRE(cfg->struct_size == (int)sizeof(StDetectorConfig), "st_detector_create: struct_size mismatch (%d vs %zu)",
+             cfg->struct_size, sizeof(StDetectorConfig));
+  ST_REQUIRE(cfg->batch > 0 && cfg->height > 0 && cfg->width > 0 && cfg->height % 32 == 0 && cfg->width % 32 == 0,
+             "st_detector_create: height/width must be positive multiples of 32 (got %dx%d)", cfg->height, cfg->width);
+  ST_REQUIRE(cfg->widen_factor > 0 && cfg->deepen_factor > 0, "st_detector_create: bad widen/deepen factor");
+  auto det = std::make_unique<StDetector>();
+  det->cfg = *cfg;
+  if (det->cfg.bn_eps <= 0) det->cfg.bn_eps = 1e-3;
+  ST_CHECK(det->build());
+  *out = det.release();
+  return ST_OK;
+}
+
+extern "C" int st_detector_destroy(StDetector* det) {
+  if (!det) return ST_OK;
+  if (det->wgt_dev) (void)hipFree(det->wgt_dev);
+  delete det;
+  return ST_OK;
+}
+
+extern "C" int st_detector_num_params(const StDetector* det) { return det ? (int)det->params.size() : 0; }
+
+extern "C" int st_detector_param_info(const StDetector* det, int idx, char* name, int name_cap,
+                                      int64_t shape[4], int* ndim) {
+  if (!det || idx < 0 || idx >= (int)det->params.size())
+    return set_error(ST_ERR_INVALID, "st_detector_param_info: bad index %d", idx);
+  const Param& p = det->params[idx];
+  if (name && name_cap > 0) {
+    std::strncpy(name, p.name.c_str(), (size_t)name_cap - 1);
+    name[name_cap - 1] = 0;
+  }
+  if (ndim) *ndim = (int)p.shape.size();
+  if (shape)
+    for (size_t i = 0; i < 4; ++i) shape[i] = i < p.shape.size() ? p.shape[i] : 1;
+  return ST_OK;
+}
+
+extern "C" int st_detector_set_param(StDetector* det, const char* name, const float* host, int64_t numel) {
+  if (!det || !name || !host) return set_error(ST_ERR_INVALID, "st_detector_set_param: null argument");
+  auto it = det->pindex.find(name);
+  if (it == det->pindex.end()) return set_error(ST_ERR_NOTFOUND, "st_detector_set_param: unknown parameter '%s'", name);
+  Param& p = det->params[it->second];
+  ST_REQUIRE(numel == p.numel(), "st_detector_set_param: '%s' expects %lld values, got %lld", name,
+             (long long)p.numel(), (long long)numel);
+  p.data.assign(host, host + numel);
+  p.set = true;
+  det->finalized = false;
+  return ST_OK;
+}
+
+extern "C" int st_detector_finalize(StDetector* det) {
+  if (!det) return set_error(ST_ERR_INVALID, "st_detector_finalize: null detector");
+  for (const Param& p : det->params)
+    if (!p.set) return set_error(ST_ERR_STATE, "st_detector_finalize: parameter '%s' was never set", p.name.c_str());
+  std::vector<float> host(det->wgt_floats, 0.f);
+  auto get = [&](const std::string& n) -> const float* { return det->params[det->pindex.at(n)].data.data(); };
+  for (const PackedConv& pc : det->convs) {
+    const int Kpad = round_up(pc.k * pc.k * pc.cin, 32);
+    int row = 0;
+    for (const ConvSrc& s : pc.srcs) {
+      const size_t nf = st_conv_packed_floats(s.cout, pc.cin, pc.k, pc.k);
+      std::vector<float> wtmp(nf), btmp(round_up(s.cout, 32));
+      const bool bn = !s.bn_prefix.empty();
+      ST_CHECK(st_conv_pack_weights(get(s.conv_prefix + ".weight"), s.has_bias ? get(s.conv_prefix + ".bias") : nullptr,
+                                    bn ? get(s.bn_prefix + ".weight") : nullptr, bn ? get(s.bn_prefix + ".bias") : nullptr,
+                                    bn ? get(s.bn_prefix + ".running_mean") : nullptr,
+                                    bn ? get(s.bn_prefix + ".running_var") : nullptr, det->cfg.bn_eps, s.cout, pc.cin,
+                                    pc.k, pc.k, wtmp.data(), btmp.data()));
+      std::memcpy(host.data() + pc.wgt_off + (size_t)row * Kpad, wtmp.data(), sizeof(float) * (size_t)s.cout * Kpad);
+      std::memcpy(host.data() + pc.bias_off + row, btmp.data(), sizeof(float) * (size_t)s.cout);
+      row += s.cout;
+    }
+  }
+  if (!det->wgt_dev) ST_CHECK_HIP(hipMalloc(reinterpret_cast<void**>(&det->wgt_dev), det->wgt_floats * sizeof(float)));
+  ST_CHECK_HIP(hipMemcpy(det->wgt_dev, host.data(), det->wgt_floats * sizeof(float), hipMemcpyHostToDevice));
+  det->finalized = true;
+  return ST_OK;
+}
+
+extern "C" size_t st_detector_workspace_bytes(const StDetector* det) { return det ? det->ws_floats * sizeof(float) : 0; }
+extern "C" size_t st_detector_head_floats(const StDetector* det) { return det ? det->head_floats : 0; }
+extern "C" int st_detector_num_levels(const StDetector* det) { return det ? det->n_levels : 0; }
+extern "C" double st_detector_macs(const StDetector* det) { return det ? det->macs : 0.0; }
+
+extern "C" int st_detector_level_info(const StDetector* det, int level, int* h, int* w, int* stride,
+                                      size_t* float_offset) {
+  if (!det || level < 0 || level >= det->n_levels) return set_error(ST_ERR_INVALID, "st_detector_level_info: bad level");
+  if (h) *h = det->lvl_h[level];
+  if (w) *w = det->lvl_w[level];
+  if (stride) *stride = det->lvl_stride[level];
+  if (float_offset) *float_offset = det->lvl_off[level];
+  return ST_OK;
+}
+
+namespace {
+
+float* resolve(const StDetector* det, const TRef& t, float* ws, float* head) {
+  if (t.buf == BUF_NONE) return nullptr;
+  if (t.buf == BUF_HEAD) return head + t.base;
+  return ws + det->buf_off[t.buf] + t.base;
+}
+
+int run_ops(StDetector* det, int phase_lo, int phase_hi, const float* const inputs[3], float* ws,
+            float* head, hipStream_t stream) {
+  for (const Op& o : det->ops) {
+    if (o.phase < phase_lo || o.phase > phase_hi) continue;
+    switch (o.type) {
+      case Op::FOCUS: {
+        const float* src = inputs[o.focus_input];
+        ST_REQUIRE(src != nullptr, "detector: input %d not provided", o.focus_input);
+        float* dst = resolve(det, o.out1, ws, head) +
+                     (size_t)o.focus_batch_off * o.out1.H * o.out1.W * o.out1.ld;
+        ST_CHECK(focus_pack_launch(src, det->cfg.batch, 3, det->cfg.height, det->cfg.width, dst, stream));
+        break;
+      }
+      case Op::SPP: {
+        float* x = resolve(det, o.in, ws, head);
+        float* out = resolve(det, o.out1, ws, head);
+        ST_CHECK(spp_pool_launch(x, o.in.ld, o.in.off, o.in.N, o.in.H, o.in.W, o.in.C, out, o.out1.ld,
+                                 o.out1.off, stream));
+        break;
+      }
+      case Op::CONV: {
+        const PackedConv& pc = det->convs[o.pc];
+        StConvDesc d{};
+        d.in_dev = resolve(det, o.in, ws, head);
+        d.N = o.in.N; d.Hi = o.in.H; d.Wi = o.in.W; d.Cin = pc.cin; d.in_ld = o.in.ld; d.in_off = o.in.off;
+        d.wgt_dev = det->wgt_dev + pc.wgt_off;
+        d.bias_dev = det->wgt_dev + pc.bias_off;
+        d.Cout = pc.cout; d.KH = pc.k; d.KW = pc.k; d.stride = o.stride; d.pad = o.pad;
+        d.out1_dev = resolve(det, o.out1, ws, head); d.out1_ld = o.out1.ld; d.out1_off = o.out1.off;
+        d.split = o.split;
+        d.out2_dev = resolve(det, o.out2, ws, head); d.out2_ld = o.out2.ld; d.out2_off = o.out2.off;
+        d.up_dev = resolve(det, o.up, ws, head); d.up_ld = o.up.ld; d.up_off = o.up.off;
+        d.res_dev = resolve(det, o.res, ws, head); d.res_ld = o.res.ld; d.res_off = o.res.off;
+        d.post_scale = o.post_scale; d.act = o.act;
+        ST_CHECK(conv2d_launch(d, stream, -1));
+        break;
+      }
+    }
+  }
+  return ST_OK;
+}
+
+}  // namespace
+
+extern "C" int st_detector_forward(StDetector* det, const float* img_dev, const float* disp_dev,
+                                   void* workspace_dev, size_t workspace_bytes, st_stream_t stream,
+                                   float* head_out_dev) {
+  if (!det) return set_error(ST_ERR_INVALID, "st_detector_forward: null detector");
+  if (!det->finalized) return set_error(ST_ERR_STATE, "st_detector_forward: call st_detector_finalize first");
+  ST_REQUIRE(img_dev && disp_dev && workspace_dev && head_out_dev, "st_detector_forward: null pointer");
+  ST_REQUIRE(!det->cfg.with_right_branch, "st_detector_forward: detector was built for stereo; use st_detector_forward_phase");
+  if (workspace_bytes < det->ws_floats * sizeof(float))
+    return set_error(ST_ERR_WORKSPACE, "st_detector_forward: workspace %zu < required %zu", workspace_bytes,
+                     det->ws_floats * sizeof(float));
+  const float* inputs[3] = {img_dev, disp_dev, nullptr};
+  return run_ops(det, 0, 1, inputs, static_cast<float*>(workspace_dev), head_out_dev,
+                 static_cast<hipStream_t>(stream));
+}
+
+// Phase API for the stereo configuration: phase 0 = stem+stage1 features of left (and right),
+// phase 1 = disparity branch + fused trunk + neck + head.  Between the two the caller runs the
+// cost-volume module on the "stage1_rgb" tap to produce disp_postp.
+extern "C" int st_detector_forward_phase(StDetector* det, int phase, const float* img_dev,
+                                         const float* disp_dev, const float* right_dev,
+                                         void* workspace_dev, size_t workspace_bytes,
+                                         st_stream_t stream, float* head_out_dev) {
+  if (!det) return set_error(ST_ERR_INVALID, "st_detector_forward_phase: null detector");
+  if (!det->finalized) return set_error(ST_ERR_STATE, "st_detector_forward_phase: call st_detector_finalize first");
+  ST_REQUIRE(phase == 0 || phase == 1, "st_detector_forward_phase: phase must be 0 or 1");
+  ST_REQUIRE(workspace_dev != nullptr, "st_detector_forward_phase: null workspace");
+  if (workspace_bytes < det->ws_floats * sizeof(float))
+    return set_error(ST_ERR_WORKSPACE, "st_detector_forward_phase: workspace %zu < required %zu", workspace_bytes,
+                     det->ws_floats * sizeof(float));
+  if (phase == 0) {
+    ST_REQUIRE(img_dev != nullptr, "st_detector_forward_phase: null img");
+    ST_REQUIRE(!det->cfg.with_right_branch || right_dev != nullptr, "st_detector_forward_phase: right image required");
+  } else {
+    ST_REQUIRE(disp_dev && head_out_dev, "st_detector_forward_phase: null disp/head pointer");
+  }
+  const float* inputs[3] = {img_dev, disp_dev, right_dev};
+  return run_ops(det, phase, phase, inputs, static_cast<float*>(workspace_dev), head_out_dev,
+                 static_cast<hipStream_t>(stream));
+}
+
+extern "C" int st_detector_tap(const StDetector* det, const char* name, const void* workspace_dev,
+                               const float** ptr_dev, int* N, int* C, int* H, int* W, int* ld) {
+  if (!det || !name) return set_error(ST_ERR_INVALID, "st_detector_tap: null argument");
+  auto it = det->taps.find(name);
+  if (it == det->taps.end()) return set_error(ST_ERR_NOTFOUND, "st_detector_tap: unknown tap '%s'", name);
+  const TRef& t = it->second;
+  if (ptr_dev) *ptr_dev = static_cast<const float*>(workspace_dev) + det->buf_off[t.buf] + t.off;
+  if (N) *N = t.N;
+  if (ld) *ld = t.ld;
+  if (C) *C = t.C;
+  if (H) *H = t.H;
+  if (W) *W = t.W;
+  return ST_OK;
+}

@@ -1,0 +1,133 @@
+// Small bandwidth-bound helpers of the detector: Focus space-to-depth packing and SPP pooling.
+#include <algorithm>
+
+#include "st_common.h"
+
+namespace st {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// NCHW [N][C][H][W] -> NHWC [N][H/2][W/2][4C], channel = q*C + c with q = TL, BL, TR, BR
+// (mmdet Focus order; reference csp_darknet_disparity_v1.py:104-111).
+// One thread per output pixel: 2x2 float2 reads per channel (8 B/lane, coalesced along x),
+// 4C contiguous floats written.
+template <int C>
+__global__ __launch_bounds__(256) void focus_pack_kernel(const float* __restrict__ img, int N, int H,
+                                                         int W, float* __restrict__ out) {
+  const int Ho = H >> 1, Wo = W >> 1;
+  const long long total = (long long)N * Ho * Wo;
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (long long)gridDim.x * blockDim.x) {
+    const int ox = (int)(idx % Wo);
+    const long long t = idx / Wo;
+    const int oy = (int)(t % Ho);
+    const int n = (int)(t / Ho);
+    float v[4 * C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      const float* base = img + (((size_t)n * C + c) * H + 2 * oy) * W + 2 * ox;
+      const f32x2 top = *reinterpret_cast<const f32x2*>(base);
+      const f32x2 bot = *reinterpret_cast<const f32x2*>(base + W);
+      v[0 * C + c] = top[0];  // TL
+      v[1 * C + c] = bot[0];  // BL
+      v[2 * C + c] = top[1];  // TR
+      v[3 * C + c] = bot[1];  // BR
+    }
+    float* o = out + (size_t)idx * (4 * C);
+#pragma unroll
+    for (int g = 0; g < C; ++g) {
+      f32x4 w = {v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]};
+      *reinterpret_cast<f32x4*>(o + 4 * g) = w;
+    }
+  }
+}
+
+// SPP pooling: max over 5x5 / 9x9 / 13x13 windows (stride 1, implicit -inf padding).
+// One thread per (pixel, 4-channel group); windows are nested so one 13x13 sweep feeds all three.
+__global__ __launch_bounds__(256) void spp_pool_kernel(const float* __restrict__ x, int x_ld, int x_off,
+                                                       int N, int H, int W, int C,
+                                                       float* __restrict__ out, int out_ld, int out_off,
+                                                       int copy_x) {
+  const int C4 = C >> 2;
+  const long long total = (long long)N * H * W * C4;
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (long long)gridDim.x * blockDim.x) {
+    const int c4 = (int)(idx % C4);
+    long long t = idx / C4;
+    const int px = (int)(t % W);
+    t /= W;
+    const int py = (int)(t % H);
+    const int n = (int)(t / H);
+    const float ninf = -__builtin_inff();
+    f32x4 m5 = {ninf, ninf, ninf, ninf}, m9 = m5, m13 = m5;
+    for (int dy = -6; dy <= 6; ++dy) {
+      const int yy = py + dy;
+      if ((unsigned)yy >= (unsigned)H) continue;
+      const int ady = dy < 0 ? -dy : dy;
+      for (int dx = -6; dx <= 6; ++dx) {
+        const int xx = px + dx;
+        if ((unsigned)xx >= (unsigned)W) continue;
+        const int adx = dx < 0 ? -dx : dx;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(
+            x + ((size_t)(n * H + yy) * W + xx) * x_ld + x_off + 4 * c4);
+        const int rad = ady > adx ? ady : adx;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          m13[e] = fmaxf(m13[e], v[e]);
+          if (rad <= 4) m9[e] = fmaxf(m9[e], v[e]);
+          if (rad <= 2) m5[e] = fmaxf(m5[e], v[e]);
+        }
+      }
+    }
+    float* o = out + ((size_t)(n * H + py) * W + px) * out_ld + out_off + 4 * c4;
+    if (copy_x)
+      *reinterpret_cast<f32x4*>(o) = *reinterpret_cast<const f32x4*>(
+          x + ((size_t)(n * H + py) * W + px) * x_ld + x_off + 4 * c4);
+    *reinterpret_cast<f32x4*>(o + C) = m5;
+    *reinterpret_cast<f32x4*>(o + 2 * C) = m9;
+    *reinterpret_cast<f32x4*>(o + 3 * C) = m13;
+  }
+}
+
+int focus_pack_launch(const float* img, int N, int C, int H, int W, float* out, hipStream_t stream) {
+  ST_REQUIRE(img && out, "focus_pack: null pointer");
+  ST_REQUIRE(N > 0 && H > 0 && W > 0 && (H % 2) == 0 && (W % 2) == 0, "focus_pack: H, W must be even");
+  const long long total = (long long)N * (H / 2) * (W / 2);
+  const int blocks = (int)std::min<long long>((total + 255) / 256, 256 * 16);
+  switch (C) {
+    case 1: hipLaunchKernelGGL(focus_pack_kernel<1>, dim3(blocks), dim3(256), 0, stream, img, N, H, W, out); break;
+    case 3: hipLaunchKernelGGL(focus_pack_kernel<3>, dim3(blocks), dim3(256), 0, stream, img, N, H, W, out); break;
+    default: return set_error(ST_ERR_INVALID, "focus_pack: C must be 1 or 3 (got %d)", C);
+  }
+  ST_CHECK_HIP(hipGetLastError());
+  return ST_OK;
+}
+
+int spp_pool_launch(const float* x, int x_ld, int x_off, int N, int H, int W, int C, float* out,
+                    int out_ld, int out_off, hipStream_t stream) {
+  ST_REQUIRE(x && out, "spp_pool: null pointer");
+  ST_REQUIRE(C % 4 == 0 && x_ld % 4 == 0 && x_off % 4 == 0 && out_ld % 4 == 0 && out_off % 4 == 0,
+             "spp_pool: channel counts/offsets must be multiples of 4");
+  ST_REQUIRE(out_off + 4 * C <= out_ld && x_off + C <= x_ld, "spp_pool: slice exceeds ld");
+  const int copy_x = !(x == out && x_ld == out_ld && x_off == out_off);
+  const long long total = (long long)N * H * W * (C / 4);
+  const int blocks = (int)std::min<long long>((total + 255) / 256, 256 * 16);
+  hipLaunchKernelGGL(spp_pool_kernel, dim3(blocks), dim3(256), 0, stream, x, x_ld, x_off, N, H, W, C,
+                     out, out_ld, out_off, copy_x);
+  ST_CHECK_HIP(hipGetLastError());
+  return ST_OK;
+}
+
+}  // namespace st
+
+extern "C" int st_focus_pack(const float* img, int N, int C, int H, int W, float* out,
+                             st_stream_t stream) {
+  return st::focus_pack_launch(img, N, C, H, W, out, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int st_spp_pool(const float* x, int x_ld, int x_off, int N, int H, int W, int C,
+                           float* out, int out_ld, int out_off, st_stream_t stream) {
+  return st::spp_pool_launch(x, x_ld, x_off, N, H, W, C, out, out_ld, out_off,
+                             static_cast<hipStream_t>(stream));
+}

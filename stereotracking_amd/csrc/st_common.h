@@ -1,0 +1,38 @@
+// Shared helpers for libstereotrack_hip (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <string>
+
+#include "../../include/stereotrack.h"
+
+namespace st {
+
+std::string& last_error();
+int set_error(int code, const char* fmt, ...);
+
+inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+inline int round_up(int a, int b) { return ceil_div(a, b) * b; }
+
+}  // namespace st
+
+#define ST_CHECK_HIP(expr)                                                              \
+  do {                                                                                  \
+    hipError_t e_ = (expr);                                                             \
+    if (e_ != hipSuccess)                                                               \
+      return st::set_error(ST_ERR_HIP, "%s failed: %s (%s:%d)", #expr,                  \
+                           hipGetErrorString(e_), __FILE__, __LINE__);                  \
+  } while (0)
+
+#define ST_REQUIRE(cond, ...)                                        \
+  do {                                                               \
+    if (!(cond)) return st::set_error(ST_ERR_INVALID, __VA_ARGS__);  \
+  } while (0)
+
+#define ST_CHECK(expr)        \
+  do {                        \
+    int rc_ = (expr);         \
+    if (rc_ != ST_OK) return rc_; \
+  } while (0)

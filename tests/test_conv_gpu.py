@@ -1,0 +1,164 @@
+"""GPU parity of the conv primitive (st_conv2d_nhwc) against plain PyTorch CPU convolution.
+
+This is the one floating-point GEMM-shaped kernel of the path, so (per the tier rules) it keeps a
+torch fp32/fp64 reference: tolerance 1e-4 relative to the fp64 result's scale — two fp32
+summation orders of K <= 4608 products differ by ~sqrt(K)*2^-24.
+"""
+import ctypes as C
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from stereotracking_amd import _lib
+from stereotracking_amd._lib import StConvDesc, check, ptr
+
+pytestmark = pytest.mark.gpu
+
+
+def pack(w, bias=None, bn=None, eps=1e-3):
+    lib = _lib.load()
+    cout, cin, kh, kw = w.shape
+    nf = lib.st_conv_packed_floats(cout, cin, kh, kw)
+    wp = torch.empty(nf, dtype=torch.float32)
+    bp = torch.empty((cout + 31) // 32 * 32, dtype=torch.float32)
+    g = [ptr(t.contiguous()) if t is not None else None for t in (bn or (None,) * 4)]
+    check(lib.st_conv_pack_weights(ptr(w.contiguous()), ptr(bias) if bias is not None else None, g[0], g[1], g[2],
+                                   g[3], eps, cout, cin, kh, kw, ptr(wp), ptr(bp)))
+    return wp, bp
+
+
+def run_conv(x_nchw, w, bias, stride, pad, act, dev, variant=-1, res=None, post_scale=1.0, split=None, up=False,
+             in_ld=None, in_off=0):
+    lib = _lib.load()
+    N, Cin, Hi, Wi = x_nchw.shape
+    Cout, _, KH, KW = w.shape
+    Ho = (Hi + 2 * pad - KH) // stride + 1
+    Wo = (Wi + 2 * pad - KW) // stride + 1
+    in_ld = in_ld or Cin
+    xin = torch.randn(N, Hi, Wi, in_ld) * 3.0  # garbage in the unused channels
+    xin[..., in_off:in_off + Cin] = x_nchw.permute(0, 2, 3, 1)
+    xin = xin.contiguous().to(dev)
+    wp, bp = pack(w, bias)
+    wp, bp = wp.to(dev), bp.to(dev)
+    d = StConvDesc()
+    d.in_dev = xin.data_ptr(); d.N, d.Hi, d.Wi, d.Cin, d.in_ld, d.in_off = N, Hi, Wi, Cin, in_ld, in_off
+    d.wgt_dev = wp.data_ptr(); d.bias_dev = bp.data_ptr()
+    d.Cout, d.KH, d.KW, d.stride, d.pad = Cout, KH, KW, stride, pad
+    s = Cout if split is None else split
+    out1 = torch.full((N, Ho, Wo, s + 4), -777.0, device=dev)  # ld = s+4, off = 4
+    d.out1_dev = out1.data_ptr(); d.out1_ld, d.out1_off, d.split = s + 4, 4, s
+    out2 = None
+    if split is not None:
+        out2 = torch.full((N, Ho, Wo, Cout - s), -777.0, device=dev)
+        d.out2_dev = out2.data_ptr(); d.out2_ld, d.out2_off = Cout - s, 0
+    upb = None
+    if up:
+        upb = torch.full((N, 2 * Ho, 2 * Wo, Cout), -777.0, device=dev)
+        d.up_dev = upb.data_ptr(); d.up_ld, d.up_off = Cout, 0
+    resb = None
+    if res is not None:
+        resb = res.permute(0, 2, 3, 1).contiguous().to(dev)
+        d.res_dev = resb.data_ptr(); d.res_ld, d.res_off = Cout, 0
+    d.post_scale = post_scale
+    d.act = act
+    stream = _lib.current_stream()
+    if variant >= 0:
+        check(lib.st_conv2d_nhwc_variant(C.byref(d), stream, variant), 'conv')
+    else:
+        check(lib.st_conv2d_nhwc(C.byref(d), stream), 'conv')
+    torch.cuda.synchronize()
+    o1 = out1.cpu()
+    assert torch.all(o1[..., :4] == -777.0), 'kernel wrote outside its channel slice'
+    full = o1[..., 4:]
+    if out2 is not None:
+        full = torch.cat([full, out2.cpu()], dim=-1)
+    return full.permute(0, 3, 1, 2), (upb.cpu().permute(0, 3, 1, 2) if upb is not None else None)
+
+
+def ref_conv(x, w, bias, stride, pad, act, res=None, post_scale=1.0):
+    y = F.conv2d(x.double(), w.double(), bias.double() if bias is not None else None, stride, pad)
+    if act:
+        y = F.silu(y)
+    if res is not None:
+        y = (y + res.double()) * post_scale
+    return y
+
+
+def assert_close(got, ref, tol=1e-4):
+    scale = ref.abs().max().item() + 1e-6
+    err = (got.double() - ref).abs().max().item()
+    assert err <= tol * scale, f'max abs err {err:.3e} vs scale {scale:.3e}'
+
+
+CASES = [
+    # N, Cin, H, W, Cout, k, stride  (shapes of the path at reduced resolution + ragged sizes)
+    (2, 12, 20, 36, 32, 3, 1),     # stem conv on focus-packed input (Cin=12: K=108 crosses taps inside a chunk)
+    (1, 32, 23, 41, 64, 3, 2),     # stride-2 stage conv, odd sizes
+    (2, 64, 17, 19, 64, 1, 1),     # CSP 1x1
+    (1, 128, 9, 13, 256, 3, 1),    # head tower
+    (1, 512, 6, 10, 512, 1, 1),    # SPP conv2-like (K=512..)
+    (1, 24, 10, 12, 48, 3, 2),     # tiny-config channels (Cin not a multiple of 32)
+    (1, 128, 7, 9, 5, 1, 1),       # prediction conv, Cout=5 (padded to 32)
+    (3, 48, 5, 7, 48, 3, 1),       # cost-volume aggregation shape
+]
+
+
+@pytest.mark.parametrize('case', CASES)
+def test_conv_matches_torch(case, cuda):
+    torch.manual_seed(sum(case))
+    N, Cin, H, W, Cout, k, stride = case
+    x = torch.randn(N, Cin, H, W)
+    w = torch.randn(Cout, Cin, k, k) / (Cin * k * k) ** 0.5
+    b = torch.randn(Cout)
+    got, _ = run_conv(x, w, b, stride, k // 2, 1, cuda)
+    assert_close(got, ref_conv(x, w, b, stride, k // 2, 1))
+
+
+@pytest.mark.parametrize('variant,cout', [(0, 128), (1, 64), (2, 32), (3, 64), (4, 32), (0, 256), (3, 128)])
+def test_conv_all_tile_variants(variant, cout, cuda):
+    torch.manual_seed(variant)
+    x = torch.randn(2, 64, 13, 21)
+    w = torch.randn(cout, 64, 3, 3) / 24.0
+    b = torch.randn(cout)
+    got, _ = run_conv(x, w, b, 1, 1, 1, cuda, variant=variant)
+    assert_close(got, ref_conv(x, w, b, 1, 1, 1))
+
+
+def test_conv_epilogue_residual_scale_split_upsample(cuda):
+    torch.manual_seed(7)
+    x = torch.randn(2, 64, 8, 12)
+    w = torch.randn(96, 64, 1, 1) / 8.0
+    b = torch.randn(96)
+    res = torch.randn(2, 96, 8, 12)
+    got, _ = run_conv(x, w, b, 1, 0, 1, cuda, res=res, post_scale=0.5)
+    assert_close(got, ref_conv(x, w, b, 1, 0, 1, res, 0.5))
+    got, up = run_conv(x, w, b, 1, 0, 1, cuda, split=64, up=True)
+    ref = ref_conv(x, w, b, 1, 0, 1)
+    assert_close(got, ref)
+    assert torch.equal(up, F.interpolate(got, scale_factor=2, mode='nearest'))
+
+
+def test_conv_no_act_and_input_slice(cuda):
+    torch.manual_seed(9)
+    x = torch.randn(1, 32, 6, 9)
+    w = torch.randn(6, 32, 1, 1) / 5.0
+    b = torch.randn(6)
+    got, _ = run_conv(x, w, b, 1, 0, 0, cuda, in_ld=96, in_off=32)
+    assert_close(got, ref_conv(x, w, b, 1, 0, 0))
+
+
+def test_bn_folding_fp64(cuda):
+    torch.manual_seed(11)
+    cout, cin = 40, 16
+    w = torch.randn(cout, cin, 3, 3)
+    gamma, beta = torch.rand(cout) + 0.5, torch.randn(cout)
+    mean, var = torch.randn(cout), torch.rand(cout) + 0.5
+    wp, bp = pack(w, None, (gamma, beta, mean, var), 1e-3)
+    scale = gamma.double() / torch.sqrt(var.double() + 1e-3)
+    wref = (w.double() * scale[:, None, None, None]).float()
+    Kpad = (cin * 9 + 31) // 32 * 32
+    wpk = wp.view(-1, Kpad)[:cout, :cin * 9].view(cout, 3, 3, cin).permute(0, 3, 1, 2)
+    assert torch.equal(wpk, wref)
+    assert torch.equal(bp[:cout], (beta.double() - mean.double() * scale).float())
+    assert torch.all(bp[cout:] == 0) and torch.all(wp.view(-1, Kpad)[cout:] == 0)
