@@ -1,0 +1,241 @@
+#!/usr/bin/env python
+"""bench.py — stereo frame-pairs/s of the dense hot path on MI355X.
+
+One step = one pass of the whole hot path over one batch of 8 synthetic 1280x720 stereo pairs
+(BASELINE.json configs[1]: D=192, full YOLOX-s two-branch detector):
+  stem+stage1 features of left AND right -> cost volume (D/4 = 48 levels at 1/4 res) + soft-argmin
+  -> bilinear x4 -> disp_postp -> disparity branch + fused trunk + PAFPN + head -> decode +
+  score filter + sort + NMS -> per-box depth + depth-guided scaling -> detection buffer
+  (-> RCCL all-gather of the detection buffers when --gpus > 1).
+Inputs are resident in HBM before the timed region.  Weights are seeded random (no checkpoints
+offline).  Prints ONE JSON line on rank 0.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W]
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md, v_mfma_f32_32x32x2_f32 dense peak
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--batch', type=int, default=8, help='stereo pairs per GPU per step')
+    ap.add_argument('--max-disp', type=int, default=192)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-seconds', type=float, default=15.0, help='budget of the CPU oracle leg')
+    return ap.parse_args()
+
+
+def conv_roofline(pipe, img, right, steps):
+    """Per-op HIP-event timing of the conv kernels over `steps` passes (events are recorded on the
+    launch stream inside the library, st_detector_set_timing)."""
+    import ctypes as C
+    import numpy as np
+    from stereotracking_amd._lib import check
+    det = pipe.det
+    lib = det.lib
+    check(lib.st_detector_set_timing(det.handle, 1))
+    nops = lib.st_detector_num_ops(det.handle)
+    ms = np.zeros(nops, np.float32)
+    kind = np.zeros(nops, np.int32)
+    var = np.zeros(nops, np.int32)
+    macs = np.zeros(nops, np.float64)
+    phase = np.zeros(nops, np.int32)
+    tot_ms = np.zeros(nops, np.float64)
+    other = {'costvolume+upsample': 0.0, 'decode_nms': 0.0, 'box_depth': 0.0}
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
+    for _ in range(steps):
+        b = pipe._buffers(img.device)
+        ev[0].record()
+        disp = pipe.disparity(img, right)          # phase-0 convs + cost volume + upsample
+        ev[1].record()
+        pipe.det.forward_phase(1, disp=disp, head_out=b['head'])
+        ev[2].record()
+        boxes, scores, labels, prior, counts = pipe.det.decode_nms(b['head'], pipe.score_thr, pipe.iou_thr,
+                                                                   pipe.max_det, (pipe.ori_h, pipe.ori_w))
+        ev[3].record()
+        pipe.box_depth(disp, boxes, counts)
+        ev[4].record()
+        torch.cuda.synchronize()
+        p = lambda a: a.ctypes.data_as(C.c_void_p)
+        check(lib.st_detector_op_times(det.handle, nops, p(ms), p(kind), p(var), p(macs), p(phase)))
+        tot_ms += ms
+        ph0 = float(ms[phase == 0].sum())
+        other['costvolume+upsample'] += ev[0].elapsed_time(ev[1]) - ph0
+        other['decode_nms'] += ev[2].elapsed_time(ev[3])
+        other['box_depth'] += ev[3].elapsed_time(ev[4])
+    check(lib.st_detector_set_timing(det.handle, 0))
+    VARIANT_TILES = {v: lib.st_conv_variant_name(v).decode() for v in range(16)}
+    per_variant = {}
+    for v in sorted(set(var[kind == 1].tolist())):
+        sel = (kind == 1) & (var == v)
+        t = tot_ms[sel].sum() / steps
+        fl = 2.0 * macs[sel].sum()
+        per_variant[VARIANT_TILES[v]] = dict(launches=int(sel.sum()), ms_per_step=round(float(t), 4),
+                                             gflop_per_step=round(fl / 1e9, 3),
+                                             tflops=round(fl / (t * 1e-3) / 1e12, 3) if t > 0 else 0.0)
+    dom = max(per_variant, key=lambda k: per_variant[k]['ms_per_step'])
+    conv_ms = float(tot_ms[kind == 1].sum() / steps)
+    conv_fl = 2.0 * float(macs[kind == 1].sum())
+    d = per_variant[dom]
+    roof = dict(bound='mfma', kernel=f'conv_igemm_kernel<{dom}>',
+                achieved=d['tflops'], peak=PEAK_FP32_MFMA_TFLOPS, unit='TFLOP/s',
+                frac=round(d['tflops'] / PEAK_FP32_MFMA_TFLOPS, 4), traffic=None,
+                flop_per_launch=round(d['gflop_per_step'] * 1e9 / d['launches']),
+                avg_launch_us=round(d['ms_per_step'] * 1e3 / d['launches'], 2),
+                launches_per_step=d['launches'],
+                all_conv=dict(ms_per_step=round(conv_ms, 4), tflops=round(conv_fl / (conv_ms * 1e-3) / 1e12, 3),
+                              frac=round(conv_fl / (conv_ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4)),
+                per_variant=per_variant,
+                other_kernels_ms_per_step={k: round(v / steps, 4) for k, v in other.items()},
+                focus_spp_ms_per_step=round(float(tot_ms[kind != 1].sum() / steps), 4))
+    return roof
+
+
+def cpu_baseline(sd, batch_cpu, max_disp, seconds):
+    """The CPU oracle (kind 'port': this repo's restatement of the reference path; the reference itself
+    cannot be imported) timed on the host cores over whole stereo pairs."""
+    import numpy as np
+    from oracle import c_oracle, depth as odepth
+    from oracle.torch_model import OracleDetector, head_to_rows
+    # a 1-GPU box shares its host: use its CPU share (16), not every core the OS reports
+    torch.set_num_threads(min(os.cpu_count() or 1, 16))
+    ora = OracleDetector(0.33, 0.5, 1).eval()
+    ora.load_state_dict(sd, strict=False)
+    img, right, = batch_cpu['img'][:1], batch_cpu['right'][:1]
+    H, W = img.shape[-2:]
+    ori_h, ori_w = 720, 1280
+    D = max_disp // 4
+
+    def one_pair():
+        with torch.no_grad():
+            fl = ora.backbone.stage1_features(img).permute(0, 2, 3, 1).contiguous().numpy()
+            fr = ora.backbone.stage1_features(right).permute(0, 2, 3, 1).contiguous().numpy()
+            cost = c_oracle.costvolume(fl, fr, fl.shape[-1], D)
+            lr = c_oracle.softargmin(cost, 32.0)
+            disp = torch.from_numpy(c_oracle.disp_upsample(lr, 4, ori_h, ori_w))
+            rows = head_to_rows(*ora(dict(img=img, disp_postp=disp)))
+        levels, off, flat = [], 0, []
+        for r, s in zip(rows, (8, 16, 32)):
+            hw = r.shape[1]
+            h = H // s
+            pad = torch.zeros(1, hw, 8)
+            pad[..., :6] = r
+            levels.append((h, hw // h, s, off))
+            off += hw * 8
+            flat.append(pad.reshape(-1))
+        head = torch.cat(flat).numpy()
+        boxes, scores, labels, prior, counts = c_oracle.decode_nms(head, 1, levels, 0.01, 0.5, 300, (ori_h, ori_w))
+        k = min(int(counts[0]), 300)
+        odepth.bbox_postp_depth(torch.from_numpy(boxes[0, :k]), disp)
+        return k
+
+    one_pair()  # warm-up (oneDNN primitive caches)
+    t0 = time.perf_counter()
+    n = 0
+    while True:
+        one_pair()
+        n += 1
+        if time.perf_counter() - t0 >= seconds or n >= 64:
+            break
+    dt = time.perf_counter() - t0
+    return dict(value=round(n / dt, 4), unit='stereo frame-pairs/s', cores=torch.get_num_threads(), kind='port',
+                sample=f'{n} x 1 synthetic 1280x720 pair (D={max_disp}, full YOLOX-s two-branch), CPU oracle '
+                       f'(PyTorch fp32 + C oracle), {dt:.1f} s', host_cpus=os.cpu_count())
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get('RANK', 0))
+    local_rank = int(os.environ.get('LOCAL_RANK', 0))
+    world = int(os.environ.get('WORLD_SIZE', 1))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}')
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs a GPU (the HIP path is the only product path)')
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+
+    from stereotracking_amd.pipeline import StereoDensePipeline
+    from stereotracking_amd.synthetic import synthetic_batch, synthetic_state_dict
+
+    B = args.batch
+    pipe = StereoDensePipeline(B, (720, 1280), 0.5, 0.33, 1, stereo=True, max_disp=args.max_disp, max_det=300)
+    sd = synthetic_state_dict(pipe.param_table(), seed=0)
+    pipe.load_state_dict(sd)
+    # every rank gets its own 8 pairs (weak scaling: frames shard across ranks)
+    batch_cpu = synthetic_batch([rank * B + i for i in range(B)], 720, 1280, args.max_disp)
+    img, right = batch_cpu['img'].to(dev), batch_cpu['right'].to(dev)
+    gathered = torch.empty(world * B, pipe.max_det, 8, device=dev) if world > 1 else None
+
+    def step():
+        out = pipe.run(img, right)
+        dets = pipe.pack_detections(out)
+        if world > 1:
+            dist.all_gather_into_tensor(gathered, dets)
+        return out
+
+    for _ in range(args.warmup):
+        out = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    counts = out['counts'].cpu().tolist()
+    line = {
+        'metric': 'stereo frame-pairs/sec @1280x720 D=192', 'value': round(world * B * args.steps / dt, 3),
+        'unit': 'stereo frame-pairs/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+        'ms_per_step': round(dt / args.steps * 1e3, 4), 'higher_is_better': True, 'scaling': 'weak',
+        'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+        'config': {'workload': f'configs[1]: batch={B} synthetic 1280x720 stereo pairs per GPU, D={args.max_disp}, '
+                               'full YOLOX-s two-branch backbone+PAFPN+head, cost volume at 1/4 res '
+                               f'({args.max_disp // 4} levels) + soft-argmin, decode+NMS, per-box depth',
+                   'global_batch': world * B, 'parallelism': f'frames sharded x{world}, all-gather of detections',
+                   'detections_kept_rank0': counts},
+    }
+    if rank == 0:
+        roof = conv_roofline(pipe, img, right, max(3, min(args.steps, 10)))
+        roof['gflop_per_pair_conv'] = round(2.0 * pipe.det.macs / B / 1e9, 3)
+        line['roofline'] = roof
+        if world == 1 and not args.no_cpu_baseline:
+            line['cpu_baseline'] = cpu_baseline(sd, batch_cpu, args.max_disp, args.cpu_seconds)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -161,6 +161,20 @@ double st_detector_macs(const StDetector* det);
 int st_detector_forward_phase(StDetector* det, int phase, const float* img_dev,
                               const float* disp_dev, const float* right_dev, void* workspace_dev,
                               size_t workspace_bytes, st_stream_t stream, float* head_out_dev);
+/* Per-op timing for bench.py / profiling.  When enabled every op (focus pack, conv, spp) of the
+ * following forwards is bracketed by hipEvents on the caller's stream; st_detector_op_times
+ * synchronises on them and returns, per op: elapsed ms, kind (0 focus, 1 conv, 2 spp), conv tile
+ * variant (0: 128x128, 1: 128x64, 2: 128x32, 3: 64x64, 4: 64x32; -1 otherwise), conv MACs, phase. */
+int st_detector_set_timing(StDetector* det, int enable);
+int st_detector_num_ops(const StDetector* det);
+int st_detector_op_times(StDetector* det, int cap, float* ms, int* kind, int* variant, double* macs,
+                         int* phase);
+int st_detector_op_desc(const StDetector* det, int i, char* buf, int cap);
+/* Measure every valid conv tile variant on every conv op's real shape and keep the fastest
+ * (host-synchronous; call once after st_detector_finalize, never inside a timed region). */
+int st_detector_autotune(StDetector* det, void* workspace_dev, size_t workspace_bytes,
+                         float* head_out_dev, st_stream_t stream, int reps);
+const char* st_conv_variant_name(int id);
 /* Internal NHWC activations inside the workspace (valid after forward); name in
  * {"stage1_rgb","stage1_fused","stage2","stage3","stage4","p3","p4","p5"}.  Pixel p, channel c
  * is ptr[p*ld + c]. */

@@ -64,3 +64,35 @@ def decode_nms(head, N, levels, score_thr, iou_thr, max_det, ori_shape, scale_fa
     if rc != 0:
         raise RuntimeError('oracle_decode_nms failed')
     return boxes, scores, labels, prior, counts
+
+
+def costvolume(featL, featR, C_, D):
+    """featL/featR: float32 numpy (N,Hf,Wf,ld) NHWC -> cost (N,Hf,Wf,D)."""
+    lib = load()
+    featL = np.ascontiguousarray(featL, np.float32)
+    featR = np.ascontiguousarray(featR, np.float32)
+    N, Hf, Wf, ld = featL.shape
+    out = np.zeros((N, Hf, Wf, D), np.float32)
+    lib.oracle_costvolume(_p(featL), _p(featR), C.c_int(N), C.c_int(Hf), C.c_int(Wf), C.c_int(C_), C.c_int(ld),
+                          C.c_int(D), _p(out))
+    return out
+
+
+def softargmin(cost, temperature):
+    lib = load()
+    cost = np.ascontiguousarray(cost, np.float32)
+    D = cost.shape[-1]
+    out = np.zeros(cost.shape[:-1], np.float32)
+    lib.oracle_softargmin(_p(cost), C.c_longlong(out.size), C.c_int(D), C.c_float(temperature), _p(out))
+    return out
+
+
+def disp_upsample(lr, scale, valid_h, valid_w):
+    """lr (N,Hf,Wf) -> disp_postp (N,3,Hf*scale,Wf*scale)."""
+    lib = load()
+    lr = np.ascontiguousarray(lr, np.float32)
+    N, Hf, Wf = lr.shape
+    out = np.zeros((N, 3, Hf * scale, Wf * scale), np.float32)
+    lib.oracle_disp_upsample(_p(lr), C.c_int(N), C.c_int(Hf), C.c_int(Wf), C.c_int(scale), C.c_int(Hf * scale),
+                             C.c_int(Wf * scale), C.c_int(valid_h), C.c_int(valid_w), _p(out))
+    return out

@@ -155,3 +155,73 @@ int oracle_decode_nms(const float* head, int N, int num_levels, const int* lvl_h
   free(sup);
   return 0;
 }
+
+/* ---- stereo cost volume / soft-argmin / upsample (specification of the new module) ---------- */
+
+/*
+ * featL, featR: NHWC float[N][Hf][Wf][ld], channels [0,C) used.
+ * cost[n][y][x][d] = (sum_{c=0}^{C-1} fmaf(L[c], R[x-d][c], acc)) / C  for x-d >= 0, else 0.
+ */
+int oracle_costvolume(const float* featL, const float* featR, int N, int Hf, int Wf, int C, int ld, int D,
+                      float* out_cost) {
+  for (int n = 0; n < N; ++n)
+    for (int y = 0; y < Hf; ++y)
+      for (int x = 0; x < Wf; ++x) {
+        const float* l = featL + (((size_t)n * Hf + y) * Wf + x) * ld;
+        float* oc = out_cost + (((size_t)n * Hf + y) * Wf + x) * D;
+        for (int d = 0; d < D; ++d) {
+          if (x - d < 0) { oc[d] = 0.0f; continue; }
+          const float* r = featR + (((size_t)n * Hf + y) * Wf + (x - d)) * ld;
+          float acc = 0.0f;
+          for (int c = 0; c < C; ++c) acc = fmaf(l[c], r[c], acc);
+          oc[d] = acc / (float)C;
+        }
+      }
+  return 0;
+}
+
+/* disp[p] = sum_d d*e_d / sum_d e_d, e_d = exp(T*cost_d - max_d(T*cost_d)), sequential in d. */
+int oracle_softargmin(const float* cost, long long npix, int D, float temperature, float* out_disp) {
+  for (long long p = 0; p < npix; ++p) {
+    const float* c = cost + p * D;
+    float m = -INFINITY;
+    for (int d = 0; d < D; ++d) m = fmaxf(m, temperature * c[d]);
+    float s = 0.0f, t = 0.0f;
+    for (int d = 0; d < D; ++d) {
+      const float e = st_expf(temperature * c[d] - m);
+      s += e;
+      t = fmaf((float)d, e, t);
+    }
+    out_disp[p] = t / s;
+  }
+  return 0;
+}
+
+/* bilinear x`scale` upsample (align_corners=False), times scale, zero outside (valid_h, valid_w),
+ * replicated into 3 channels NCHW [N][3][H][W] — the `disp_postp` layout
+ * (reference loading_disparity.py:85-86 3-channel repeat; transforms_disparity.py:234-249 pad 0). */
+int oracle_disp_upsample(const float* lr, int N, int Hf, int Wf, int scale, int H, int W, int valid_h,
+                         int valid_w, float* out) {
+  const float inv = 1.0f / (float)scale;
+  for (int n = 0; n < N; ++n)
+    for (int Y = 0; Y < H; ++Y)
+      for (int X = 0; X < W; ++X) {
+        float v = 0.0f;
+        if (Y < valid_h && X < valid_w) {
+          float sy = ((float)Y + 0.5f) * inv - 0.5f, sx = ((float)X + 0.5f) * inv - 0.5f;
+          if (sy < 0.0f) sy = 0.0f;
+          if (sx < 0.0f) sx = 0.0f;
+          int y0 = (int)sy, x0 = (int)sx;
+          if (y0 > Hf - 1) y0 = Hf - 1;
+          if (x0 > Wf - 1) x0 = Wf - 1;
+          const int y1 = y0 + 1 < Hf ? y0 + 1 : Hf - 1, x1 = x0 + 1 < Wf ? x0 + 1 : Wf - 1;
+          const float ly = sy - (float)y0, lx = sx - (float)x0, hy = 1.0f - ly, hx = 1.0f - lx;
+          const float* b = lr + (size_t)n * Hf * Wf;
+          const float v00 = b[(size_t)y0 * Wf + x0], v01 = b[(size_t)y0 * Wf + x1];
+          const float v10 = b[(size_t)y1 * Wf + x0], v11 = b[(size_t)y1 * Wf + x1];
+          v = (hy * (hx * v00 + lx * v01) + ly * (hx * v10 + lx * v11)) * (float)scale;
+        }
+        for (int c = 0; c < 3; ++c) out[(((size_t)n * 3 + c) * H + Y) * W + X] = v;
+      }
+  return 0;
+}

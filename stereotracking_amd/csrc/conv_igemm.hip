@@ -200,13 +200,23 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(ConvKArgs p) {
     const bool vj = j < p.Cout;
 #pragma unroll
     for (int ti = 0; ti < TM; ++ti) {
+      // residual: issue all 16 loads of this 32x32 tile before the first use (one wait, not 16
+      // dependent HBM round trips)
+      float rv[16];
+      if (p.res) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = m0 + wm * 32 * TM + ti * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          rv[r] = (m < p.M && vj) ? p.res[(size_t)m * p.res_ld + p.res_off + j] : 0.f;
+        }
+      }
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int m = m0 + wm * 32 * TM + ti * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
         if (m < p.M && vj) {
           float v = acc[ti][tj][r] + bj;
           if (p.act) v = silu_f32(v);
-          if (p.res) v = (v + p.res[(size_t)m * p.res_ld + p.res_off + j]) * p.post_scale;
+          if (p.res) v = (v + rv[r]) * p.post_scale;
           if (j < p.split)
             p.out1[(size_t)m * p.out1_ld + p.out1_off + j] = v;
           else
@@ -247,7 +257,27 @@ static int launch_variant(const ConvKArgs& a, int m_tiles, hipStream_t stream) {
   return ST_OK;
 }
 
-int conv2d_launch(const StConvDesc& d, hipStream_t stream, int force_variant) {
+// Tile variants {BM, BN, threads}: id -> <TM,TN,WM,WN> in the switch of conv2d_launch.
+//  0 128x128 (4 waves 64x64)   1 128x64 (2 waves 64x64)   2 128x32 (2 waves 64x32)
+//  3  64x64  (4 waves 32x32)   4  64x32 (2 waves 32x32)   5 128x64 (4 waves 32x64)
+//  6 128x32  (4 waves 32x32)   7  64x128 (4 waves 32x64)  8 256x64 (4 waves 64x64)
+struct ConvVariant { int bm, bn, threads; };
+static const ConvVariant kVariants[] = {{128, 128, 256}, {128, 64, 128}, {128, 32, 128}, {64, 64, 256},
+                                        {64, 32, 128},   {128, 64, 256}, {128, 32, 256}, {64, 128, 256},
+                                        {256, 64, 256}};
+constexpr int kNumVariants = 9;
+
+int conv_variant_count() { return kNumVariants; }
+bool conv_variant_valid(int id, int cout) {
+  return id >= 0 && id < kNumVariants && round_up(cout, 32) % kVariants[id].bn == 0;
+}
+const char* conv_variant_name(int id) {
+  static const char* names[] = {"128x128", "128x64w2", "128x32w2", "64x64", "64x32w2",
+                                "128x64", "128x32", "64x128", "256x64"};
+  return id >= 0 && id < kNumVariants ? names[id] : "-";
+}
+
+int conv2d_launch(const StConvDesc& d, hipStream_t stream, int force_variant, int* picked_variant) {
   ST_REQUIRE(d.in_dev && d.wgt_dev && d.bias_dev && d.out1_dev, "conv: null pointer");
   ST_REQUIRE(d.Cin % 4 == 0 && d.in_ld % 4 == 0 && d.in_off % 4 == 0,
              "conv: Cin/in_ld/in_off must be multiples of 4 (got %d/%d/%d)", d.Cin, d.in_ld,
@@ -287,24 +317,25 @@ int conv2d_launch(const StConvDesc& d, hipStream_t stream, int force_variant) {
   a.act = d.act;
 
   const int cout_pad = round_up(d.Cout, 32);
-  // variant table: {BM, BN}; pick the largest tile that still gives >= 2 blocks per CU
-  struct V { int id, bm, bn; };
-  static const V variants[] = {{0, 128, 128}, {1, 128, 64}, {2, 128, 32}, {3, 64, 64}, {4, 64, 32}};
   int pick = -1;
   if (force_variant >= 0) {
-    ST_REQUIRE(force_variant < 5 && cout_pad % variants[force_variant].bn == 0,
-               "conv: variant %d does not divide Cout", force_variant);
+    ST_REQUIRE(conv_variant_valid(force_variant, d.Cout), "conv: variant %d does not divide Cout=%d",
+               force_variant, d.Cout);
     pick = force_variant;
   } else {
+    // untuned default: the largest tile that still gives >= 2 blocks per CU (the detector
+    // replaces this guess by a measured choice, st_detector_autotune)
+    static const int order[] = {0, 5, 6, 3, 4};
     long long best_blocks = -1;
-    for (const V& v : variants) {
-      if (cout_pad % v.bn) continue;
-      const long long blocks = (long long)ceil_div(a.M, v.bm) * (cout_pad / v.bn);
-      if (blocks >= 512) { pick = v.id; break; }
-      if (blocks > best_blocks) { best_blocks = blocks; pick = v.id; }
+    for (int id : order) {
+      if (!conv_variant_valid(id, d.Cout)) continue;
+      const long long blocks = (long long)ceil_div(a.M, kVariants[id].bm) * (cout_pad / kVariants[id].bn);
+      if (blocks >= 512) { pick = id; break; }
+      if (blocks > best_blocks) { best_blocks = blocks; pick = id; }
     }
   }
-  const V& v = variants[pick];
+  const ConvVariant& v = kVariants[pick];
+  if (picked_variant) *picked_variant = pick;
   a.n_tiles = cout_pad / v.bn;
   const int m_tiles = ceil_div(a.M, v.bm);
   switch (pick) {
@@ -312,7 +343,11 @@ int conv2d_launch(const StConvDesc& d, hipStream_t stream, int force_variant) {
     case 1: return launch_variant<2, 2, 2, 1>(a, m_tiles, stream);
     case 2: return launch_variant<2, 1, 2, 1>(a, m_tiles, stream);
     case 3: return launch_variant<1, 1, 2, 2>(a, m_tiles, stream);
-    default: return launch_variant<1, 1, 2, 1>(a, m_tiles, stream);
+    case 4: return launch_variant<1, 1, 2, 1>(a, m_tiles, stream);
+    case 5: return launch_variant<1, 2, 4, 1>(a, m_tiles, stream);
+    case 6: return launch_variant<1, 1, 4, 1>(a, m_tiles, stream);
+    case 7: return launch_variant<1, 2, 2, 2>(a, m_tiles, stream);
+    default: return launch_variant<2, 2, 4, 1>(a, m_tiles, stream);
   }
 }
 
@@ -320,11 +355,11 @@ int conv2d_launch(const StConvDesc& d, hipStream_t stream, int force_variant) {
 
 extern "C" int st_conv2d_nhwc(const StConvDesc* d, st_stream_t stream) {
   if (!d) return st::set_error(ST_ERR_INVALID, "st_conv2d_nhwc: null desc");
-  return st::conv2d_launch(*d, static_cast<hipStream_t>(stream), -1);
+  return st::conv2d_launch(*d, static_cast<hipStream_t>(stream), -1, nullptr);
 }
 
 // test hook: force a tile variant (0..4); not part of the documented ABI surface
 extern "C" int st_conv2d_nhwc_variant(const StConvDesc* d, st_stream_t stream, int variant) {
   if (!d) return st::set_error(ST_ERR_INVALID, "st_conv2d_nhwc_variant: null desc");
-  return st::conv2d_launch(*d, static_cast<hipStream_t>(stream), variant);
+  return st::conv2d_launch(*d, static_cast<hipStream_t>(stream), variant, nullptr);
 }

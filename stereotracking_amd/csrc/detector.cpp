@@ -30,7 +30,10 @@
 
 namespace st {
 
-int conv2d_launch(const StConvDesc& d, hipStream_t stream, int force_variant);
+int conv2d_launch(const StConvDesc& d, hipStream_t stream, int force_variant, int* picked_variant);
+int conv_variant_count();
+bool conv_variant_valid(int id, int cout);
+const char* conv_variant_name(int id);
 int focus_pack_launch(const float* img, int N, int C, int H, int W, float* out, hipStream_t stream);
 int spp_pool_launch(const float* x, int x_ld, int x_off, int N, int H, int W, int C, float* out,
                     int out_ld, int out_off, hipStream_t stream);
@@ -100,6 +103,9 @@ struct Op {
   float post_scale = 1.f;
   // SPP uses in (x) and out1 (cat buffer, x lives in its first C channels)
   int phase = 0;
+  double macs = 0.0;   // conv MACs of this op
+  int variant = -1;    // conv tile variant picked at the last launch
+  int tuned = -1;      // measured best variant (st_detector_autotune), -1 = heuristic
 };
 
 }  // namespace
@@ -127,6 +133,10 @@ struct StDetector {
   size_t head_floats = 0;
   std::map<std::string, TRef> taps;
   int cur_phase = 0;
+  // optional per-op timing (bench/profiling only): events on the caller's stream around every op
+  bool timing = false;
+  std::vector<hipEvent_t> events;  // 2 per op
+  int force_variant = -1;          // autotune only
 
   // ---- building blocks -------------------------------------------------------------------
   int add_param(const std::string& name, std::vector<int64_t> shape) {
@@ -194,10 +204,11 @@ struct StDetector {
     o.split = split < 0 ? convs[pc].cout : split;
     o.stride = stride; o.pad = convs[pc].k / 2; o.act = act; o.post_scale = post_scale;
     o.phase = cur_phase;
-    ops.push_back(o);
     const int Ho = (in.H + 2 * o.pad - convs[pc].k) / stride + 1;
     const int Wo = (in.W + 2 * o.pad - convs[pc].k) / stride + 1;
-    macs += (double)in.N * Ho * Wo * convs[pc].k * convs[pc].k * convs[pc].cin * convs[pc].cout;
+    o.macs = (double)in.N * Ho * Wo * convs[pc].k * convs[pc].k * convs[pc].cin * convs[pc].cout;
+    macs += o.macs;
+    ops.push_back(o);
   }
   // ConvModule helper: allocates the output unless `out` is given
   TRef convmodule(const std::string& p, const TRef& in, int cout, int k, int stride, TRef out = TRef()) {
@@ -390,6 +401,7 @@ extern "C" int st_detector_create(const StDetectorConfig* cfg, StDetector** out)
 extern "C" int st_detector_destroy(StDetector* det) {
   if (!det) return ST_OK;
   if (det->wgt_dev) (void)hipFree(det->wgt_dev);
+  for (auto& e : det->events) (void)hipEventDestroy(e);
   delete det;
   return ST_OK;
 }
@@ -478,8 +490,14 @@ float* resolve(const StDetector* det, const TRef& t, float* ws, float* head) {
 
 int run_ops(StDetector* det, int phase_lo, int phase_hi, const float* const inputs[3], float* ws,
             float* head, hipStream_t stream) {
-  for (const Op& o : det->ops) {
+  if (det->timing && det->events.size() != 2 * det->ops.size()) {
+    det->events.resize(2 * det->ops.size());
+    for (auto& e : det->events) ST_CHECK_HIP(hipEventCreate(&e));
+  }
+  for (size_t oi = 0; oi < det->ops.size(); ++oi) {
+    Op& o = det->ops[oi];
     if (o.phase < phase_lo || o.phase > phase_hi) continue;
+    if (det->timing) ST_CHECK_HIP(hipEventRecord(det->events[2 * oi], stream));
     switch (o.type) {
       case Op::FOCUS: {
         const float* src = inputs[o.focus_input];
@@ -510,10 +528,11 @@ int run_ops(StDetector* det, int phase_lo, int phase_hi, const float* const inpu
         d.up_dev = resolve(det, o.up, ws, head); d.up_ld = o.up.ld; d.up_off = o.up.off;
         d.res_dev = resolve(det, o.res, ws, head); d.res_ld = o.res.ld; d.res_off = o.res.off;
         d.post_scale = o.post_scale; d.act = o.act;
-        ST_CHECK(conv2d_launch(d, stream, -1));
+        ST_CHECK(conv2d_launch(d, stream, det->force_variant >= 0 ? det->force_variant : o.tuned, &o.variant));
         break;
       }
     }
+    if (det->timing) ST_CHECK_HIP(hipEventRecord(det->events[2 * oi + 1], stream));
   }
   return ST_OK;
 }
@@ -558,6 +577,109 @@ extern "C" int st_detector_forward_phase(StDetector* det, int phase, const float
   const float* inputs[3] = {img_dev, disp_dev, right_dev};
   return run_ops(det, phase, phase, inputs, static_cast<float*>(workspace_dev), head_out_dev,
                  static_cast<hipStream_t>(stream));
+}
+
+// Per-op timing for bench.py / profiling: when enabled, every op of the next forward is bracketed
+// by hipEvents on the caller's stream.  st_detector_op_times synchronises on those events.
+extern "C" int st_detector_set_timing(StDetector* det, int enable) {
+  if (!det) return set_error(ST_ERR_INVALID, "st_detector_set_timing: null detector");
+  det->timing = enable != 0;
+  return ST_OK;
+}
+
+extern "C" int st_detector_num_ops(const StDetector* det) { return det ? (int)det->ops.size() : 0; }
+
+// kind: 0 focus-pack, 1 conv, 2 spp; variant = conv tile variant (0..4) or -1; macs = conv MACs
+extern "C" int st_detector_op_times(StDetector* det, int cap, float* ms, int* kind, int* variant, double* macs,
+                                    int* phase) {
+  if (!det) return set_error(ST_ERR_INVALID, "st_detector_op_times: null detector");
+  ST_REQUIRE(det->events.size() == 2 * det->ops.size(), "st_detector_op_times: no timed forward has run");
+  ST_REQUIRE(cap >= (int)det->ops.size(), "st_detector_op_times: capacity %d < %zu ops", cap, det->ops.size());
+  for (size_t i = 0; i < det->ops.size(); ++i) {
+    ST_CHECK_HIP(hipEventSynchronize(det->events[2 * i + 1]));
+    float t = 0.f;
+    ST_CHECK_HIP(hipEventElapsedTime(&t, det->events[2 * i], det->events[2 * i + 1]));
+    if (ms) ms[i] = t;
+    if (kind) kind[i] = det->ops[i].type == Op::FOCUS ? 0 : det->ops[i].type == Op::CONV ? 1 : 2;
+    if (variant) variant[i] = det->ops[i].variant;
+    if (macs) macs[i] = det->ops[i].macs;
+    if (phase) phase[i] = det->ops[i].phase;
+  }
+  return ST_OK;
+}
+
+// Measure every valid tile variant of every conv op on the real shapes (HIP events on `stream`,
+// workspace contents are whatever the last forward left) and keep the fastest.  Host-synchronous;
+// call once after st_detector_finalize, outside any timed region.
+extern "C" int st_detector_autotune(StDetector* det, void* workspace_dev, size_t workspace_bytes,
+                                    float* head_out_dev, st_stream_t stream_, int reps) {
+  if (!det) return set_error(ST_ERR_INVALID, "st_detector_autotune: null detector");
+  if (!det->finalized) return set_error(ST_ERR_STATE, "st_detector_autotune: call st_detector_finalize first");
+  ST_REQUIRE(workspace_dev && head_out_dev, "st_detector_autotune: null pointer");
+  if (workspace_bytes < det->ws_floats * sizeof(float))
+    return set_error(ST_ERR_WORKSPACE, "st_detector_autotune: workspace too small");
+  if (reps <= 0) reps = 3;
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  hipEvent_t e0, e1;
+  ST_CHECK_HIP(hipEventCreate(&e0));
+  ST_CHECK_HIP(hipEventCreate(&e1));
+  const float* inputs[3] = {nullptr, nullptr, nullptr};
+  const bool was_timing = det->timing;
+  det->timing = false;
+  int rc = ST_OK;
+  std::vector<Op> saved = det->ops;
+  for (size_t oi = 0; oi < saved.size() && rc == ST_OK; ++oi) {
+    if (saved[oi].type != Op::CONV) continue;
+    // run only this op: temporarily make it the sole op of a private phase
+    det->ops.assign(1, saved[oi]);
+    det->ops[0].phase = 0;
+    float best = 1e30f;
+    int best_v = -1;
+    for (int v = 0; v < conv_variant_count() && rc == ST_OK; ++v) {
+      if (!conv_variant_valid(v, det->convs[saved[oi].pc].cout)) continue;
+      det->force_variant = v;
+      rc = run_ops(det, 0, 0, inputs, static_cast<float*>(workspace_dev), head_out_dev, stream);  // warm
+      if (rc != ST_OK) break;
+      if (hipEventRecord(e0, stream) != hipSuccess) { rc = set_error(ST_ERR_HIP, "autotune: event record"); break; }
+      for (int r = 0; r < reps && rc == ST_OK; ++r)
+        rc = run_ops(det, 0, 0, inputs, static_cast<float*>(workspace_dev), head_out_dev, stream);
+      if (rc != ST_OK) break;
+      if (hipEventRecord(e1, stream) != hipSuccess || hipEventSynchronize(e1) != hipSuccess) {
+        rc = set_error(ST_ERR_HIP, "autotune: event sync");
+        break;
+      }
+      float ms = 0.f;
+      (void)hipEventElapsedTime(&ms, e0, e1);
+      if (ms < best) { best = ms; best_v = v; }
+    }
+    saved[oi].tuned = best_v;
+  }
+  det->force_variant = -1;
+  det->ops = saved;
+  det->timing = was_timing;
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  return rc;
+}
+
+extern "C" const char* st_conv_variant_name(int id) { return conv_variant_name(id); }
+
+// Human-readable description of op i (profiling aid).
+extern "C" int st_detector_op_desc(const StDetector* det, int i, char* buf, int cap) {
+  if (!det || i < 0 || i >= (int)det->ops.size() || !buf || cap <= 0)
+    return set_error(ST_ERR_INVALID, "st_detector_op_desc: bad argument");
+  const Op& o = det->ops[i];
+  if (o.type == Op::FOCUS) {
+    snprintf(buf, (size_t)cap, "focus_pack input=%d", o.focus_input);
+  } else if (o.type == Op::SPP) {
+    snprintf(buf, (size_t)cap, "spp_pool N=%d H=%d W=%d C=%d", o.in.N, o.in.H, o.in.W, o.in.C);
+  } else {
+    const PackedConv& pc = det->convs[o.pc];
+    snprintf(buf, (size_t)cap, "conv k%d s%d N=%d Hi=%d Wi=%d Cin=%d Cout=%d%s%s%s  %s", pc.k, o.stride, o.in.N, o.in.H,
+             o.in.W, pc.cin, pc.cout, o.res.valid() ? " +res" : "", o.up.valid() ? " +up" : "",
+             o.out2.valid() ? " +split" : "", pc.srcs[0].conv_prefix.c_str());
+  }
+  return ST_OK;
 }
 
 extern "C" int st_detector_tap(const StDetector* det, const char* name, const void* workspace_dev,

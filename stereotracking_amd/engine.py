@@ -87,6 +87,15 @@ class HipDetector:
         check(self.lib.st_detector_finalize(self.handle), 'st_detector_finalize')
         self._finalized = True
 
+    def autotune(self, device=None, reps=3):
+        """Pick the fastest conv tile variant per layer by measurement (st_detector_autotune)."""
+        device = torch.device(device) if device is not None else torch.device('cuda', torch.cuda.current_device())
+        ws = self._workspace(device)
+        head = torch.empty(self.head_floats, dtype=torch.float32, device=device)
+        check(self.lib.st_detector_autotune(self.handle, ptr(ws), ws.numel(), ptr(head), current_stream(), int(reps)),
+              'st_detector_autotune')
+        torch.cuda.synchronize(device)
+
     # ---- forward -----------------------------------------------------------------------------
     def _workspace(self, device):
         if self._ws is None or self._ws.device != device:

@@ -1,0 +1,126 @@
+"""The per-frame dense compute path as one device-resident pipeline.
+
+   left/right (or left + disparity) --> [stem+stage1 features L,R] --> cost volume + soft-argmin
+   --> disp_postp --> disparity branch + fused trunk + PAFPN + head --> decode + NMS --> per-box
+   depth + depth-guided scaling  --> fixed-size detection buffer (ready for the RCCL all-gather)
+
+Everything between the input tensors and the detection buffer is enqueued on the current stream
+through the C ABI (include/stereotrack.h); no host synchronisation, no allocation after the
+first call.  Mirrors the dense part of OCSORT_Disparity.predict (reference
+mmtrack/models/mot/ocsort_disparity.py:50-83): detector.predict (:79) + bbox_postp_depth (:82-83).
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import check, current_stream, ptr
+from .engine import HipDetector, _require_cuda
+
+
+class StereoDensePipeline:
+    """Fixed-shape dense path for `batch` frames of `ori_shape` (H, W) pixels."""
+
+    def __init__(self, batch, ori_shape=(720, 1280), widen_factor=0.5, deepen_factor=0.33, num_classes=1,
+                 stereo=True, max_disp=192, feat_stride=4, temperature=32.0, score_thr=0.01, iou_thr=0.5,
+                 max_det=300, baseline=0.25, focal_length=640, pad_size_divisor=32):
+        self.lib = _lib.load()
+        self.batch = int(batch)
+        self.ori_h, self.ori_w = int(ori_shape[0]), int(ori_shape[1])
+        d = pad_size_divisor
+        self.height = (self.ori_h + d - 1) // d * d
+        self.width = (self.ori_w + d - 1) // d * d
+        self.stereo = bool(stereo)
+        if feat_stride != 4:
+            raise NotImplementedError('StereoCostVolume: only feat_stride=4 (stage1 features) is wired up')
+        if max_disp % feat_stride:
+            raise ValueError('max_disp must be a multiple of feat_stride')
+        self.max_disp, self.feat_stride = int(max_disp), int(feat_stride)
+        self.D = self.max_disp // self.feat_stride
+        self.temperature = float(temperature)
+        self.score_thr, self.iou_thr, self.max_det = float(score_thr), float(iou_thr), int(max_det)
+        self.baseline, self.focal_length = float(baseline), float(focal_length)
+        self.det = HipDetector(self.batch, self.height, self.width, widen_factor, deepen_factor, num_classes,
+                               stereo=self.stereo)
+        self._bufs = None
+
+    # ---- parameters ------------------------------------------------------------------------------
+    def param_table(self):
+        return self.det.param_table()
+
+    def load_state_dict(self, sd, prefix='', autotune=True):
+        self.det.load_state_dict(sd, prefix)
+        if autotune:
+            self.det.autotune()
+
+    # ---- buffers -----------------------------------------------------------------------------------
+    def _buffers(self, dev):
+        if self._bufs is None or self._bufs['dev'] != dev:
+            N, H, W, M = self.batch, self.height, self.width, self.max_det
+            f32 = dict(dtype=torch.float32, device=dev)
+            b = dict(dev=dev)
+            b['head'] = torch.empty(self.det.head_floats, **f32)
+            b['disp_lr'] = torch.empty(N, H // self.feat_stride, W // self.feat_stride, **f32)
+            b['disp_postp'] = torch.empty(N, 3, H, W, **f32)
+            b['depth'] = torch.empty(N, M, **f32)
+            b['scales'] = torch.empty(N, M, **f32)
+            b['scaled_boxes'] = torch.empty(N, M, 4, **f32)
+            self._bufs = b
+        return self._bufs
+
+    # ---- the hot path --------------------------------------------------------------------------------
+    def disparity(self, img, right):
+        """Stereo module: stem+stage1 features of left/right -> cost volume -> soft-argmin ->
+        bilinear x4 -> disp_postp (N,3,H,W) in pixels, 0 outside the original image."""
+        b = self._buffers(img.device)
+        self.det.forward_phase(0, img=img, right=right)
+        feat = self.det.tap('stage1_rgb')  # (2N, H/4, W/4, C) view: [left | right]
+        N = self.batch
+        Hf, Wf, Cf = feat.shape[1], feat.shape[2], feat.shape[3]
+        ld = feat.stride(2)
+        fl = feat.data_ptr()
+        fr = fl + N * Hf * Wf * ld * 4
+        check(self.lib.st_costvolume_softargmin(C.c_void_p(fl), C.c_void_p(fr), N, Hf, Wf, Cf, ld, self.D,
+                                                self.temperature, None, ptr(b['disp_lr']), current_stream()),
+              'st_costvolume_softargmin')
+        check(self.lib.st_disp_upsample_pack(ptr(b['disp_lr']), N, Hf, Wf, self.feat_stride, self.height,
+                                             self.width, self.ori_h, self.ori_w, ptr(b['disp_postp']),
+                                             current_stream()), 'st_disp_upsample_pack')
+        return b['disp_postp']
+
+    def box_depth(self, disp_postp, boxes, counts, out=None):
+        """bbox_postp_depth (ocsort_disparity.py:113-130) on device -> depth, scales, scaled boxes."""
+        b = self._buffers(disp_postp.device)
+        N, M = boxes.shape[0], boxes.shape[1]
+        depth, scales, sboxes = out if out is not None else (b['depth'], b['scales'], b['scaled_boxes'])
+        check(self.lib.st_box_depth(ptr(disp_postp), 3 * self.height * self.width, N, self.height, self.width,
+                                    ptr(boxes), ptr(counts), M, self.baseline, self.focal_length, None, 0,
+                                    current_stream(), ptr(depth), ptr(scales), ptr(sboxes)), 'st_box_depth')
+        return depth, scales, sboxes
+
+    def run(self, img, right=None, disp_postp=None):
+        """img (N,3,H,W) fp32 CUDA; stereo: right (N,3,H,W); mono: disp_postp (N,3,H,W).
+        Returns a dict of device tensors (no host sync): boxes (N,M,4) unscaled xyxy, scores, labels,
+        prior_idx, counts, depth, scales, scaled_boxes, disp_postp, head."""
+        _require_cuda(img, 'img')
+        b = self._buffers(img.device)
+        if self.stereo:
+            if right is None:
+                raise ValueError('stereo pipeline needs the right image')
+            disp_postp = self.disparity(img, right)
+            self.det.forward_phase(1, disp=disp_postp, head_out=b['head'])
+        else:
+            if disp_postp is None:
+                raise ValueError('mono pipeline needs disp_postp')
+            self.det.forward(img, disp_postp, b['head'])
+        boxes, scores, labels, prior, counts = self.det.decode_nms(
+            b['head'], self.score_thr, self.iou_thr, self.max_det, (self.ori_h, self.ori_w))
+        depth, scales, sboxes = self.box_depth(disp_postp, boxes, counts)
+        return dict(boxes=boxes, scores=scores, labels=labels, prior_idx=prior, counts=counts, depth=depth,
+                    scales=scales, scaled_boxes=sboxes, disp_postp=disp_postp, head=b['head'])
+
+    @staticmethod
+    def pack_detections(out):
+        """Fixed-size buffer for the all-gather: (N, M, 8) = x1,y1,x2,y2,score,label,depth,scale."""
+        return torch.cat([out['boxes'], out['scores'][..., None], out['labels'][..., None].float(),
+                          out['depth'][..., None], out['scales'][..., None]], dim=-1)

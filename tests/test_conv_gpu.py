@@ -115,7 +115,8 @@ def test_conv_matches_torch(case, cuda):
     assert_close(got, ref_conv(x, w, b, stride, k // 2, 1))
 
 
-@pytest.mark.parametrize('variant,cout', [(0, 128), (1, 64), (2, 32), (3, 64), (4, 32), (0, 256), (3, 128)])
+@pytest.mark.parametrize('variant,cout', [(0, 128), (1, 64), (2, 32), (3, 64), (4, 32), (0, 256), (3, 128), (5, 64),
+                                          (6, 32), (7, 128), (8, 64), (5, 192), (6, 96)])
 def test_conv_all_tile_variants(variant, cout, cuda):
     torch.manual_seed(variant)
     x = torch.randn(2, 64, 13, 21)

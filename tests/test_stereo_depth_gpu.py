@@ -1,0 +1,172 @@
+"""GPU parity of the stereo module (cost volume, soft-argmin, upsample) and of the per-box depth
+kernel against their oracles.  Cost volume and stand-alone soft-argmin / upsample are BIT-EXACT
+(same fmaf order as oracle/st_oracle.c); the fused soft-argmin merges disparity groups in a
+different order, so it is held to 1e-3 (north_star's float tolerance); box depth: exact decisions
+(-1 / NaN / scale clamps), floats within 1e-3."""
+import ctypes as C
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import c_oracle
+from oracle import depth as odepth
+from stereotracking_amd import _lib
+from stereotracking_amd._lib import check, current_stream, ptr
+
+pytestmark = pytest.mark.gpu
+
+
+def run_costvolume(fl, fr, Cc, D, T, cuda, want_cost=True):
+    lib = _lib.load()
+    N, Hf, Wf, ld = fl.shape
+    l, r = torch.from_numpy(fl).to(cuda), torch.from_numpy(fr).to(cuda)
+    cost = torch.full((N, Hf, Wf, D), float('nan'), device=cuda) if want_cost else None
+    disp = torch.full((N, Hf, Wf), float('nan'), device=cuda)
+    check(lib.st_costvolume_softargmin(ptr(l), ptr(r), N, Hf, Wf, Cc, ld, D, T, ptr(cost), ptr(disp),
+                                       current_stream()))
+    torch.cuda.synchronize()
+    return (cost.cpu().numpy() if want_cost else None), disp.cpu().numpy()
+
+
+@pytest.mark.parametrize('N,Hf,Wf,Cc,ld,D', [(2, 5, 70, 64, 64, 48), (1, 3, 130, 48, 64, 16), (1, 4, 33, 24, 24, 7),
+                                             (1, 2, 200, 32, 32, 96)])
+def test_costvolume_bit_exact_and_softargmin(N, Hf, Wf, Cc, ld, D, cuda):
+    rng = np.random.RandomState(N * 100 + D)
+    fl = rng.normal(0, 1, (N, Hf, Wf, ld)).astype(np.float32)
+    fr = rng.normal(0, 1, (N, Hf, Wf, ld)).astype(np.float32)
+    T = 8.0
+    ref_cost = c_oracle.costvolume(fl, fr, Cc, D)
+    ref_disp = c_oracle.softargmin(ref_cost, T)
+    cost, disp = run_costvolume(fl, fr, Cc, D, T, cuda)
+    assert np.array_equal(cost.view(np.uint32), ref_cost.view(np.uint32)), 'cost volume not bit-exact'
+    assert np.abs(disp - ref_disp).max() <= 1e-3 * max(1.0, ref_disp.max())
+    # streaming form (volume never written) gives the same disparity
+    _, disp2 = run_costvolume(fl, fr, Cc, D, T, cuda, want_cost=False)
+    assert np.array_equal(disp, disp2)
+    # stand-alone soft-argmin on the materialised volume: sequential order => bit-exact
+    lib = _lib.load()
+    c = torch.from_numpy(ref_cost).to(cuda)
+    o = torch.empty(N, Hf, Wf, device=cuda)
+    check(lib.st_softargmin(ptr(c), N, Hf, Wf, D, T, ptr(o), current_stream()))
+    torch.cuda.synchronize()
+    assert np.array_equal(o.cpu().numpy().view(np.uint32), ref_disp.view(np.uint32))
+
+
+def test_costvolume_recovers_known_shift(cuda):
+    """Right = left shifted by a constant disparity: soft-argmin with a sharp temperature returns it."""
+    rng = np.random.RandomState(3)
+    N, Hf, Wf, Cc, D, d_true = 1, 4, 96, 32, 24, 9
+    fr = rng.normal(0, 1, (N, Hf, Wf, Cc)).astype(np.float32)
+    fl = np.zeros_like(fr)
+    fl[:, :, d_true:] = fr[:, :, :-d_true]  # left[x] = right[x - d]
+    _, disp = run_costvolume(fl, fr, Cc, D, 64.0, cuda)
+    assert np.abs(disp[:, :, D:] - d_true).max() < 1e-2
+
+
+def test_upsample_pack_bit_exact_and_matches_torch(cuda):
+    rng = np.random.RandomState(4)
+    N, Hf, Wf, s = 2, 24, 40, 4
+    lr = rng.uniform(0, 48, (N, Hf, Wf)).astype(np.float32)
+    H, W, vh, vw = Hf * s, Wf * s, Hf * s - 16, Wf * s
+    ref = c_oracle.disp_upsample(lr, s, vh, vw)
+    lib = _lib.load()
+    out = torch.full((N, 3, H, W), float('nan'), device=cuda)
+    check(lib.st_disp_upsample_pack(ptr(torch.from_numpy(lr).to(cuda)), N, Hf, Wf, s, H, W, vh, vw, ptr(out),
+                                    current_stream()))
+    torch.cuda.synchronize()
+    got = out.cpu().numpy()
+    assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))
+    # the oracle itself agrees with torch's bilinear interpolation (align_corners=False)
+    t = torch.nn.functional.interpolate(torch.from_numpy(lr)[:, None], scale_factor=s, mode='bilinear',
+                                        align_corners=False)[:, 0].numpy() * s
+    assert np.abs(ref[:, 0, :vh] - t[:, :vh]).max() <= 1e-4 * 48 * s
+    assert np.all(ref[:, :, vh:] == 0)
+
+
+def make_disp(rng, H, W):
+    """Disparity map with structure: background far, a few nearer rectangles, invalid holes."""
+    disp = np.full((H, W), 2.0, np.float32) + rng.uniform(0, 0.5, (H, W)).astype(np.float32)
+    for _ in range(12):
+        y, x = rng.randint(0, H - 40), rng.randint(0, W - 60)
+        h, w = rng.randint(6, 40), rng.randint(6, 60)
+        disp[y:y + h, x:x + w] = rng.uniform(3, 40) + rng.uniform(0, 0.3, (h, w))
+    disp[rng.uniform(size=(H, W)) < 0.05] = 0.0
+    return disp
+
+
+def run_box_depth(disp3, boxes, counts, cuda, baseline=0.25, focal=640.0):
+    lib = _lib.load()
+    N, _, H, W = disp3.shape
+    M = boxes.shape[1]
+    d = torch.from_numpy(disp3).to(cuda)
+    b = torch.from_numpy(boxes).to(cuda)
+    c = torch.from_numpy(counts).to(cuda)
+    depth = torch.full((N, M), -7.0, device=cuda)
+    scale = torch.full((N, M), -7.0, device=cuda)
+    sb = torch.full((N, M, 4), -7.0, device=cuda)
+    check(lib.st_box_depth(ptr(d), 3 * H * W, N, H, W, ptr(b), ptr(c), M, baseline, focal, None, 0, current_stream(),
+                           ptr(depth), ptr(scale), ptr(sb)))
+    torch.cuda.synchronize()
+    return depth.cpu().numpy(), scale.cpu().numpy(), sb.cpu().numpy()
+
+
+def test_box_depth_matches_reference_semantics(cuda):
+    rng = np.random.RandomState(11)
+    N, H, W, M = 2, 160, 256, 48
+    disp = np.stack([make_disp(rng, H, W) for _ in range(N)])
+    disp3 = np.repeat(disp[:, None], 3, 1)
+    boxes = np.zeros((N, M, 4), np.float32)
+    counts = np.array([M, M - 9], np.int32)
+    for n in range(N):
+        for k in range(M):
+            x1, y1 = rng.uniform(0, W - 8), rng.uniform(0, H - 8)
+            boxes[n, k] = (x1, y1, min(W, x1 + rng.uniform(1, 90)), min(H, y1 + rng.uniform(1, 70)))
+    # edge cases the reference code has branches / quirks for
+    boxes[0, 0] = (10.2, 10.7, 10.9, 30.0)        # zero-width after int truncation -> no valid px -> -1
+    boxes[0, 1] = (0.0, 0.0, 1.9, 40.0)           # x2-2 < 0: corner slice wraps to an empty slice (NaN mean)
+    boxes[0, 2] = (0.0, 5.0, 256.0, 60.0)         # wide box
+    boxes[0, 3] = (30.0, 158.0, 60.0, 160.0)      # touches the bottom border
+    boxes[0, 4] = (-3.5, 20.0, 40.0, 50.0)        # negative coordinate: Python slice wrap -> empty
+    boxes[0, 5] = (100.0, 100.0, 101.5, 101.5)    # 1x1 box: len 1
+    hole = disp3.copy()
+    hole[0, :, 120:140, 200:230] = 0.0
+    boxes[0, 6] = (200.0, 120.0, 230.0, 140.0)    # all-invalid window -> -1
+    depth, scale, sb = run_box_depth(hole, boxes, counts, cuda)
+    for n in range(N):
+        k = int(counts[n])
+        tb = torch.from_numpy(boxes[n, :k])
+        ref_d, ref_s, ref_sb = odepth.bbox_postp_depth(tb, torch.from_numpy(hole[n:n + 1]))
+        ref_d = np.array([float(v) for v in ref_d], np.float32)
+        for i in range(k):
+            if math.isnan(ref_d[i]):
+                assert math.isnan(depth[n, i]), (n, i)
+            elif ref_d[i] == -1:
+                assert depth[n, i] == -1 and scale[n, i] == 1.0, (n, i, depth[n, i])
+            else:
+                assert abs(depth[n, i] - ref_d[i]) <= 1e-3 * max(1.0, abs(ref_d[i])), (n, i, depth[n, i], ref_d[i])
+        rs, rsb = ref_s.numpy(), ref_sb.numpy()
+        ok = ~np.isnan(rs)
+        assert np.abs(scale[n, :k][ok] - rs[ok]).max() <= 1e-3
+        assert np.abs(sb[n, :k][ok] - rsb[ok]).max() <= 1e-3 * 256
+        assert np.all(depth[n, k:] == -7.0), 'rows past counts[n] must not be written'
+    assert (depth[0, :7] == -1).sum() >= 3
+
+
+def test_box_depth_large_box_and_w_gt_800(cuda):
+    rng = np.random.RandomState(12)
+    H, W = 736, 1280
+    disp = (rng.uniform(1.2, 30.0, (H, W))).astype(np.float32)
+    disp[720:] = 0.0
+    disp3 = np.repeat(disp[None, None], 3, 1)
+    boxes = np.array([[[100.0, 50.0, 890.0, 700.0], [100.0, 50.0, 901.5, 700.0], [0.0, 0.0, 1280.0, 720.0],
+                       [600.3, 300.9, 640.2, 330.1]]], np.float32)
+    counts = np.array([4], np.int32)
+    depth, scale, sb = run_box_depth(disp3, boxes, counts, cuda)
+    ref_d, ref_s, ref_sb = odepth.bbox_postp_depth(torch.from_numpy(boxes[0]), torch.from_numpy(disp3))
+    assert ref_d[1] == -1 and ref_d[2] == -1  # w > 800
+    for i in range(4):
+        assert abs(depth[0, i] - float(ref_d[i])) <= 1e-3 * max(1.0, abs(float(ref_d[i])))
+    assert np.abs(scale[0] - ref_s.numpy()).max() <= 1e-3
+    assert np.abs(sb[0] - ref_sb.numpy()).max() <= 1e-3 * 1280
