@@ -181,7 +181,7 @@ def main():
     B = args.batch
     pipe = StereoDensePipeline(B, (720, 1280), 0.5, 0.33, 1, stereo=True, max_disp=args.max_disp, max_det=300)
     sd = synthetic_state_dict(pipe.param_table(), seed=0)
-    pipe.load_state_dict(sd)
+    pipe.load_state_dict(sd, tuning_cache=os.environ.get('ST_TUNE_CACHE'))
     # every rank gets its own 8 pairs (weak scaling: frames shard across ranks)
     batch_cpu = synthetic_batch([rank * B + i for i in range(B)], 720, 1280, args.max_disp)
     img, right = batch_cpu['img'].to(dev), batch_cpu['right'].to(dev)

@@ -175,6 +175,10 @@ int st_detector_op_desc(const StDetector* det, int i, char* buf, int cap);
 int st_detector_autotune(StDetector* det, void* workspace_dev, size_t workspace_bytes,
                          float* head_out_dev, st_stream_t stream, int reps);
 const char* st_conv_variant_name(int id);
+/* Per-op tile choice (one int per op of st_detector_num_ops, -1 = heuristic): read it after an
+ * autotune, restore it in another process to skip the measurement. */
+int st_detector_get_tuning(const StDetector* det, int* variants, int cap);
+int st_detector_set_tuning(StDetector* det, const int* variants, int n);
 /* Internal NHWC activations inside the workspace (valid after forward); name in
  * {"stage1_rgb","stage1_fused","stage2","stage3","stage4","p3","p4","p5"}.  Pixel p, channel c
  * is ptr[p*ld + c]. */

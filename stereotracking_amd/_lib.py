@@ -83,6 +83,8 @@ _PROTOS = {
     'st_detector_op_times': (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp]),
     'st_detector_autotune': (_i, [_vp, _vp, _sz, _vp, _vp, _i]),
     'st_conv_variant_name': (C.c_char_p, [_i]),
+    'st_detector_get_tuning': (_i, [_vp, _vp, _i]),
+    'st_detector_set_tuning': (_i, [_vp, _vp, _i]),
     'st_detector_op_desc': (_i, [_vp, _i, C.c_char_p, _i]),
     'st_detector_tap': (_i, [_vp, C.c_char_p, _vp, C.POINTER(_vp), C.POINTER(_i), C.POINTER(_i),
                              C.POINTER(_i), C.POINTER(_i), C.POINTER(_i)]),

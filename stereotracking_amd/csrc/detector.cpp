@@ -664,6 +664,29 @@ extern "C" int st_detector_autotune(StDetector* det, void* workspace_dev, size_t
 
 extern "C" const char* st_conv_variant_name(int id) { return conv_variant_name(id); }
 
+// Read / restore the per-op tile choice (one int per op, -1 = heuristic) so a tuning result can be
+// cached across processes (e.g. to keep autotune launches out of a rocprofv3 trace).
+extern "C" int st_detector_get_tuning(const StDetector* det, int* variants, int cap) {
+  if (!det || !variants) return set_error(ST_ERR_INVALID, "st_detector_get_tuning: null argument");
+  ST_REQUIRE(cap >= (int)det->ops.size(), "st_detector_get_tuning: capacity too small");
+  for (size_t i = 0; i < det->ops.size(); ++i) variants[i] = det->ops[i].tuned;
+  return ST_OK;
+}
+
+extern "C" int st_detector_set_tuning(StDetector* det, const int* variants, int n) {
+  if (!det || !variants) return set_error(ST_ERR_INVALID, "st_detector_set_tuning: null argument");
+  ST_REQUIRE(n == (int)det->ops.size(), "st_detector_set_tuning: expected %zu entries, got %d", det->ops.size(), n);
+  for (int i = 0; i < n; ++i) {
+    const Op& o = det->ops[i];
+    if (variants[i] < 0 || o.type != Op::CONV) continue;
+    ST_REQUIRE(conv_variant_valid(variants[i], det->convs[o.pc].cout), "st_detector_set_tuning: variant %d invalid for op %d",
+               variants[i], i);
+  }
+  for (int i = 0; i < n; ++i)
+    if (det->ops[i].type == Op::CONV) det->ops[i].tuned = variants[i];
+  return ST_OK;
+}
+
 // Human-readable description of op i (profiling aid).
 extern "C" int st_detector_op_desc(const StDetector* det, int i, char* buf, int cap) {
   if (!det || i < 0 || i >= (int)det->ops.size() || !buf || cap <= 0)

@@ -96,6 +96,16 @@ class HipDetector:
               'st_detector_autotune')
         torch.cuda.synchronize(device)
 
+    def get_tuning(self):
+        n = self.lib.st_detector_num_ops(self.handle)
+        arr = (C.c_int * n)()
+        check(self.lib.st_detector_get_tuning(self.handle, arr, n), 'st_detector_get_tuning')
+        return list(arr)
+
+    def set_tuning(self, variants):
+        arr = (C.c_int * len(variants))(*[int(v) for v in variants])
+        check(self.lib.st_detector_set_tuning(self.handle, arr, len(variants)), 'st_detector_set_tuning')
+
     # ---- forward -----------------------------------------------------------------------------
     def _workspace(self, device):
         if self._ws is None or self._ws.device != device:

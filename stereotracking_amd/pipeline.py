@@ -16,6 +16,7 @@ import torch
 from . import _lib
 from ._lib import check, current_stream, ptr
 from .engine import HipDetector, _require_cuda
+from .stereo import StereoCostVolume
 
 
 class StereoDensePipeline:
@@ -31,12 +32,9 @@ class StereoDensePipeline:
         self.height = (self.ori_h + d - 1) // d * d
         self.width = (self.ori_w + d - 1) // d * d
         self.stereo = bool(stereo)
-        if feat_stride != 4:
-            raise NotImplementedError('StereoCostVolume: only feat_stride=4 (stage1 features) is wired up')
-        if max_disp % feat_stride:
-            raise ValueError('max_disp must be a multiple of feat_stride')
+        self.stereo_module = StereoCostVolume(max_disp, feat_stride, temperature)
         self.max_disp, self.feat_stride = int(max_disp), int(feat_stride)
-        self.D = self.max_disp // self.feat_stride
+        self.D = self.stereo_module.levels
         self.temperature = float(temperature)
         self.score_thr, self.iou_thr, self.max_det = float(score_thr), float(iou_thr), int(max_det)
         self.baseline, self.focal_length = float(baseline), float(focal_length)
@@ -48,10 +46,29 @@ class StereoDensePipeline:
     def param_table(self):
         return self.det.param_table()
 
-    def load_state_dict(self, sd, prefix='', autotune=True):
+    def load_state_dict(self, sd, prefix='', autotune=True, tuning_cache=None):
+        """Upload weights; then pick conv tile variants by measurement, or restore them from
+        `tuning_cache` (a JSON file keyed by the graph signature) when it holds this graph."""
+        import json
+        import os
         self.det.load_state_dict(sd, prefix)
-        if autotune:
-            self.det.autotune()
+        if not autotune:
+            return
+        key = f'b{self.batch}_{self.height}x{self.width}_s{int(self.stereo)}_ops{self.det.lib.st_detector_num_ops(self.det.handle)}'
+        cache = {}
+        if tuning_cache and os.path.exists(tuning_cache):
+            try:
+                cache = json.load(open(tuning_cache))
+            except (OSError, ValueError):
+                cache = {}
+        if key in cache:
+            self.det.set_tuning(cache[key])
+            return
+        self.det.autotune()
+        if tuning_cache:
+            cache[key] = self.det.get_tuning()
+            os.makedirs(os.path.dirname(os.path.abspath(tuning_cache)), exist_ok=True)
+            json.dump(cache, open(tuning_cache, 'w'))
 
     # ---- buffers -----------------------------------------------------------------------------------
     def _buffers(self, dev):
@@ -73,19 +90,7 @@ class StereoDensePipeline:
         """Stereo module: stem+stage1 features of left/right -> cost volume -> soft-argmin ->
         bilinear x4 -> disp_postp (N,3,H,W) in pixels, 0 outside the original image."""
         b = self._buffers(img.device)
-        self.det.forward_phase(0, img=img, right=right)
-        feat = self.det.tap('stage1_rgb')  # (2N, H/4, W/4, C) view: [left | right]
-        N = self.batch
-        Hf, Wf, Cf = feat.shape[1], feat.shape[2], feat.shape[3]
-        ld = feat.stride(2)
-        fl = feat.data_ptr()
-        fr = fl + N * Hf * Wf * ld * 4
-        check(self.lib.st_costvolume_softargmin(C.c_void_p(fl), C.c_void_p(fr), N, Hf, Wf, Cf, ld, self.D,
-                                                self.temperature, None, ptr(b['disp_lr']), current_stream()),
-              'st_costvolume_softargmin')
-        check(self.lib.st_disp_upsample_pack(ptr(b['disp_lr']), N, Hf, Wf, self.feat_stride, self.height,
-                                             self.width, self.ori_h, self.ori_w, ptr(b['disp_postp']),
-                                             current_stream()), 'st_disp_upsample_pack')
+        self.stereo_module.compute(self.det, img, right, (self.ori_h, self.ori_w), b['disp_lr'], b['disp_postp'])
         return b['disp_postp']
 
     def box_depth(self, disp_postp, boxes, counts, out=None):

@@ -25,7 +25,8 @@ def synthetic_state_dict(param_table, seed=0, img_stats=(127.5, 73.9), disp_stat
                          prior_prob=0.01, logit_std=1.0):
     """param_table: iterable of (name, shape) in reference state_dict naming.
     Returns an OrderedDict name -> float32 tensor (BN `num_batches_tracked` not included)."""
-    g = torch.Generator().manual_seed(seed)
+    import zlib
+    g = torch.Generator()
     table = [(n, tuple(int(s) for s in shp)) for n, shp in param_table]
     shapes = dict(table)
     sd = OrderedDict()
@@ -40,6 +41,8 @@ def synthetic_state_dict(param_table, seed=0, img_stats=(127.5, 73.9), disp_stat
         return w - w.mean(dim=(1, 2, 3), keepdim=True)
 
     for name, shape in table:
+        # one RNG stream per tensor group, keyed by NAME: the result does not depend on table order
+        g.manual_seed((zlib.crc32(name.encode()) + 1000003 * int(seed)) & 0x7FFFFFFF)
         if name.endswith('.conv.weight') and len(shape) == 4:  # ConvModule conv
             fan_in = shape[1] * shape[2] * shape[3]
             prefix = name[:-len('.conv.weight')]

@@ -1,0 +1,342 @@
+"""Depth-guided OC-SORT association (host side, CPU) — the consumer of the dense path's detection
+buffer.  north_star keeps this step on the CPU; it is restated from scratch so that, fed the same
+detections, it produces the same track ids as the reference.
+
+Behavioural spec (file:line in /root/reference):
+  OCSORTTracker_Disparity.track            mmtrack/models/trackers/ocsort_tracker_disparity.py:345-618
+    init_track / update_track              :105-146   (+ kalman_tracker_base.py:55-76, base_tracker.py:54-113)
+    vel_direction(_batch), k_step_observation, last_obs   :148-185, :267-271
+    ocm_assign_ids (IoU + 0.2 * normalised velocity angle, lapjv)     :187-265
+    ocr_assign_ids (last-observation IoU, lapjv)                      :273-317
+    online_smooth (virtual KF updates over the lost gap)              :319-343
+  pop_invalid_tracks                       kalman_tracker_base.py:78-88
+  lap.lapjv(cost, extend_cost=True, cost_limit=c) is un-vendored: its published behaviour is restated in
+  `lapjv_extended` (pad to (n+m)^2 with c/2 off-blocks and a zero corner, solve, map padded matches to -1).
+  mmdet.bbox_overlaps is un-vendored: restated in `bbox_overlaps` (eps = 1e-6 on the union).
+"""
+import math
+
+import numpy as np
+import torch
+from scipy.optimize import linear_sum_assignment
+
+from .registry import MODELS
+from .structures import InstanceData
+
+
+def bbox_xyxy_to_cxcyah(b):
+    """mmtrack/structures/bbox/transforms.py:72-86."""
+    w, h = b[:, 2] - b[:, 0], b[:, 3] - b[:, 1]
+    return torch.stack([(b[:, 2] + b[:, 0]) / 2, (b[:, 3] + b[:, 1]) / 2, w / h, h], -1)
+
+
+def bbox_cxcyah_to_xyxy(b):
+    """mmtrack/structures/bbox/transforms.py:89-101."""
+    cx, cy, ratio, h = b.split((1, 1, 1, 1), dim=-1)
+    w = ratio * h
+    return torch.cat([cx - w / 2.0, cy - h / 2.0, cx + w / 2.0, cy + h / 2.0], dim=-1)
+
+
+def bbox_overlaps(b1, b2, eps=1e-6):
+    """Pairwise IoU (T,4) x (M,4) -> (T,M), fp32; mmdet.structures.bbox.bbox_overlaps, mode='iou'."""
+    a1 = (b1[:, 2] - b1[:, 0]) * (b1[:, 3] - b1[:, 1])
+    a2 = (b2[:, 2] - b2[:, 0]) * (b2[:, 3] - b2[:, 1])
+    lt = torch.max(b1[:, None, :2], b2[None, :, :2])
+    rb = torch.min(b1[:, None, 2:], b2[None, :, 2:])
+    wh = (rb - lt).clamp(min=0)
+    overlap = wh[..., 0] * wh[..., 1]
+    union = torch.max(a1[:, None] + a2[None, :] - overlap, overlap.new_tensor([eps]))
+    return overlap / union
+
+
+def lapjv_extended(cost, cost_limit):
+    """lap.lapjv(cost, extend_cost=True, cost_limit=cost_limit) -> (x, y): x[i] = column matched to row i or
+    -1, y[j] = row matched to column j or -1."""
+    cost = np.asarray(cost, dtype=np.float64)
+    # NaN costs (a NaN box out of extract_depth's empty-segment branch, ocsort_disparity.py:163-165) are
+    # undefined behaviour inside lap's C solver; here they are made unmatchable instead
+    cost = np.where(np.isfinite(cost), cost, 1e6)
+    n_rows, n_cols = cost.shape
+    n = n_rows + n_cols
+    ext = np.full((n, n), cost_limit / 2.0, dtype=np.float64)
+    ext[n_rows:, n_cols:] = 0.0
+    ext[:n_rows, :n_cols] = cost
+    r, c = linear_sum_assignment(ext)
+    x = np.full(n, -1, dtype=np.int64)
+    y = np.full(n, -1, dtype=np.int64)
+    x[r] = c
+    y[c] = r
+    x[x >= n_cols] = -1
+    y[y >= n_rows] = -1
+    return x[:n_rows].astype(np.int32), y[:n_cols].astype(np.int32)
+
+
+class _Track:
+    """State of one tracklet (the reference keeps the same items in an addict.Dict)."""
+    __slots__ = ('memo', 'mean', 'covariance', 'tentative', 'tracked', 'obs', 'saved', 'velocity')
+
+    def __init__(self):
+        self.memo = {}           # item name -> list of (1, ...) tensors, one per frame the track was fed
+        self.mean = None
+        self.covariance = None
+        self.tentative = True
+        self.tracked = True
+        self.obs = []            # per frame: associated detection box (4,) or None
+        self.saved = None        # (mean, covariance) right before the track was lost
+        self.velocity = None
+
+    @property
+    def last_frame(self):
+        return int(self.memo['frame_ids'][-1])
+
+
+@MODELS.register_module(name=['OCSORTTracker_Disparity'])
+class OCSORTTracker_Disparity:
+    def __init__(self, obj_score_thr=0.3, init_track_thr=0.7, weight_iou_with_det_scores=True, match_iou_thr=0.3,
+                 num_tentatives=3, vel_consist_weight=0.2, vel_delta_t=3, cmc=None, momentums=None,
+                 num_frames_retain=10, reid=None, **kwargs):
+        self.obj_score_thr = obj_score_thr
+        self.init_track_thr = init_track_thr
+        self.weight_iou_with_det_scores = weight_iou_with_det_scores
+        self.match_iou_thr = match_iou_thr
+        self.num_tentatives = num_tentatives
+        self.vel_consist_weight = vel_consist_weight
+        self.vel_delta_t = vel_delta_t
+        self.num_frames_retain = num_frames_retain
+        if momentums is not None:
+            raise NotImplementedError('momentum buffers are not used by the stereo configs')
+        method = cmc.get('method') if cmc is not None else None
+        if method is not None:
+            if method != 'glme_affine':
+                raise ValueError(f"Unknown cmc method '{method}', expected 'glme_affine' or None.")
+            raise NotImplementedError('Mesh-Affine CMC needs OpenCV (absent); the shipped config runs with cmc=None')
+        self.reset()
+
+    # ---- bookkeeping ---------------------------------------------------------------------------
+    def reset(self):
+        self.num_tracks = 0
+        self.tracks = {}
+
+    @property
+    def empty(self):
+        return not self.tracks
+
+    @property
+    def ids(self):
+        return list(self.tracks.keys())
+
+    @property
+    def confirmed_ids(self):
+        return [i for i, t in self.tracks.items() if not t.tentative]
+
+    @property
+    def unconfirmed_ids(self):
+        return [i for i, t in self.tracks.items() if t.tentative]
+
+    @staticmethod
+    def _last_obs(track):
+        for box in reversed(track.obs):
+            if box is not None:
+                return box
+        return None
+
+    def _k_step_observation(self, track):
+        n = len(track.obs)
+        if n == 0:
+            return torch.tensor((-1., -1., -1., -1.))
+        if n > self.vel_delta_t and track.obs[n - 1 - self.vel_delta_t] is not None:
+            return track.obs[n - 1 - self.vel_delta_t]
+        return self._last_obs(track)
+
+    @staticmethod
+    def _vel_direction(b1, b2):
+        if b1.sum() < 0 or b2.sum() < 0:
+            return torch.tensor((-1., -1.))
+        cx1, cy1 = (b1[0] + b1[2]) / 2.0, (b1[1] + b1[3]) / 2.0
+        cx2, cy2 = (b2[0] + b2[2]) / 2.0, (b2[1] + b2[3]) / 2.0
+        speed = torch.stack([cy2 - cy1, cx2 - cx1])
+        return speed / (torch.sqrt(speed[0] ** 2 + speed[1] ** 2) + 1e-6)
+
+    @staticmethod
+    def _vel_direction_batch(b1, b2):
+        cx1, cy1 = (b1[:, 0] + b1[:, 2]) / 2.0, (b1[:, 1] + b1[:, 3]) / 2.0
+        cx2, cy2 = (b2[:, 0] + b2[:, 2]) / 2.0, (b2[:, 1] + b2[:, 3]) / 2.0
+        speed = torch.stack((cy2[None, :] - cy1[:, None], cx2[None, :] - cx1[:, None]), dim=-1)
+        norm = torch.sqrt(speed[..., 0] ** 2 + speed[..., 1] ** 2) + 1e-6
+        return speed / norm[..., None]
+
+    # ---- per-object memo update ---------------------------------------------------------------------
+    def _feed(self, tid, items, frame_id):
+        """One detection assigned to track `tid` this frame: start the track or extend it."""
+        box = items['bboxes']
+        new = tid not in self.tracks
+        if new:
+            t = self.tracks[tid] = _Track()
+            for k, v in items.items():
+                t.memo[k] = [v[None]]
+            t.memo['frame_ids'] = [frame_id]
+            t.tentative = frame_id != 0          # tracks born on the first frame are confirmed at once
+            t.mean, t.covariance = self.kf.initiate(bbox_xyxy_to_cxcyah(box[None])[0].numpy().astype(np.float64))
+            t.obs = [box]
+            t.tracked = True
+            t.saved = None
+            t.velocity = torch.tensor((-1., -1.))
+            return
+        t = self.tracks[tid]
+        for k, v in items.items():
+            t.memo[k].append(v[None])
+        t.memo['frame_ids'].append(frame_id)
+        if t.tentative and len(t.memo['bboxes']) >= self.num_tentatives:
+            t.tentative = False
+        t.mean, t.covariance = self.kf.update(t.mean, t.covariance,
+                                              bbox_xyxy_to_cxcyah(box[None])[0].numpy().astype(np.float64))
+        t.tracked = True
+        t.obs.append(box)
+        t.velocity = self._vel_direction(self._k_step_observation(t), box)
+
+    def _pop_invalid(self, frame_id):
+        dead = [i for i, t in self.tracks.items()
+                if frame_id - t.last_frame >= self.num_frames_retain or (t.tentative and t.last_frame != frame_id)]
+        for i in dead:
+            del self.tracks[i]
+
+    # ---- association stages ----------------------------------------------------------------------------
+    def _assign(self, dists):
+        if dists.size > 0:
+            return lapjv_extended(dists, 1 - self.match_iou_thr)
+        return (np.full(dists.shape[0], -1, np.int32), np.full(dists.shape[1], -1, np.int32))
+
+    def ocm_assign_ids(self, ids, det_bboxes, det_scores):
+        """Observation-centric momentum: cost = 1 - IoU(KF prediction, det) + w * normalised angle between the
+        track's velocity direction and the direction (k-step-old observation -> det)."""
+        means = np.zeros((0, 4))
+        for i in ids:
+            means = np.concatenate((means, self.tracks[i].mean[:4][None]), axis=0)
+        track_boxes = bbox_cxcyah_to_xyxy(torch.from_numpy(means).to(det_bboxes))
+        ious = bbox_overlaps(track_boxes, det_bboxes[:, :4])
+        if self.weight_iou_with_det_scores:
+            ious = ious * det_scores[None]
+        dists = (1 - ious).numpy()
+        if len(ids) > 0 and len(det_bboxes) > 0:
+            vel = torch.stack([self.tracks[i].velocity.float() for i in ids])
+            kobs = torch.stack([self._k_step_observation(self.tracks[i]).float() for i in ids])
+            valid = (vel.sum(dim=1) != -2) & (kobs.sum(dim=1) != -4)
+            to_match = self._vel_direction_batch(kobs[:, :4], det_bboxes[:, :4])
+            cos = (to_match * vel[:, None, :]).sum(dim=-1).clamp(min=-1, max=1)
+            norm_angle = (torch.acos(cos) - math.pi / 2.) / math.pi
+            norm_angle = norm_angle * valid[:, None].int()
+            dists = dists + norm_angle.numpy() * self.vel_consist_weight
+        return self._assign(dists)
+
+    def ocr_assign_ids(self, track_obs, det_bboxes, det_scores):
+        """Observation-centric recovery: IoU-only matching of last observations to leftover detections."""
+        ious = bbox_overlaps(track_obs[:, :4], det_bboxes[:, :4])
+        if self.weight_iou_with_det_scores:
+            ious = ious * det_scores[None]
+        return self._assign((1 - ious).numpy())
+
+    def _online_smooth(self, track, new_box):
+        """Re-run the KF over a linear interpolation of the gap the track was lost for."""
+        last = self._last_obs(track)[:4]
+        gap = 0
+        for b in reversed(track.obs):
+            if b is not None:
+                break
+            gap += 1
+        step = (new_box[:4] - last) / (gap + 1)
+        track.mean, track.covariance = track.saved
+        for i in range(gap):
+            virt = bbox_xyxy_to_cxcyah((last + (i + 1) * step)[None])[0].numpy()
+            track.mean, track.covariance = self.kf.update(track.mean, track.covariance, virt)
+
+    # ---- main entry ---------------------------------------------------------------------------------------
+    def track(self, model, img, feats, data_sample, data_preprocessor=None, rescale=False, **kwargs):
+        det = data_sample.pred_det_instances
+        dev = det.bboxes.device
+        fields = {k: det[k].detach().cpu() for k in ('bboxes', 'labels', 'scores', 'scales', 'depth')}
+        frame_id = data_sample.metainfo.get('frame_id', -1)
+        if frame_id == 0:
+            self.reset()
+        if not hasattr(self, 'kf'):
+            self.kf = model.motion
+
+        def take(sel):
+            return {k: v[sel] for k, v in fields.items()}
+
+        if self.empty or fields['bboxes'].size(0) == 0:
+            fields = take(fields['scores'] > self.init_track_thr)
+            n_new = fields['bboxes'].size(0)
+            ids = torch.arange(self.num_tracks, self.num_tracks + n_new).to(fields['labels'])
+            self.num_tracks += n_new
+        else:
+            b = fields['bboxes']
+            keep = (fields['scores'] > self.obj_score_thr) & ((b[:, 2] - b[:, 0]) * (b[:, 3] - b[:, 1]) > 100)
+            cand = take(keep)                               # detections entering association
+            cand_ids = torch.full((cand['bboxes'].size(0),), -1, dtype=fields['labels'].dtype)
+
+            # KF predict for confirmed tracks (velocity of h zeroed while lost)
+            confirmed = self.confirmed_ids
+            for i in confirmed:
+                t = self.tracks[i]
+                if t.last_frame != frame_id - 1:
+                    t.mean[7] = 0
+                if t.tracked:
+                    t.saved = (t.mean, t.covariance)
+                t.mean, t.covariance = self.kf.predict(t.mean, t.covariance)
+
+            def split(pool, pool_ids, det_to_track, track_ids):
+                """apply one assignment: returns (matched pool, matched ids, rest pool, rest ids)"""
+                hit = torch.from_numpy(det_to_track > -1)
+                pool_ids = pool_ids.clone()
+                if hit.any():
+                    pool_ids[hit] = torch.tensor(track_ids, dtype=pool_ids.dtype)[
+                        torch.from_numpy(det_to_track[det_to_track > -1].astype(np.int64))]
+                return ({k: v[hit] for k, v in pool.items()}, pool_ids[hit],
+                        {k: v[~hit] for k, v in pool.items()}, pool_ids[~hit])
+
+            def cat(a, bb):
+                return {k: torch.cat((a[k], bb[k]), dim=0) for k in a}
+
+            # stage 1: confirmed tracks (OCM)
+            _, d2t = self.ocm_assign_ids(confirmed, cand['bboxes'], cand['scores'])
+            matched, matched_ids, rest, rest_ids = split(cand, cand_ids, d2t, confirmed)
+            # stage 2: tentative tracks (OCM)
+            tentative = self.unconfirmed_ids
+            _, d2t = self.ocm_assign_ids(tentative, rest['bboxes'], rest['scores'])
+            m2, m2_ids, rest, rest_ids = split(rest, rest_ids, d2t, tentative)
+            matched, matched_ids = cat(matched, m2), torch.cat((matched_ids, m2_ids))
+            # stage 3: observation-centric recovery on every still-unmatched track
+            all_ids = list(self.tracks.keys())
+            matched_set = set(matched_ids.tolist())
+            lost = [i for i in all_ids if i not in matched_set]
+            if lost:
+                last_obs = torch.stack([self._last_obs(self.tracks[i]) for i in lost])
+                _, d2t = self.ocr_assign_ids(last_obs, rest['bboxes'], rest['scores'])
+                m3, m3_ids, rest, rest_ids = split(rest, rest_ids, d2t, lost)
+                matched, matched_ids = cat(matched, m3), torch.cat((matched_ids, m3_ids))
+            # re-found tracks: smooth the KF over the gap; unmatched tracks: mark lost
+            for i in range(len(matched_ids)):
+                t = self.tracks[int(matched_ids[i])]
+                if not t.tracked:
+                    self._online_smooth(t, matched['bboxes'][i])
+            matched_set = set(matched_ids.tolist())
+            for i in all_ids:
+                if i not in matched_set:
+                    self.tracks[i].tracked = False
+                    self.tracks[i].obs.append(None)
+            fields = cat(matched, rest)
+            ids = torch.cat((matched_ids, rest_ids))
+            fresh = ids == -1
+            n_new = int(fresh.sum())
+            ids[fresh] = torch.arange(self.num_tracks, self.num_tracks + n_new).to(ids)
+            self.num_tracks += n_new
+
+        for j in range(len(ids)):
+            self._feed(int(ids[j]), {k: v[j] for k, v in fields.items()}, frame_id)
+        self._pop_invalid(frame_id)
+
+        out = InstanceData()
+        for k in ('bboxes', 'labels', 'scores', 'scales', 'depth'):
+            out[k] = fields[k].to(dev)
+        out.instances_id = ids.to(dev)
+        return out

@@ -1,0 +1,118 @@
+#!/usr/bin/env python
+"""Generates the golden fixtures in this directory FROM THE ORACLE (oracle/), on the CPU.
+
+The reference cannot be imported here or on the GPU box (mmcv/mmdet/mmyolo/mmengine absent) and
+ships no fixtures of its own, so these vectors pin the oracle, not the reference:
+  detector_tiny.npz    head rows of the CPU PyTorch oracle, tiny two-branch YOLOX (widen .375), 1x64x96
+  decode_nms.npz       C-oracle decode+NMS on a seeded random head (840 priors x 2 images)
+  box_depth.npz        numpy restatement of extract_depth (reference ocsort_disparity.py:136-175) on a
+                       structured disparity map, incl. the NaN / -1 / w>800-style branches
+  costvolume.npz       C-oracle cost volume + soft-argmin + upsample on seeded features
+Run:  python tests/golden/make_golden.py   (deterministic; CI checks the files are reproduced)."""
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+
+from oracle import c_oracle, depth as odepth  # noqa: E402
+from oracle.torch_model import OracleDetector, head_to_rows  # noqa: E402
+from stereotracking_amd.synthetic import synthetic_batch, synthetic_state_dict  # noqa: E402
+
+
+def detector_tiny():
+    torch.manual_seed(0)
+    torch.set_num_threads(1)
+    ora = OracleDetector(0.33, 0.375, 1).eval()
+    table = [(k, tuple(v.shape)) for k, v in ora.state_dict().items() if not k.endswith('num_batches_tracked')]
+    sd = synthetic_state_dict(table, seed=7)
+    ora.load_state_dict(sd, strict=False)
+    batch = synthetic_batch([11], 48, 96, 32)  # padded to 64 x 96
+    with torch.no_grad():
+        rows = head_to_rows(*ora(batch))
+        feats = ora.backbone(batch)
+    out = {f'head{l}': r.numpy() for l, r in enumerate(rows)}
+    out.update({f'stage{i + 2}_sum': np.float64(f.double().sum().item()) for i, f in enumerate(feats)})
+    out['img_sum'] = np.float64(batch['img'].double().sum().item())
+    out['disp_sum'] = np.float64(batch['disp_postp'].double().sum().item())
+    out['weights_seed'], out['input_seed'] = 7, 11
+    return out
+
+
+def levels_for(H, W, N):
+    lv, off = [], 0
+    for s in (8, 16, 32):
+        h, w = H // s, W // s
+        lv.append((h, w, s, off))
+        off += N * h * w * 8
+    return lv, off
+
+
+def random_head(levels, total, N, rng, mean=-2.0, std=2.0):
+    head = np.zeros(total, np.float32)
+    for h, w, s, off in levels:
+        rows = head[off:off + N * h * w * 8].reshape(N, h * w, 8)
+        rows[..., 0] = rng.normal(mean, std, rows.shape[:2])
+        rows[..., 5] = rng.normal(mean, std, rows.shape[:2])
+        rows[..., 1:3] = rng.normal(0, 1.0, rows.shape[:2] + (2,))
+        rows[..., 3:5] = rng.normal(0.5, 0.8, rows.shape[:2] + (2,))
+    return head
+
+
+def decode_nms():
+    N, H, W = 2, 160, 256
+    levels, total = levels_for(H, W, N)
+    head = random_head(levels, total, N, np.random.RandomState(21))
+    b, s, l, p, c = c_oracle.decode_nms(head, N, levels, 0.01, 0.5, 840, (H - 10, W), (1.0, 1.0), None)
+    k = int(c.max())
+    return dict(head=head, levels=np.array(levels, np.int64), boxes=b[:, :k], scores=s[:, :k], prior=p[:, :k],
+                counts=c, score_thr=0.01, iou_thr=0.5, ori_h=H - 10, ori_w=W)
+
+
+def box_depth():
+    rng = np.random.RandomState(31)
+    H, W = 96, 160
+    disp = np.full((H, W), 2.0, np.float32) + rng.uniform(0, 0.5, (H, W)).astype(np.float32)
+    for _ in range(8):
+        y, x = rng.randint(0, H - 30), rng.randint(0, W - 40)
+        h, w = rng.randint(5, 30), rng.randint(5, 40)
+        disp[y:y + h, x:x + w] = rng.uniform(3, 40) + rng.uniform(0, 0.3, (h, w))
+    disp[rng.uniform(size=(H, W)) < 0.05] = 0.0
+    disp[80:90, 100:120] = 0.0
+    disp[20:50, 20:70] = 120.0 + rng.uniform(0, 8.0, (30, 50)).astype(np.float32)  # near object: 1 < depth^2 < 3
+    boxes = [(22.0, 22.0, 68.0, 48.0), (18.5, 15.0, 75.0, 55.0)]
+    for _ in range(24):
+        x1, y1 = rng.uniform(0, W - 6), rng.uniform(0, H - 6)
+        boxes.append((x1, y1, min(W, x1 + rng.uniform(1, 70)), min(H, y1 + rng.uniform(1, 50))))
+    boxes += [(10.2, 10.7, 10.9, 30.0), (0.0, 0.0, 1.9, 40.0), (-3.5, 20.0, 40.0, 50.0), (50.0, 50.0, 51.5, 51.5),
+              (100.0, 80.0, 120.0, 90.0), (0.0, 0.0, 160.0, 96.0)]
+    boxes = np.array(boxes, np.float32)
+    disp3 = np.repeat(disp[None, None], 3, 1)
+    d, s, sb = odepth.bbox_postp_depth(torch.from_numpy(boxes), torch.from_numpy(disp3))
+    return dict(disp=disp, boxes=boxes, depth=np.array([float(v) for v in d], np.float32), scales=s.numpy(),
+                scaled_boxes=sb.numpy())
+
+
+def costvolume():
+    rng = np.random.RandomState(41)
+    N, Hf, Wf, Cc, D = 1, 6, 80, 24, 12
+    fr = rng.normal(0, 1, (N, Hf, Wf, Cc)).astype(np.float32)
+    fl = rng.normal(0, 0.2, (N, Hf, Wf, Cc)).astype(np.float32)
+    fl[:, :3, 5:] += fr[:, :3, :-5]   # top half: true disparity 5
+    fl[:, 3:, 9:] += fr[:, 3:, :-9]   # bottom half: true disparity 9
+    cost = c_oracle.costvolume(fl, fr, Cc, D)
+    lr = c_oracle.softargmin(cost, 16.0)
+    up = c_oracle.disp_upsample(lr, 4, Hf * 4 - 8, Wf * 4)
+    return dict(featL=fl, featR=fr, cost=cost, disp_lr=lr, disp_postp=up, temperature=16.0)
+
+
+if __name__ == '__main__':
+    c_oracle.build()
+    for name, fn in (('detector_tiny', detector_tiny), ('decode_nms', decode_nms), ('box_depth', box_depth),
+                     ('costvolume', costvolume)):
+        np.savez_compressed(os.path.join(HERE, name + '.npz'), **fn())
+        print('wrote', name)

@@ -1,0 +1,273 @@
+"""CPU suite (-m "not gpu"), part 2: host logic — plugin surface (registry / config merge / model
+build), containers, preprocessor, Kalman filter, LAP, OC-SORT association, frame sharding and the
+world_size-2 gloo all-gather of detection buffers."""
+import itertools
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CFG = os.path.join(ROOT, 'configs', 'stereo_tracking', 'ocsort', 'yolox_s_mmyolo_mot_airdrone_disp.py')
+
+
+# ---- plugin surface ---------------------------------------------------------------------------------
+def test_config_base_merge_and_overrides():
+    from stereotracking_amd.config import Config
+    cfg = Config.fromfile(CFG)
+    det = cfg.model.detector
+    # child overrides type + thresholds, base keys survive the merge
+    assert det.type == 'mmtrack.YOLODetector_Disparity_V1'
+    assert det.backbone.type == 'mmtrack.YOLOXCSPDarknet_Disparity_V1_MMYOLO'
+    assert det.backbone.widen_factor == 0.5 and det.backbone.deepen_factor == 0.33
+    assert det.bbox_head.head_module.num_classes == 1 and det.bbox_head.head_module.feat_channels == 256
+    assert det.test_cfg == dict(yolox_style=True, multi_label=True, score_thr=0.01, max_per_img=300,
+                                nms=dict(type='nms', iou_threshold=0.5))
+    assert cfg.model.tracker.match_iou_thr == 0.1 and cfg.model.tracker.num_frames_retain == 30
+    cfg.merge_from_dict({'model.detector.test_cfg.score_thr': 0.2})
+    assert cfg.model.detector.test_cfg.score_thr == 0.2
+
+
+def test_models_build_from_reference_shaped_config():
+    from stereotracking_amd import mot  # noqa: F401
+    from stereotracking_amd.config import Config
+    from stereotracking_amd.registry import MODELS, TASK_UTILS
+    cfg = Config.fromfile(CFG)
+    model = MODELS.build(cfg.model)
+    assert type(model).__name__ == 'OCSORT_Disparity'
+    assert type(model.detector).__name__ == 'YOLODetector_Disparity_V1'
+    assert type(model.tracker).__name__ == 'OCSORTTracker_Disparity' and model.tracker.init_track_thr == 0.7
+    assert type(model.motion).__name__ == 'KalmanFilter'
+    assert model.baseline == 0.25 and model.focal_length == 640
+    keys = set(model.state_dict().keys())
+    for k in ('detector.backbone.stem.conv.conv.weight', 'detector.backbone.disp_stem.conv.bn.running_mean',
+              'detector.backbone.disp_stage1.1.blocks.0.conv1.bn.num_batches_tracked',
+              'detector.neck.reduce_layers.2.conv.weight', 'detector.bbox_head.head_module.multi_level_conv_reg.1.bias'):
+        assert k in keys, k
+    for name in ('OCSORT_Disparity', 'mmtrack.YOLODetector_Disparity_V1', 'YOLOXPAFPN', 'YOLOXHead',
+                 'YOLOXHeadModule', 'TrackDataPreprocessor_Disparity_V1', 'OCSORTTracker_Disparity',
+                 'StereoCostVolume'):
+        assert name in MODELS, name
+    assert 'KalmanFilter' in TASK_UTILS
+    with pytest.raises(KeyError):
+        MODELS.build(dict(type='NoSuchModel'))
+    with pytest.raises(NotImplementedError):
+        MODELS.build(dict(type='YOLOXCSPDarknet_Disparity_V1_MMYOLO', use_depthwise=True))
+    # checkpoints in the reference layout load with plain load_state_dict
+    from stereotracking_amd.synthetic import synthetic_state_dict
+    sd = synthetic_state_dict(model.detector._table, seed=3)
+    missing, unexpected = model.detector.load_state_dict(sd, strict=False)
+    assert not unexpected and all(k.endswith('num_batches_tracked') for k in missing)
+    with pytest.raises(RuntimeError, match='HIP path only'):
+        z = torch.zeros(1, 3, 64, 96)
+        model.detector.predict(dict(img=z, disp_postp=z), [])
+
+
+def test_structures_and_preprocessor():
+    from stereotracking_amd.mot import TrackDataPreprocessor_Disparity_V1, stack_batch
+    from stereotracking_amd.structures import InstanceData, TrackDataSample
+    inst = InstanceData(bboxes=torch.arange(12.).view(3, 4), scores=torch.tensor([.9, .2, .5]))
+    assert len(inst) == 3 and 'scores' in inst and len(inst[inst.scores > .3]) == 2
+    inst['labels'] = torch.zeros(3, dtype=torch.long)
+    c = inst.clone()
+    c.bboxes[0, 0] = 100
+    assert inst.bboxes[0, 0] == 0
+    with pytest.raises(ValueError):
+        inst['bad'] = torch.zeros(2)
+    s = TrackDataSample(dict(frame_id=3, ori_shape=(720, 1280)))
+    s.pred_det_instances = inst
+    assert s.frame_id == 3 and s.metainfo['ori_shape'] == (720, 1280) and len(s.pred_det_instances) == 3
+    x = stack_batch([torch.ones(1, 3, 720, 1280)], 32, 0)
+    assert x.shape == (1, 1, 3, 736, 1280) and x[0, 0, :, 720:].abs().sum() == 0
+    pre = TrackDataPreprocessor_Disparity_V1(pad_size_divisor=32, device='cpu')
+    data = dict(inputs=dict(img=[torch.full((1, 3, 50, 70), 7, dtype=torch.uint8)],
+                            disp_postp=[torch.ones(1, 3, 50, 70)]), data_samples=[s])
+    out = pre(data)
+    assert out['inputs']['img'].shape == (1, 1, 3, 64, 96) and out['inputs']['img'].dtype == torch.float32
+    assert s.metainfo['batch_input_shape'] == (64, 96) and s.metainfo['pad_shape'] == (50, 70)
+
+
+# ---- motion / association --------------------------------------------------------------------------------
+def test_kalman_filter_closed_form():
+    from stereotracking_amd.motion import KalmanFilter
+    kf = KalmanFilter()
+    z = np.array([100., 50., 0.5, 40.])
+    mean, cov = kf.initiate(z)
+    assert np.allclose(mean, [100, 50, .5, 40, 0, 0, 0, 0])
+    assert np.allclose(np.diag(cov), np.square([4, 4, 1e-2, 4, 2.5, 2.5, 1e-5, 2.5]))
+    m1, c1 = kf.predict(mean, cov)
+    assert np.allclose(m1, mean)  # zero velocity
+    assert np.isclose(c1[0, 0], 16 + 6.25 + 4.0) and np.isclose(c1[0, 4], 6.25) and np.isclose(c1[4, 4], 6.25 + 0.0625)
+    # scalar Kalman gain on x: P/(P+R)
+    z2 = np.array([110., 50., 0.5, 40.])
+    m2, c2 = kf.update(m1, c1, z2)
+    P, R = c1[0, 0], 4.0
+    assert np.isclose(m2[0], 100 + P / (P + R) * 10) and np.isclose(c2[0, 0], P - P * P / (P + R))
+    assert np.isclose(m2[4], c1[4, 0] / (P + R) * 10)
+
+
+def test_lapjv_extended_is_optimal_and_respects_cost_limit():
+    from stereotracking_amd.trackers import lapjv_extended
+    rng = np.random.RandomState(0)
+    for n, m in [(3, 3), (4, 2), (2, 5), (5, 6), (1, 1)]:
+        for _ in range(5):
+            cost = rng.uniform(0, 1.2, (n, m))
+            limit = 0.9
+            x, y = lapjv_extended(cost, limit)
+            assert len(x) == n and len(y) == m
+            for i, j in enumerate(x):
+                if j >= 0:
+                    assert y[j] == i
+            got = sum(cost[i, j] for i, j in enumerate(x) if j >= 0) + limit / 2 * ((x < 0).sum() + (y < 0).sum())
+            # brute force over partial matchings of the same extended objective
+            best = np.inf
+            for k in range(min(n, m) + 1):
+                for rows in itertools.combinations(range(n), k):
+                    for cols in itertools.permutations(range(m), k):
+                        v = sum(cost[r, c] for r, c in zip(rows, cols)) + limit / 2 * (n + m - 2 * k)
+                        best = min(best, v)
+            assert np.isclose(got, best), (cost, x, y)
+            assert all(cost[i, j] <= limit + 1e-12 for i, j in enumerate(x) if j >= 0)
+
+
+class _Model:
+    def __init__(self):
+        from stereotracking_amd.motion import KalmanFilter
+        self.motion = KalmanFilter()
+
+
+def synthetic_stream(num_frames=64, K=6, seed=0, drop_prob=0.08, noise=0.4):
+    """K rectangles with constant velocity + noise, depth-consistent scales."""
+    rng = np.random.RandomState(seed)
+    pos = rng.uniform([100, 80], [1100, 600], (K, 2))
+    vel = rng.uniform(-4, 4, (K, 2))
+    size = rng.uniform(12, 50, (K, 2))
+    depth = rng.uniform(5, 60, K)
+    frames = []
+    for t in range(num_frames):
+        p = pos + vel * t + rng.normal(0, noise, (K, 2))
+        keep = (rng.uniform(size=K) > drop_prob) | (t == 0)
+        b = np.concatenate([p - size / 2, p + size / 2], 1)[keep].astype(np.float32)
+        frames.append(dict(bboxes=torch.from_numpy(b), scores=torch.full((len(b),), 0.9),
+                           labels=torch.zeros(len(b), dtype=torch.long), scales=torch.ones(len(b)),
+                           depth=torch.from_numpy(depth[keep].astype(np.float32)), gt=np.nonzero(keep)[0]))
+    return frames
+
+
+def run_tracker(frames, **kw):
+    from stereotracking_amd.structures import InstanceData, TrackDataSample
+    from stereotracking_amd.trackers import OCSORTTracker_Disparity
+    args = dict(obj_score_thr=0.3, init_track_thr=0.7, weight_iou_with_det_scores=False, match_iou_thr=0.1,
+                num_tentatives=3, vel_consist_weight=0.2, vel_delta_t=3, num_frames_retain=30)
+    args.update(kw)
+    trk = OCSORTTracker_Disparity(**args)
+    model = _Model()
+    out = []
+    for t, f in enumerate(frames):
+        s = TrackDataSample(dict(frame_id=t))
+        s.pred_det_instances = InstanceData(**{k: f[k] for k in ('bboxes', 'scores', 'labels', 'scales', 'depth')})
+        out.append(trk.track(model, None, None, s))
+    return trk, out
+
+
+def test_tracker_keeps_identities_on_a_clean_stream():
+    frames = synthetic_stream(64, 6, seed=1)
+    trk, out = run_tracker(frames)
+    # every object keeps ONE id over the whole sequence, across the dropped frames (OCR re-association)
+    gt_to_ids = {}
+    for f, o in zip(frames, out):
+        assert len(o) == len(f['gt'])
+        for row in range(len(o)):
+            j = int(torch.argmin((f['bboxes'] - o.bboxes[row]).abs().sum(1)))
+            gt_to_ids.setdefault(int(f['gt'][j]), set()).add(int(o.instances_id[row]))
+    assert all(len(v) == 1 for v in gt_to_ids.values()), gt_to_ids
+    assert len(set.union(*gt_to_ids.values())) == 6
+    assert set(out[0].keys()) >= {'bboxes', 'labels', 'scores', 'scales', 'depth', 'instances_id'}
+
+
+def test_tracker_reference_semantics_first_frame_tentative_and_retain():
+    f0 = dict(bboxes=torch.tensor([[10., 10, 50, 50], [200., 200, 260, 260]]), scores=torch.tensor([0.9, 0.5]),
+              labels=torch.zeros(2, dtype=torch.long), scales=torch.ones(2), depth=torch.ones(2))
+    far = dict(bboxes=torch.tensor([[600., 400, 650, 450]]), scores=torch.tensor([0.4]),
+               labels=torch.zeros(1, dtype=torch.long), scales=torch.ones(1), depth=torch.ones(1))
+    empty = {k: v[:0] for k, v in f0.items()}
+    strong = dict(far, scores=torch.tensor([0.95]))
+    trk, out = run_tracker([f0, far, empty, far, strong], num_frames_retain=2)
+    # frame 0: only score > init_track_thr starts a track, born confirmed
+    assert out[0].instances_id.tolist() == [0]
+    # frame 1: unmatched det with score 0.4 (> obj_score_thr, <= init_track_thr) still starts a (tentative) track
+    assert out[1].instances_id.tolist() == [1]
+    # frame 2 (no detections): tentative track 1 is popped, track 0 (lost 2 >= num_frames_retain) too ->
+    # frame 3 sees an EMPTY tracker, where only score > init_track_thr may start a track: 0.4 does not
+    assert out[2].instances_id.tolist() == [] and out[3].instances_id.tolist() == []
+    # frame 4: a strong detection starts id 2 (ids are never reused); it is tentative and unmatched... but it
+    # was fed THIS frame, so it survives pop_invalid_tracks
+    assert out[4].instances_id.tolist() == [2]
+    trk2, _ = run_tracker([f0, far, empty, far, strong], num_frames_retain=2)
+    assert sorted(trk2.tracks.keys()) == [2] and trk2.tracks[2].tentative
+    # small boxes (area <= 100) never enter association
+    tiny = dict(bboxes=torch.tensor([[10., 10, 19, 19]]), scores=torch.tensor([0.95]),
+                labels=torch.zeros(1, dtype=torch.long), scales=torch.ones(1), depth=torch.ones(1))
+    trk, out = run_tracker([f0, tiny])
+    assert len(out[1]) == 0
+    with pytest.raises(ValueError):
+        from stereotracking_amd.trackers import OCSORTTracker_Disparity
+        OCSORTTracker_Disparity(cmc=dict(method='bogus'))
+
+
+# ---- sharding + all-gather (world_size 2, gloo) ---------------------------------------------------------------
+def _free_port():
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, frames_total, q):
+    import torch.distributed as dist
+    from stereotracking_amd import dist as sdist
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    start, stop, chunk = sdist.shard_frames(frames_total)
+    M = 5
+    local = torch.zeros(chunk, M, 8)
+    counts = torch.zeros(chunk, dtype=torch.int32)
+    for i, t in enumerate(range(start, stop)):
+        k = t % M + 1
+        counts[i] = k
+        local[i, :k, 4] = t            # score slot carries the global frame index
+        local[i, :k, 0] = torch.arange(k)
+    full, call = sdist.gather_detections(local, counts)
+    q.put((rank, full[:, :, 4].max(dim=1)[0].tolist(), call.tolist(), sdist.shard_videos(5)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_frame_sharding_and_allgather_world2_gloo():
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    T = 7  # ragged: 4 + 3 frames
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, T, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, frame_idx, counts, vids in res:
+        # every rank holds all frames in frame order; the padded 8th slot has count 0
+        assert frame_idx[:T] == [float(t) for t in range(T)] and counts[:T] == [t % 5 + 1 for t in range(T)]
+        assert counts[T:] == [0]
+    assert res[0][3] == [0, 1, 2] and res[1][3] == [3, 4]  # reference video split (np.array_split)
+
+
+def test_shard_frames_single_process():
+    from stereotracking_amd import dist as sdist
+    assert sdist.shard_frames(512, 3, 8) == (192, 256, 64)
+    assert sdist.shard_frames(10, 3, 4) == (9, 10, 3)
+    assert sdist.shard_frames(2, 3, 4) == (2, 2, 1)
+    x = torch.zeros(2, 3, 8)
+    assert sdist.gather_detections(x) is x

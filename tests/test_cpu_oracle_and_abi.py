@@ -1,0 +1,239 @@
+"""CPU suite (-m "not gpu"), part 1: the oracle against independent formulations and the committed
+golden vectors; the C ABI exports every symbol include/stereotrack.h declares (no compute calls)."""
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import c_oracle
+from oracle import depth as odepth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, 'tests', 'golden')
+
+
+# ---- C ABI -------------------------------------------------------------------------------------------
+def header_functions():
+    src = open(os.path.join(ROOT, 'include', 'stereotrack.h')).read()
+    src = re.sub(r'/\*.*?\*/', '', src, flags=re.S)
+    return sorted(set(re.findall(r'\b(st_[a-z0-9_]+)\s*\(', src)))
+
+
+def test_library_exports_every_declared_symbol(stlib):
+    from stereotracking_amd import _lib
+    names = header_functions()
+    assert len(names) >= 30
+    for n in names:
+        assert hasattr(stlib, n), f'{n} declared in include/stereotrack.h but not exported'
+        assert n in _lib._PROTOS, f'{n} has no ctypes prototype'
+    assert stlib.st_version() == 100
+
+
+def test_struct_sizes_match_the_library(stlib):
+    """A struct_size mismatch is reported, not crashed on."""
+    import ctypes as C
+    from stereotracking_amd._lib import StDetectorConfig
+    cfg = StDetectorConfig(4, 0.5, 0.33, 1, 1, 64, 64, 1e-3, 0)  # wrong struct_size
+    h = C.c_void_p()
+    assert stlib.st_detector_create(C.byref(cfg), C.byref(h)) == -1
+    assert b'struct_size' in stlib.st_last_error()
+    cfg = StDetectorConfig(C.sizeof(StDetectorConfig), 0.5, 0.33, 1, 1, 70, 64, 1e-3, 0)  # H not /32
+    assert stlib.st_detector_create(C.byref(cfg), C.byref(h)) == -1
+
+
+def test_param_table_equals_reference_state_dict_layout():
+    from oracle.torch_model import OracleDetector
+    from stereotracking_amd.engine import HipDetector
+    for widen in (0.375, 0.5):
+        det = HipDetector(1, 64, 96, widen, 0.33, 1)
+        table = dict(det.param_table())
+        sd = {k: tuple(v.shape) for k, v in OracleDetector(0.33, widen, 1).state_dict().items()
+              if not k.endswith('num_batches_tracked')}
+        assert table == sd
+        assert 'backbone.disp_stage1.1.blocks.0.conv2.bn.running_var' in table
+        assert 'neck.top_down_layers.0.1.conv.weight' in table
+        assert 'bbox_head.head_module.multi_level_conv_obj.2.bias' in table
+    # analytic cost of the path (33.478 GMAC per frame-pair at 736x1280, YOLOX-s)
+    det = HipDetector(1, 736, 1280, 0.5, 0.33, 1)
+    assert abs(det.macs / 1e9 - 33.478) < 0.01
+    assert det.num_priors == 19320
+
+
+def test_forward_without_gpu_fails_loudly():
+    from stereotracking_amd.engine import HipDetector
+    det = HipDetector(1, 64, 96, 0.375, 0.33, 1)
+    x = torch.zeros(1, 3, 64, 96)
+    with pytest.raises(RuntimeError, match='CUDA'):
+        det.forward(x, x)
+
+
+# ---- oracle: exact helpers -------------------------------------------------------------------------------
+def test_oracle_expf_is_within_2ulp_of_libm():
+    lib = c_oracle.load()
+    x = np.concatenate([np.linspace(-87, 88, 4001), np.linspace(-1, 1, 1001)]).astype(np.float32)
+    got = np.array([lib.oracle_expf(float(v)) for v in x], np.float32)
+    ref = np.exp(x.astype(np.float64))
+    ulp = np.abs(got.astype(np.float64) - ref) / np.spacing(ref.astype(np.float32)).astype(np.float64)
+    assert ulp.max() <= 2.0
+    assert lib.oracle_expf(0.0) == 1.0 and lib.oracle_expf(float(np.float32(np.log(2.0)))) == 2.0
+    assert lib.oracle_expf(-200.0) == 0.0 and np.isinf(lib.oracle_expf(100.0))
+
+
+# ---- oracle: decode + NMS --------------------------------------------------------------------------------
+def torch_decode_nms(head, N, levels, score_thr, iou_thr, ori_shape):
+    """Independent formulation with torch ops (sigmoid/exp from ATen, brute-force greedy NMS)."""
+    outs = []
+    for n in range(N):
+        rows, priors, strides = [], [], []
+        for h, w, s, off in levels:
+            r = torch.from_numpy(head[off:off + N * h * w * 8].reshape(N, h * w, 8)[n])
+            ys, xs = torch.meshgrid(torch.arange(h), torch.arange(w), indexing='ij')
+            priors.append(torch.stack([xs.reshape(-1) * s, ys.reshape(-1) * s], -1).float())
+            strides.append(torch.full((h * w,), float(s)))
+            rows.append(r)
+        r, p, s = torch.cat(rows), torch.cat(priors), torch.cat(strides)
+        score = torch.sigmoid(r[:, 0]) * torch.sigmoid(r[:, 5])
+        xy = r[:, 1:3] * s[:, None] + p
+        wh = r[:, 3:5].exp() * s[:, None]
+        boxes = torch.cat([xy - wh / 2, xy + wh / 2], -1)
+        idx = torch.nonzero(score > score_thr)[:, 0]
+        order = idx[torch.sort(score[idx], descending=True, stable=True)[1]]
+        keep = []
+        sup = torch.zeros(len(order), dtype=torch.bool)
+        b = boxes[order]
+        area = (b[:, 2] - b[:, 0]) * (b[:, 3] - b[:, 1])
+        for i in range(len(order)):
+            if sup[i]:
+                continue
+            keep.append(i)
+            lt = torch.max(b[i, :2], b[i + 1:, :2])
+            rb = torch.min(b[i, 2:], b[i + 1:, 2:])
+            wh_ = (rb - lt).clamp(min=0)
+            inter = wh_[:, 0] * wh_[:, 1]
+            sup[i + 1:] |= inter / (area[i] + area[i + 1:] - inter) > iou_thr
+        kb = b[keep].clone()
+        kb[:, 0::2] = kb[:, 0::2].clamp(0, ori_shape[1])
+        kb[:, 1::2] = kb[:, 1::2].clamp(0, ori_shape[0])
+        outs.append((order[keep].numpy(), kb.numpy(), score[order[keep]].numpy()))
+    return outs
+
+
+def test_oracle_decode_nms_matches_torch_formulation_and_golden():
+    g = np.load(os.path.join(GOLD, 'decode_nms.npz'))
+    levels = [tuple(int(v) for v in l) for l in g['levels']]
+    N = 2
+    ori = (int(g['ori_h']), int(g['ori_w']))
+    b, s, l, p, c = c_oracle.decode_nms(g['head'], N, levels, float(g['score_thr']), float(g['iou_thr']), 840, ori)
+    # golden: bit-exact regression pin of the oracle
+    assert np.array_equal(c, g['counts'])
+    k = int(c.max())
+    assert np.array_equal(p[:, :k], g['prior']) and np.array_equal(b[:, :k], g['boxes'])
+    assert np.array_equal(s[:, :k], g['scores'])
+    # independent torch formulation: same kept set and order, floats within 1e-4 relative
+    ref = torch_decode_nms(g['head'], N, levels, float(g['score_thr']), float(g['iou_thr']), ori)
+    for n in range(N):
+        idx, rb, rs = ref[n]
+        kk = int(c[n])
+        assert kk == len(idx) and np.array_equal(p[n, :kk], idx)
+        assert np.allclose(b[n, :kk], rb, rtol=1e-5, atol=1e-3)
+        assert np.allclose(s[n, :kk], rs, rtol=1e-5, atol=1e-7)
+
+
+def test_oracle_nms_properties():
+    """Kept boxes are mutually non-overlapping above thr; every dropped candidate overlaps an earlier kept one."""
+    g = np.load(os.path.join(GOLD, 'decode_nms.npz'))
+    levels = [tuple(int(v) for v in l) for l in g['levels']]
+    thr = 0.5
+    # shift every box by +2000 px (negative pad_param) so the final clamp to [0, ori] never bites and the
+    # returned boxes are exactly the ones NMS ran on
+    shift = (-2000.0, 0.0, -2000.0, 0.0)
+    b, s, l, p, c = c_oracle.decode_nms(g['head'], 2, levels, 0.01, thr, 840, (1e6, 1e6), (1.0, 1.0), shift)
+    ball, sall, _, pall, call = c_oracle.decode_nms(g['head'], 2, levels, 0.01, 2.0, 840, (1e6, 1e6), (1.0, 1.0),
+                                                    shift)  # thr > 1: no suppression
+    assert b[:, :int(c.min())].min() > 0
+
+    def iou(a, bb):
+        lt, rb = np.maximum(a[:2], bb[:, :2]), np.minimum(a[2:], bb[:, 2:])
+        wh = np.clip(rb - lt, 0, None)
+        inter = wh[:, 0] * wh[:, 1]
+        return inter / ((a[2] - a[0]) * (a[3] - a[1]) + (bb[:, 2] - bb[:, 0]) * (bb[:, 3] - bb[:, 1]) - inter)
+
+    for n in range(2):
+        k, ka = int(c[n]), int(call[n])
+        assert np.all(np.diff(s[n, :k]) <= 0), 'kept boxes must come in score order'
+        for i in range(k):
+            assert np.all(iou(b[n, i], b[n, :i]) <= thr + 1e-6)
+        kept = set(p[n, :k].tolist())
+        for j in range(ka):
+            if int(pall[n, j]) in kept:
+                continue
+            earlier = [i for i in range(k) if s[n, i] >= sall[n, j]]
+            assert np.any(iou(ball[n, j], b[n, earlier]) > thr - 1e-6)
+
+
+# ---- oracle: stereo module -----------------------------------------------------------------------------------
+def test_oracle_costvolume_softargmin_upsample_vs_numpy_torch_and_golden():
+    g = np.load(os.path.join(GOLD, 'costvolume.npz'))
+    fl, fr = g['featL'], g['featR']
+    N, Hf, Wf, Cc = fl.shape
+    D = g['cost'].shape[-1]
+    cost = c_oracle.costvolume(fl, fr, Cc, D)
+    assert np.array_equal(cost, g['cost'])
+    ref = np.zeros_like(cost, dtype=np.float64)
+    for d in range(D):
+        ref[:, :, d:, d] = (fl[:, :, d:].astype(np.float64) * fr[:, :, :Wf - d]).sum(-1) / Cc
+    assert np.abs(cost - ref).max() < 1e-5
+    T = float(g['temperature'])
+    lr = c_oracle.softargmin(cost, T)
+    assert np.array_equal(lr, g['disp_lr'])
+    sm = torch.softmax(torch.from_numpy(cost).double() * T, -1)
+    ref_lr = (sm * torch.arange(D, dtype=torch.float64)).sum(-1).numpy()
+    assert np.abs(lr - ref_lr).max() < 1e-4
+    # known answer: top half shifted by 5, bottom half by 9 (away from the left border)
+    # (soft-argmin of noisy features: most pixels land on the true shift, a few are pulled by a second peak)
+    assert np.mean(np.abs(lr[0, :3, 16:] - 5) < 0.05) > 0.9 and np.mean(np.abs(lr[0, 3:, 16:] - 9) < 0.05) > 0.9
+    assert abs(np.median(lr[0, :3, 16:]) - 5) < 1e-3 and abs(np.median(lr[0, 3:, 16:]) - 9) < 1e-3
+    up = c_oracle.disp_upsample(lr, 4, Hf * 4 - 8, Wf * 4)
+    assert np.array_equal(up, g['disp_postp'])
+    t = torch.nn.functional.interpolate(torch.from_numpy(lr)[:, None], scale_factor=4, mode='bilinear',
+                                        align_corners=False)[:, 0].numpy() * 4
+    assert np.abs(up[:, 0, :Hf * 4 - 8] - t[:, :Hf * 4 - 8]).max() < 1e-4
+    assert np.all(up[:, :, Hf * 4 - 8:] == 0) and np.array_equal(up[:, 0], up[:, 2])
+
+
+# ---- oracle: per-box depth -------------------------------------------------------------------------------------
+def test_oracle_box_depth_golden_and_branches():
+    g = np.load(os.path.join(GOLD, 'box_depth.npz'))
+    disp3 = np.repeat(g['disp'][None, None], 3, 1)
+    d, s, sb = odepth.bbox_postp_depth(torch.from_numpy(g['boxes']), torch.from_numpy(disp3))
+    d = np.array([float(v) for v in d], np.float32)
+    assert np.array_equal(np.isnan(d), np.isnan(g['depth']))
+    ok = ~np.isnan(d)
+    assert np.array_equal(d[ok], g['depth'][ok]) and np.array_equal(s.numpy()[ok], g['scales'][ok])
+    assert np.array_equal(sb.numpy()[ok], g['scaled_boxes'][ok])
+    # the fixture exercises every branch of extract_depth
+    assert (d == -1).sum() >= 3, 'empty window / wrapped slice / all-invalid window'
+    assert np.isnan(d).sum() >= 1, 'len 1 with all corners above the median -> empty segment -> NaN'
+    assert ((g['scales'] > 1) & (g['scales'] < 3)).sum() >= 2, 'unclamped d*d'
+    assert (g['scales'] == 3).sum() >= 5
+
+
+def test_oracle_detector_golden():
+    from oracle.torch_model import OracleDetector, head_to_rows
+    from stereotracking_amd.synthetic import synthetic_batch, synthetic_state_dict
+    g = np.load(os.path.join(GOLD, 'detector_tiny.npz'))
+    torch.set_num_threads(1)
+    ora = OracleDetector(0.33, 0.375, 1).eval()
+    table = [(k, tuple(v.shape)) for k, v in ora.state_dict().items() if not k.endswith('num_batches_tracked')]
+    ora.load_state_dict(synthetic_state_dict(table, seed=int(g['weights_seed'])), strict=False)
+    batch = synthetic_batch([int(g['input_seed'])], 48, 96, 32)
+    assert abs(batch['img'].double().sum().item() - float(g['img_sum'])) < 1e-6
+    with torch.no_grad():
+        rows = head_to_rows(*ora(batch))
+    for l, r in enumerate(rows):
+        ref = g[f'head{l}']
+        assert r.shape == ref.shape
+        # same code, same seeds: only the BLAS/oneDNN summation order may differ between hosts
+        assert np.abs(r.numpy() - ref).max() <= 1e-4 * max(1.0, np.abs(ref).max())

@@ -73,7 +73,8 @@ def test_upsample_pack_bit_exact_and_matches_torch(cuda):
     ref = c_oracle.disp_upsample(lr, s, vh, vw)
     lib = _lib.load()
     out = torch.full((N, 3, H, W), float('nan'), device=cuda)
-    check(lib.st_disp_upsample_pack(ptr(torch.from_numpy(lr).to(cuda)), N, Hf, Wf, s, H, W, vh, vw, ptr(out),
+    lr_dev = torch.from_numpy(lr).to(cuda)  # keep alive: ptr() does not hold a reference
+    check(lib.st_disp_upsample_pack(ptr(lr_dev), N, Hf, Wf, s, H, W, vh, vw, ptr(out),
                                     current_stream()))
     torch.cuda.synchronize()
     got = out.cpu().numpy()
