@@ -4,7 +4,7 @@
 // (reference mmtrack/models/mot/ocsort_disparity.py:113-175) and scale_bbox
 // (mmtrack/models/trackers/utils.py:58-73).  The reference copies the whole depth map to the
 // host (3.77 MB + sync) and loops over boxes in numpy, twice per frame; here one workgroup per
-// box streams its window straight from the disparity map (HBM/L2 -> registers), so nothing
+// box streams its window straight from the disparity map (HBM/L2 -> registers -> LDS), so nothing
 // leaves the GPU.
 //
 // numpy semantics that are reproduced on purpose (SURVEY.md §7 "hard parts"):
@@ -18,9 +18,11 @@
 //     seg = sorted[int(w_start):int(w_end)], empty => sorted[:-1], still empty => NaN
 //   * scale = max(min(d*d, 3.), 1.) with Python min/max NaN behaviour (NaN propagates)
 // Order statistics come from an 8-bit-per-pass radix select on the float bit patterns (valid
-// depths are positive, so the unsigned order equals the float order); the trimmed mean is
-// accumulated in fp64 and rounded once (numpy uses fp32 pairwise summation: equal to ~1e-6
-// relative, inside the 1e-3 float tolerance of the path).
+// depths are positive, so the unsigned order equals the float order); the two segment bounds are
+// selected together (two histograms per pass); the trimmed mean is accumulated in fp64 and rounded
+// once (numpy uses fp32 pairwise summation: equal to ~1e-6 relative, inside the 1e-3 float
+// tolerance of the path).  Windows of up to 12288 pixels (every realistic drone box) are cached in
+// LDS by the counting pass, so the 9 following passes never touch memory again.
 #include <algorithm>
 
 #include "st_common.h"
@@ -28,6 +30,8 @@
 namespace st {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int BD_CACHE = 12288;  // floats of LDS window cache (48 KiB)
 
 __device__ __forceinline__ int py_slice_index(int i, int len) {
   if (i < 0) {
@@ -39,51 +43,107 @@ __device__ __forceinline__ int py_slice_index(int i, int len) {
   return i;
 }
 
-struct BoxWin {
-  int ys, ye, xs, xe;  // normalised slice of the box window
-};
-
-__device__ __forceinline__ float depth_at(const float* disp, int W, int y, int x, float bf, int is_depth) {
-  const float v = disp[(size_t)y * W + x];
+__device__ __forceinline__ float to_depth(float v, float bf, int is_depth) {
   return is_depth ? v : bf / (v + 1e-6f);
 }
 
 __device__ __forceinline__ bool depth_valid(float d) { return d < 150.0f && d > 0.0f; }
 
-// value (bit pattern) at 0-based `rank` among the valid depths of the window; all threads call it
-__device__ unsigned select_rank(const float* disp, int W, const BoxWin& w, float bf, int is_depth, int rank,
-                                unsigned* hist /*[256]*/, unsigned* sh /*[2]*/) {
-  const int cols = w.xe - w.xs, total = (w.ye - w.ys) * cols;
-  unsigned prefix = 0, prefix_mask = 0;
-  int r = rank;
+struct Window {
+  const float* disp;   // image base
+  const float* cache;  // LDS copy of the window's depths (window order) or nullptr
+  int W, ys, xs, ye, xe, cols, total;
+  float bf;
+  int is_depth;
+  __device__ __forceinline__ float get(int e) const {
+    if (cache) return cache[e];
+    return to_depth(disp[(size_t)(ys + e / cols) * W + xs + e % cols], bf, is_depth);
+  }
+  // visit every depth of the window once: LDS cache (linear) or, for large windows, one wave per row
+  // with lanes along x (coalesced, no index division)
+  template <class F>
+  __device__ __forceinline__ void for_each(F f) const {
+    if (cache) {
+      for (int e = threadIdx.x; e < total; e += blockDim.x) f(cache[e]);
+    } else {
+      const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = blockDim.x >> 6;
+      for (int y = ys + wave; y < ye; y += nw) {
+        const float* row = disp + (size_t)y * W;
+        for (int x = xs + lane; x < xe; x += 64) f(to_depth(row[x], bf, is_depth));
+      }
+    }
+  }
+};
+
+// values (bit patterns) at NR 0-based ranks among the valid depths, selected together (NR histograms per
+// pass, 4 passes of 8 bits); all threads call it
+constexpr int BD_NR = 7;
+__device__ void select_ranks(const Window& w, const int* ranks, unsigned (*hist)[256], unsigned* sh, unsigned* out) {
+  unsigned prefix[BD_NR], mask = 0;
+  int r[BD_NR];
+#pragma unroll
+  for (int q = 0; q < BD_NR; ++q) { prefix[q] = 0; r[q] = ranks[q]; }
   for (int shift = 24; shift >= 0; shift -= 8) {
-    for (int b = threadIdx.x; b < 256; b += blockDim.x) hist[b] = 0;
+    for (int b = threadIdx.x; b < BD_NR * 256; b += blockDim.x) hist[b >> 8][b & 255] = 0;
     __syncthreads();
-    for (int e = threadIdx.x; e < total; e += blockDim.x) {
-      const int yy = w.ys + e / cols, xx = w.xs + e % cols;
-      const float d = depth_at(disp, W, yy, xx, bf, is_depth);
+    w.for_each([&](float d) {
       if (depth_valid(d)) {
-        const unsigned u = __float_as_uint(d);
-        if ((u & prefix_mask) == prefix) atomicAdd(&hist[(u >> shift) & 255u], 1u);
+        const unsigned u = __float_as_uint(d), um = u & mask, bin = (u >> shift) & 255u;
+#pragma unroll
+        for (int q = 0; q < BD_NR; ++q) {
+          // ranks that still share a prefix share a histogram: count once, in the first of them
+          bool first = true;
+#pragma unroll
+          for (int q2 = 0; q2 < q; ++q2) first = first && (prefix[q2] != prefix[q]);
+          if (first && um == prefix[q]) atomicAdd(&hist[q][bin], 1u);
+        }
+      }
+    });
+    __syncthreads();
+    // one wave per rank: 64-lane prefix sum over the 256 bins (4 bins per lane), the lane whose bins
+    // straddle the rank reports (bin, count below it)
+    const int wv = threadIdx.x >> 6, ln = threadIdx.x & 63;
+    if (wv < BD_NR) {
+      int rq = 0;
+      unsigned pq = 0;
+#pragma unroll
+      for (int q = 0; q < BD_NR; ++q)
+        if (q == wv) { rq = r[q]; pq = prefix[q]; }
+      int src = wv;  // the histogram this rank's prefix was counted in
+#pragma unroll
+      for (int q2 = BD_NR - 1; q2 >= 0; --q2)
+        if (q2 < wv && prefix[q2] == pq) src = q2;
+      unsigned h[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) h[j] = hist[src][4 * ln + j];
+      const unsigned tot = h[0] + h[1] + h[2] + h[3];
+      unsigned incl = tot;
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) {
+        const unsigned t = __shfl_up(incl, off);
+        if (ln >= off) incl += t;
+      }
+      unsigned cum = incl - tot;
+      if (cum <= (unsigned)rq && (unsigned)rq < incl) {
+        int b = 4 * ln;
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+          if (cum + h[j] <= (unsigned)rq && b == 4 * ln + j) { cum += h[j]; ++b; }
+        sh[2 * wv] = b;
+        sh[2 * wv + 1] = cum;
       }
     }
     __syncthreads();
-    if (threadIdx.x == 0) {
-      unsigned cum = 0, b = 0;
-      for (; b < 256; ++b) {
-        if (cum + hist[b] > (unsigned)r) break;
-        cum += hist[b];
-      }
-      sh[0] = b;
-      sh[1] = cum;
+#pragma unroll
+    for (int q = 0; q < BD_NR; ++q) {
+      prefix[q] |= sh[2 * q] << shift;
+      r[q] -= (int)sh[2 * q + 1];
     }
-    __syncthreads();
-    prefix |= sh[0] << shift;
-    prefix_mask |= 255u << shift;
-    r -= (int)sh[1];
+    mask |= 255u << shift;
     __syncthreads();
   }
-  return prefix;
+#pragma unroll
+  for (int q = 0; q < BD_NR; ++q) out[q] = prefix[q];
 }
 
 __device__ float corner_mean(const float* disp, int H, int W, int r0, int r1, int c0, int c1, float bf,
@@ -94,55 +154,92 @@ __device__ float corner_mean(const float* disp, int H, int W, int r0, int r1, in
   int cnt = 0;
   for (int y = r0; y < r1; ++y)
     for (int x = c0; x < c1; ++x) {
-      s += depth_at(disp, W, y, x, bf, is_depth);
+      s += to_depth(disp[(size_t)y * W + x], bf, is_depth);
       ++cnt;
     }
   if (cnt == 0) return __builtin_nanf("");
   return s / (float)cnt;
 }
 
-__global__ __launch_bounds__(256) void box_depth_kernel(const float* __restrict__ disp_all, size_t img_pitch, int H,
+__global__ __launch_bounds__(512) void box_depth_kernel(const float* __restrict__ disp_all, size_t img_pitch, int H,
                                                         int W, const float* __restrict__ boxes,
                                                         const int* __restrict__ counts, int max_det, float bf,
                                                         int is_depth, float* __restrict__ out_depth,
                                                         float* __restrict__ out_scale,
                                                         float* __restrict__ out_sboxes) {
-  __shared__ unsigned hist[256];
-  __shared__ unsigned sh[2];
+  __shared__ float cache[BD_CACHE];
+  __shared__ unsigned hist[BD_NR][256];
+  __shared__ unsigned sh[2 * BD_NR];
   __shared__ int s_len;
-  __shared__ double s_red[256];
-  __shared__ int s_cnt[4][256];
+  __shared__ double s_red[512];
+  __shared__ int s_cnt[4][512];
   const int n = blockIdx.y, k = blockIdx.x;
   const int cnt_n = min(counts[n], max_det);
   if (k >= cnt_n) return;  // block-uniform
   const float* disp = disp_all + (size_t)n * img_pitch;
   const f32x4 bx = *reinterpret_cast<const f32x4*>(boxes + ((size_t)n * max_det + k) * 4);
   const int x1 = (int)bx[0], y1 = (int)bx[1], x2 = (int)bx[2], y2 = (int)bx[3];
-  BoxWin w;
-  w.ys = py_slice_index(y1, H); w.ye = py_slice_index(y2, H);
-  w.xs = py_slice_index(x1, W); w.xe = py_slice_index(x2, W);
-  if (w.ye < w.ys) w.ye = w.ys;
-  if (w.xe < w.xs) w.xe = w.xs;
-  const int cols = w.xe - w.xs, total = (w.ye - w.ys) * cols;
+  Window w;
+  w.disp = disp; w.W = W; w.bf = bf; w.is_depth = is_depth;
+  w.ys = py_slice_index(y1, H);
+  w.xs = py_slice_index(x1, W);
+  w.ye = max(py_slice_index(y2, H), w.ys);
+  w.xe = max(py_slice_index(x2, W), w.xs);
+  w.cols = w.xe - w.xs;
+  w.total = (w.ye - w.ys) * w.cols;
+  const bool use_cache = w.total <= BD_CACHE;
+  w.cache = nullptr;
 
-  // ---- pass 0: number of valid depths
+  // ---- pass 0: number of valid depths (and fill the LDS window cache)
   if (threadIdx.x == 0) s_len = 0;
   __syncthreads();
   int local = 0;
-  for (int e = threadIdx.x; e < total; e += blockDim.x) {
-    const float d = depth_at(disp, W, w.ys + e / cols, w.xs + e % cols, bf, is_depth);
-    local += depth_valid(d);
+  if (use_cache) {
+    for (int e = threadIdx.x; e < w.total; e += blockDim.x) {
+      const float d = w.get(e);
+      cache[e] = d;
+      local += depth_valid(d);
+    }
+  } else {
+    w.for_each([&](float d) { local += depth_valid(d); });
   }
   if (local) atomicAdd(&s_len, local);
   __syncthreads();
+  if (use_cache) w.cache = cache;
   const int len = s_len;
   float dval, scale;
   if (len < 1 || (x2 - x1) > 800) {
     dval = -1.0f;
     scale = 1.0f;
   } else {
-    const unsigned mid_bits = select_rank(disp, W, w, bf, is_depth, len / 2, hist, sh);
-    const float d_mid = __uint_as_float(mid_bits);
+    // the segment [a, b) depends on the median only through cnt in {0..4}, i.e. through 3 possible
+    // fractions (0.4, 0.25, 0): select the median and all 6 candidate bounds in the same 4 passes
+    int cand_a[3], cand_b[3];
+    const double fr[3] = {0.4, 0.25, 0.0};
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const double w_start = fr[c] * (double)len;
+      const double w_end = w_start + 0.6 * (double)len;
+      int a = (int)w_start, b = (int)w_end;
+      if (b > len) b = len;
+      if (a > len) a = len;
+      if (b - a <= 0) {  // d_seg empty -> d_sorted[:-1]
+        a = 0;
+        b = len - 1;
+      }
+      cand_a[c] = a;
+      cand_b[c] = b;
+    }
+    int ranks[BD_NR];
+    unsigned bits[BD_NR];
+    ranks[0] = len / 2;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      ranks[1 + 2 * c] = min(cand_a[c], len - 1);
+      ranks[2 + 2 * c] = max(min(cand_b[c] - 1, len - 1), 0);
+    }
+    select_ranks(w, ranks, hist, sh, bits);
+    const float d_mid = __uint_as_float(bits[0]);
     int cnt = 0;
     {
       const float v_tl = corner_mean(disp, H, W, y1, y1 + 2, x1, x1 + 2, bf, is_depth);
@@ -151,37 +248,28 @@ __global__ __launch_bounds__(256) void box_depth_kernel(const float* __restrict_
       const float v_br = corner_mean(disp, H, W, y2 - 2, y2, x2 - 2, x2, bf, is_depth);
       cnt = (v_tl > d_mid) + (v_tr > d_mid) + (v_bl > d_mid) + (v_br > d_mid);
     }
-    const double frac = 1.0 - (double)cnt / 4.0;
-    const double w_start = (frac < 0.4 ? frac : 0.4) * (double)len;
-    const double w_end = w_start + 0.6 * (double)len;
-    int a = (int)w_start, b = (int)w_end;
-    if (b > len) b = len;
-    if (a > len) a = len;
-    if (b - a <= 0) {  // d_seg empty -> d_sorted[:-1]
-      a = 0;
-      b = len - 1;
-    }
+    // frac = min(1 - cnt/4, 0.4): cnt <= 2 -> 0.4, cnt == 3 -> 0.25, cnt == 4 -> 0
+    const int csel = cnt <= 2 ? 0 : (cnt == 3 ? 1 : 2);
+    const int a = cand_a[csel], b = cand_b[csel];
     if (b - a <= 0) {
       dval = __builtin_nanf("");
     } else {
-      const unsigned va_bits = select_rank(disp, W, w, bf, is_depth, a, hist, sh);
-      const unsigned vb_bits = select_rank(disp, W, w, bf, is_depth, b - 1, hist, sh);
+      const unsigned va_bits = bits[1 + 2 * csel], vb_bits = bits[2 + 2 * csel];
       const float va = __uint_as_float(va_bits), vb = __uint_as_float(vb_bits);
       double sum = 0.0;
       int lt_a = 0, eq_a = 0, lt_b = 0, eq_b = 0;
-      for (int e = threadIdx.x; e < total; e += blockDim.x) {
-        const float d = depth_at(disp, W, w.ys + e / cols, w.xs + e % cols, bf, is_depth);
+      w.for_each([&](float d) {
         if (depth_valid(d)) {
           lt_a += d < va; eq_a += d == va;
           lt_b += d < vb; eq_b += d == vb;
           if (d > va && d < vb) sum += (double)d;
         }
-      }
+      });
       s_red[threadIdx.x] = sum;
       s_cnt[0][threadIdx.x] = lt_a; s_cnt[1][threadIdx.x] = eq_a;
       s_cnt[2][threadIdx.x] = lt_b; s_cnt[3][threadIdx.x] = eq_b;
       __syncthreads();
-      for (int s = 128; s > 0; s >>= 1) {
+      for (int s = 256; s > 0; s >>= 1) {
         if ((int)threadIdx.x < s) {
           s_red[threadIdx.x] += s_red[threadIdx.x + s];
 #pragma unroll
@@ -232,7 +320,7 @@ extern "C" int st_box_depth(const float* disp_dev, size_t img_pitch, int N, int 
   // ocsort_disparity.py:120-122); bf = baseline * focal as a Python float product rounded to fp32
   const int is_depth = baseline < 0.f;
   const float bf = (float)((double)baseline * (double)focal);
-  hipLaunchKernelGGL(box_depth_kernel, dim3(max_det, N), dim3(256), 0, static_cast<hipStream_t>(stream_), disp_dev,
+  hipLaunchKernelGGL(box_depth_kernel, dim3(max_det, N), dim3(512), 0, static_cast<hipStream_t>(stream_), disp_dev,
                      img_pitch, H, W, boxes_dev, counts_dev, max_det, bf, is_depth, out_depth_dev, out_scale_dev,
                      out_scaled_boxes_dev);
   ST_CHECK_HIP(hipGetLastError());

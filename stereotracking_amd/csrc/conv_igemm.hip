@@ -28,6 +28,7 @@ namespace st {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 struct ConvKArgs {
   const float* in;
@@ -39,8 +40,9 @@ struct ConvKArgs {
   const float* res;
   int Hi, Wi, Cin, in_ld, in_off;
   int Ho, Wo, HoWo, Cout;
-  int KW, stride, pad;
+  int KH, KW, stride, pad;
   int K, Kpad, M;
+  unsigned in_bytes, wgt_bytes;  // buffer-descriptor extents (range-checked loads)
   int out1_ld, out1_off, split;
   int out2_ld, out2_off;
   int up_ld, up_off;
@@ -54,12 +56,20 @@ constexpr int BK = 32;
 constexpr int LDK = 36;  // padded LDS row (floats)
 
 __device__ __forceinline__ float silu_f32(float v) {
-  // v * sigmoid(v); __expf = v_exp_f32(x*log2e), 1 ulp-class; v/(1+inf) -> -0 for v << 0
-  return v / (1.0f + __expf(-v));
+  // v * sigmoid(v) with v_exp_f32 / v_rcp_f32 (1 ulp each): v * rcp(1 + exp(-v)); exp(-v) = inf for
+  // v << 0 gives v * 0 = -0
+  return v * __builtin_amdgcn_rcpf(1.0f + __expf(-v));
 }
 
-template <int TM, int TN, int WM, int WN>
+// NBUF = 2: LDS double buffer, one barrier per K-chunk (multi-wave blocks).
+// NBUF = 1: single-wave blocks (WM = WN = 1) only - the wave's own in-order LDS queue orders the
+//           write of chunk k+1 behind the reads of chunk k, so there is no cross-wave barrier at all and
+//           half the LDS (2 such waves per SIMD fit in 160 KiB).
+// ABL != 0: timing-only ablation builds (wrong results): 1 = no global loads / LDS stores after the first
+// chunk, 2 = additionally no barrier.
+template <int TM, int TN, int WM, int WN, int NBUF, int ABL = 0, int ILV = 1>
 __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(ConvKArgs p) {
+  static_assert(NBUF == 2 || (WM == 1 && WN == 1), "single LDS buffer needs a single-wave block");
   constexpr int NT = 64 * WM * WN;
   constexpr int BM = 32 * TM * WM;
   constexpr int BN = 32 * TN * WN;
@@ -69,8 +79,8 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(ConvKArgs p) {
   static_assert(BM % ROWS == 0 && BN % ROWS == 0, "tile/thread mismatch");
 
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* As = smem;                 // [2][BM][LDK]
-  float* Bs = smem + 2 * BM * LDK;  // [2][BN][LDK]
+  float* As = smem;                    // [NBUF][BM][LDK]
+  float* Bs = smem + NBUF * BM * LDK;  // [NBUF][BN][LDK]
 
   // XCD-aware tile order: blocks b and b+8 share an XCD (and its L2); give each XCD a
   // contiguous run of tiles so Cout-tiles of one pixel tile and neighbouring pixel
@@ -87,9 +97,18 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(ConvKArgs p) {
   const int wm = wave / WN, wn = wave - wm * WN;
   const int l31 = lane & 31, lh = lane >> 5;
 
-  // ---- staging geometry: thread owns 4-float group kq of rows r0 + ROWS*pass
+  // ---- staging geometry: thread owns 4-float group kq of rows r0 + ROWS*pass.
+  // Loads are raw buffer loads: the hardware range check returns 0 for an out-of-range offset, so the
+  // im2col zero fill (padding, ragged M, K tail) costs one v_cndmask instead of an exec-masked branch.
+  // Per row: the byte offset of its window's (0,0) tap (may be "negative" at the border: only added to
+  // in-range taps) and a bit mask of the KH*KW taps that fall inside the image.
   const int kq = tid & 7, r0 = tid >> 3;
-  int iy0[AP], ix0[AP], pix0[AP];
+  const __amdgpu_buffer_rsrc_t rsrcA =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in), 0, p.in_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrcB =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.wgt), 0, p.wgt_bytes, 0x00020000);
+  int rowoff[AP];
+  unsigned vmask[AP];
 #pragma unroll
   for (int a = 0; a < AP; ++a) {
     const int m = m0 + r0 + a * ROWS;
@@ -99,56 +118,69 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(ConvKArgs p) {
     const int rem = mm - n * p.HoWo;
     const int oy = rem / p.Wo;
     const int ox = rem - oy * p.Wo;
-    iy0[a] = vm ? oy * p.stride - p.pad : -(1 << 20);
-    ix0[a] = ox * p.stride - p.pad;
-    pix0[a] = n * p.Hi * p.Wi;
+    const int iy0 = oy * p.stride - p.pad, ix0 = ox * p.stride - p.pad;
+    rowoff[a] = (((n * p.Hi + iy0) * p.Wi + ix0) * p.in_ld + p.in_off) * 4;
+    unsigned msk = 0;
+    for (int kh = 0; kh < p.KH; ++kh)
+      for (int kw = 0; kw < p.KW; ++kw)
+        if (vm && (unsigned)(iy0 + kh) < (unsigned)p.Hi && (unsigned)(ix0 + kw) < (unsigned)p.Wi)
+          msk |= 1u << (kh * p.KW + kw);
+    vmask[a] = msk;
   }
-  const float* wrow[BP];
+  unsigned woff[BP];
 #pragma unroll
-  for (int b = 0; b < BP; ++b) wrow[b] = p.wgt + (size_t)(n0 + r0 + b * ROWS) * p.Kpad + kq * 4;
+  for (int b = 0; b < BP; ++b) woff[b] = ((unsigned)(n0 + r0 + b * ROWS) * (unsigned)p.Kpad + kq * 4) * 4u;
 
-  // running (kh, kw, c) of this lane's 4-float group; advanced by 32 per chunk
+  // running (tap, c) of this lane's 4-float group and the tap's byte offset; advanced by 32 per chunk
   int kc_c = kq * 4, kc_kh = 0, kc_kw = 0, kc_k = kq * 4;
   while (kc_c >= p.Cin) {
     kc_c -= p.Cin;
     if (++kc_kw == p.KW) { kc_kw = 0; ++kc_kh; }
   }
+  int kc_tap = kc_kh * p.KW + kc_kw;
+  int kc_off = ((kc_kh * p.Wi + kc_kw) * p.in_ld + kc_c) * 4;
 
   f32x4 areg[AP], breg[BP];
-  auto load_chunk = [&](int kc) {
-    const bool vk = kc_k < p.K;
-#pragma unroll
-    for (int a = 0; a < AP; ++a) {
-      const int iy = iy0[a] + kc_kh, ix = ix0[a] + kc_kw;
-      const bool v = vk && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
-      f32x4 val = {0.f, 0.f, 0.f, 0.f};
-      if (v) {
-        const float* src =
-            p.in + (size_t)(pix0[a] + iy * p.Wi + ix) * p.in_ld + p.in_off + kc_c;
-        val = *reinterpret_cast<const f32x4*>(src);
-      }
-      areg[a] = val;
-    }
-#pragma unroll
-    for (int b = 0; b < BP; ++b)
-      breg[b] = *reinterpret_cast<const f32x4*>(wrow[b] + (size_t)kc * BK);
-    // advance to the next chunk
+  // one 16-B staging item of this thread: A row `a` (im2col gather, zero fill) / W row `b`
+  auto load_a = [&](int a, bool vk) {
+    const bool v = vk && ((vmask[a] >> kc_tap) & 1u);
+    const unsigned off = v ? (unsigned)(rowoff[a] + kc_off) : 0x80000000u;
+    areg[a] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrcA, off, 0, 0));
+  };
+  auto load_b = [&](int b, int kc) {
+    breg[b] = __builtin_bit_cast(
+        f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrcB, woff[b], (ABL == 6 ? 0 : kc) * (BK * 4), 0));
+  };
+  auto advance = [&]() {  // move this lane's (kh, kw, c) to the next K-chunk
+    if (ABL == 6) return;
     kc_k += BK;
     kc_c += BK;
     while (kc_c >= p.Cin) {
       kc_c -= p.Cin;
       if (++kc_kw == p.KW) { kc_kw = 0; ++kc_kh; }
     }
+    kc_tap = kc_kh * p.KW + kc_kw;
+    kc_off = ((kc_kh * p.Wi + kc_kw) * p.in_ld + kc_c) * 4;
+  };
+  auto store_a = [&](int a, int buf) {
+    *reinterpret_cast<f32x4*>(As + buf * BM * LDK + (r0 + a * ROWS) * LDK + kq * 4) = areg[a];
+  };
+  auto store_b = [&](int b, int buf) {
+    *reinterpret_cast<f32x4*>(Bs + buf * BN * LDK + (r0 + b * ROWS) * LDK + kq * 4) = breg[b];
+  };
+  auto load_chunk = [&](int kc) {
+    const bool vk = kc_k < p.K;
+#pragma unroll
+    for (int a = 0; a < AP; ++a) load_a(a, vk);
+#pragma unroll
+    for (int b = 0; b < BP; ++b) load_b(b, kc);
+    advance();
   };
   auto store_chunk = [&](int buf) {
-    float* Ab = As + buf * BM * LDK;
-    float* Bb = Bs + buf * BN * LDK;
 #pragma unroll
-    for (int a = 0; a < AP; ++a)
-      *reinterpret_cast<f32x4*>(Ab + (r0 + a * ROWS) * LDK + kq * 4) = areg[a];
+    for (int a = 0; a < AP; ++a) store_a(a, buf);
 #pragma unroll
-    for (int b = 0; b < BP; ++b)
-      *reinterpret_cast<f32x4*>(Bb + (r0 + b * ROWS) * LDK + kq * 4) = breg[b];
+    for (int b = 0; b < BP; ++b) store_b(b, buf);
   };
 
   f32x16 acc[TM][TN];
@@ -164,9 +196,18 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(ConvKArgs p) {
   store_chunk(0);
   __syncthreads();
 
+  // Main loop.  A K-chunk is 16 MFMA "slots" (4 fragment groups x 4 k-steps) per accumulator tile.  The
+  // staging of chunk k+1 is threaded through the MFMA stream of chunk k, one 16-B item per slot: global
+  // loads in the first 8 slots, LDS stores (into the other buffer) in the last 8.  Issued between MFMAs
+  // they ride in the shadow of the 64-cycle matrix instructions instead of forming a load burst at the
+  // top and a vmcnt-wait + ds_write burst at the bottom of every chunk.
+  constexpr int NI = AP + BP;
   for (int kc = 0; kc < nchunks; ++kc) {
-    const int buf = kc & 1;
-    if (kc + 1 < nchunks) load_chunk(kc + 1);  // global loads in flight under the MFMAs
+    const int buf = NBUF == 2 ? (kc & 1) : 0;
+    const int nbuf = NBUF == 2 ? (buf ^ 1) : 0;
+    const bool more = (ABL == 0 || ABL >= 4) && kc + 1 < nchunks;  // ABL 6: cache-hot re-loads
+    const bool vk = kc_k < p.K;  // the lane state already describes chunk kc + 1
+    if (!ILV && more && ABL != 5) load_chunk(kc + 1);
 
     const float* Ab = As + buf * BM * LDK + (wm * 32 * TM + l31) * LDK + 4 * lh;
     const float* Bb = Bs + buf * BN * LDK + (wn * 32 * TN + l31) * LDK + 4 * lh;
@@ -180,19 +221,77 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(ConvKArgs p) {
       for (int j = 0; j < TN; ++j)
         b[j] = *reinterpret_cast<const f32x4*>(Bb + j * 32 * LDK + g * 8);
 #pragma unroll
-      for (int s = 0; s < 4; ++s)
+      for (int s = 0; s < 4; ++s) {
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
           for (int j = 0; j < TN; ++j)
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][s], b[j][s], acc[i][j], 0, 0, 0);
+        if (ILV && NBUF == 2) {
+          const int slot = g * 4 + s;
+          if (more) {
+#pragma unroll
+            for (int it = 0; it < NI; ++it) {
+              if ((it * 8) / NI == slot) {
+                if (it < AP) load_a(it, vk); else load_b(it - AP, kc + 1);
+              }
+              if (8 + (it * 8) / NI == slot) {
+                if (it < AP) store_a(it, nbuf); else store_b(it - AP, nbuf);
+              }
+            }
+            if (slot == 7) advance();
+          }
+        }
+      }
     }
 
-    if (kc + 1 < nchunks) store_chunk(buf ^ 1);
-    __syncthreads();
+    if ((!ILV || NBUF != 2) && more) {
+      if (ILV) load_chunk(kc + 1);  // single-buffer blocks: stage after the reads of this chunk
+      if (ABL != 4) {
+        store_chunk(nbuf);
+      } else {
+#pragma unroll
+        for (int a = 0; a < AP; ++a) asm volatile("" ::"v"(areg[a]));
+#pragma unroll
+        for (int b = 0; b < BP; ++b) asm volatile("" ::"v"(breg[b]));
+      }
+    }
+    if (ABL < 2) __syncthreads();
   }
 
   // ---- epilogue: lane holds column j = lane&31, rows (r&3) + 8*(r>>2) + 4*(lane>>5)
+  // All element offsets fit 32 bits (checked on the host), bases are wave-uniform: stores/loads use
+  // the SGPR-base + 32-bit VGPR-offset form.  The common case (tile fully inside, no split / upsample)
+  // runs without per-element predicates.
+  const bool full_tile = (m0 + BM <= p.M) && (n0 + BN <= p.Cout);
+  const bool simple = full_tile && !p.up && !p.out2;
+  if (simple) {
+    float* __restrict__ o1 = p.out1 + p.out1_off;
+    const float* __restrict__ rs = p.res ? p.res + p.res_off : nullptr;
+#pragma unroll
+    for (int tj = 0; tj < TN; ++tj) {
+      const unsigned j = n0 + wn * 32 * TN + tj * 32 + l31;
+      const float bj = p.bias[j];
+#pragma unroll
+      for (int ti = 0; ti < TM; ++ti) {
+        const unsigned mb = m0 + wm * 32 * TM + ti * 32 + 4 * lh;
+        float rv[16];
+        if (rs) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            rv[r] = rs[(mb + (r & 3) + 8 * (r >> 2)) * (unsigned)p.res_ld + j];
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          float v = acc[ti][tj][r] + bj;
+          if (p.act) v = silu_f32(v);
+          if (rs) v = (v + rv[r]) * p.post_scale;
+          o1[(mb + (r & 3) + 8 * (r >> 2)) * (unsigned)p.out1_ld + j] = v;
+        }
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int tj = 0; tj < TN; ++tj) {
     const int j = n0 + wn * 32 * TN + tj * 32 + l31;
@@ -207,7 +306,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(ConvKArgs p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int m = m0 + wm * 32 * TM + ti * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-          rv[r] = (m < p.M && vj) ? p.res[(size_t)m * p.res_ld + p.res_off + j] : 0.f;
+          rv[r] = (m < p.M && vj) ? p.res[(unsigned)m * (unsigned)p.res_ld + p.res_off + j] : 0.f;
         }
       }
 #pragma unroll
@@ -218,21 +317,21 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(ConvKArgs p) {
           if (p.act) v = silu_f32(v);
           if (p.res) v = (v + rv[r]) * p.post_scale;
           if (j < p.split)
-            p.out1[(size_t)m * p.out1_ld + p.out1_off + j] = v;
+            p.out1[(unsigned)m * (unsigned)p.out1_ld + p.out1_off + j] = v;
           else
-            p.out2[(size_t)m * p.out2_ld + p.out2_off + (j - p.split)] = v;
+            p.out2[(unsigned)m * (unsigned)p.out2_ld + p.out2_off + (j - p.split)] = v;
           if (p.up) {
             const int n = m / p.HoWo;
             const int rem = m - n * p.HoWo;
             const int oy = rem / p.Wo;
             const int ox = rem - oy * p.Wo;
-            const size_t W2 = 2 * (size_t)p.Wo;
-            const size_t base = ((size_t)n * 2 * p.Ho + 2 * oy) * W2 + 2 * ox;
+            const unsigned W2 = 2u * p.Wo;
+            const unsigned base = ((unsigned)n * 2u * p.Ho + 2u * oy) * W2 + 2u * ox;
             float* u = p.up + p.up_off + j;
-            u[base * p.up_ld] = v;
-            u[(base + 1) * p.up_ld] = v;
-            u[(base + W2) * p.up_ld] = v;
-            u[(base + W2 + 1) * p.up_ld] = v;
+            u[base * (unsigned)p.up_ld] = v;
+            u[(base + 1) * (unsigned)p.up_ld] = v;
+            u[(base + W2) * (unsigned)p.up_ld] = v;
+            u[(base + W2 + 1) * (unsigned)p.up_ld] = v;
           }
         }
       }
@@ -240,12 +339,12 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(ConvKArgs p) {
   }
 }
 
-template <int TM, int TN, int WM, int WN>
+template <int TM, int TN, int WM, int WN, int NBUF = 2, int ABL = 0, int ILV = 1>
 static int launch_variant(const ConvKArgs& a, int m_tiles, hipStream_t stream) {
   constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
-  constexpr size_t lds = (size_t)2 * (BM + BN) * LDK * sizeof(float);
+  constexpr size_t lds = (size_t)NBUF * (BM + BN) * LDK * sizeof(float);
   static bool attr_set = false;
-  auto kern = conv_igemm_kernel<TM, TN, WM, WN>;
+  auto kern = conv_igemm_kernel<TM, TN, WM, WN, NBUF, ABL, ILV>;
   if (!attr_set) {
     ST_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -261,11 +360,12 @@ static int launch_variant(const ConvKArgs& a, int m_tiles, hipStream_t stream) {
 //  0 128x128 (4 waves 64x64)   1 128x64 (2 waves 64x64)   2 128x32 (2 waves 64x32)
 //  3  64x64  (4 waves 32x32)   4  64x32 (2 waves 32x32)   5 128x64 (4 waves 32x64)
 //  6 128x32  (4 waves 32x32)   7  64x128 (4 waves 32x64)  8 256x64 (4 waves 64x64)
+//  9  64x64  (1 wave, barrier-free, single LDS buffer)   10 64x32 (1 wave)   11 32x64 (1 wave)
 struct ConvVariant { int bm, bn, threads; };
 static const ConvVariant kVariants[] = {{128, 128, 256}, {128, 64, 128}, {128, 32, 128}, {64, 64, 256},
                                         {64, 32, 128},   {128, 64, 256}, {128, 32, 256}, {64, 128, 256},
-                                        {256, 64, 256}};
-constexpr int kNumVariants = 9;
+                                        {256, 64, 256},  {64, 64, 64},   {64, 32, 64},   {32, 64, 64}};
+constexpr int kNumVariants = 12;
 
 int conv_variant_count() { return kNumVariants; }
 bool conv_variant_valid(int id, int cout) {
@@ -273,7 +373,7 @@ bool conv_variant_valid(int id, int cout) {
 }
 const char* conv_variant_name(int id) {
   static const char* names[] = {"128x128", "128x64w2", "128x32w2", "64x64", "64x32w2",
-                                "128x64", "128x32", "64x128", "256x64"};
+                                "128x64", "128x32", "64x128", "256x64", "64x64w1", "64x32w1", "32x64w1"};
   return id >= 0 && id < kNumVariants ? names[id] : "-";
 }
 
@@ -297,8 +397,12 @@ int conv2d_launch(const StConvDesc& d, hipStream_t stream, int force_variant, in
   if (d.up_dev) ST_REQUIRE(d.up_off + d.Cout <= d.up_ld, "conv: up slice exceeds up_ld");
   if (d.res_dev) ST_REQUIRE(d.res_off + d.Cout <= d.res_ld, "conv: res slice exceeds res_ld");
   const long long M_ll = (long long)d.N * Ho * Wo;
-  ST_REQUIRE(M_ll * (long long)std::max(std::max(d.out1_ld, d.out2_ld), d.in_ld) < (1ll << 40),
-             "conv: tensor too large");
+  // the kernel addresses every tensor with 32-bit element offsets
+  ST_REQUIRE(M_ll * (long long)std::max(std::max(d.out1_ld, d.out2_ld), d.res_dev ? d.res_ld : 1) < (1ll << 31) &&
+                 (long long)d.N * d.Hi * d.Wi * d.in_ld < (1ll << 29) &&   // bytes < 2^31: offset bit 31 = "invalid"
+                 d.KH * d.KW <= 32 &&
+                 (!d.up_dev || 4 * M_ll * d.up_ld < (1ll << 31)),
+             "conv: tensor exceeds 2^31 elements");
   ST_REQUIRE((long long)d.N * d.Hi * d.Wi < (1ll << 31) && M_ll < (1ll << 31),
              "conv: pixel count exceeds int32");
 
@@ -307,8 +411,10 @@ int conv2d_launch(const StConvDesc& d, hipStream_t stream, int force_variant, in
   a.out1 = d.out1_dev; a.out2 = d.out2_dev; a.up = d.up_dev; a.res = d.res_dev;
   a.Hi = d.Hi; a.Wi = d.Wi; a.Cin = d.Cin; a.in_ld = d.in_ld; a.in_off = d.in_off;
   a.Ho = Ho; a.Wo = Wo; a.HoWo = Ho * Wo; a.Cout = d.Cout;
-  a.KW = d.KW; a.stride = d.stride; a.pad = d.pad;
+  a.KH = d.KH; a.KW = d.KW; a.stride = d.stride; a.pad = d.pad;
   a.K = d.KH * d.KW * d.Cin; a.Kpad = round_up(a.K, BK); a.M = (int)M_ll;
+  a.in_bytes = (unsigned)((long long)d.N * d.Hi * d.Wi * d.in_ld * 4);
+  a.wgt_bytes = (unsigned)((long long)round_up(d.Cout, 32) * a.Kpad * 4);
   a.out1_ld = d.out1_ld; a.out1_off = d.out1_off; a.split = split;
   a.out2_ld = d.out2_ld; a.out2_off = d.out2_off;
   a.up_ld = d.up_ld; a.up_off = d.up_off;
@@ -319,9 +425,9 @@ int conv2d_launch(const StConvDesc& d, hipStream_t stream, int force_variant, in
   const int cout_pad = round_up(d.Cout, 32);
   int pick = -1;
   if (force_variant >= 0) {
-    ST_REQUIRE(conv_variant_valid(force_variant, d.Cout), "conv: variant %d does not divide Cout=%d",
+    ST_REQUIRE(conv_variant_valid(force_variant % 100, d.Cout), "conv: variant %d does not divide Cout=%d",
                force_variant, d.Cout);
-    pick = force_variant;
+    pick = force_variant % 100;
   } else {
     // untuned default: the largest tile that still gives >= 2 blocks per CU (the detector
     // replaces this guess by a measured choice, st_detector_autotune)
@@ -338,6 +444,22 @@ int conv2d_launch(const StConvDesc& d, hipStream_t stream, int force_variant, in
   if (picked_variant) *picked_variant = pick;
   a.n_tiles = cout_pad / v.bn;
   const int m_tiles = ceil_div(a.M, v.bm);
+  if (force_variant >= 100) {  // timing-only ablations (tools/conv_ablation.py)
+    const int abl = force_variant / 100;
+    if (pick == 0 && abl == 1) return launch_variant<2, 2, 2, 2, 2, 1>(a, m_tiles, stream);
+    if (pick == 0 && abl == 2) return launch_variant<2, 2, 2, 2, 2, 2>(a, m_tiles, stream);
+    if (pick == 3 && abl == 1) return launch_variant<1, 1, 2, 2, 2, 1>(a, m_tiles, stream);
+    if (pick == 3 && abl == 2) return launch_variant<1, 1, 2, 2, 2, 2>(a, m_tiles, stream);
+    if (pick == 0 && abl == 6) return launch_variant<2, 2, 2, 2, 2, 6, 0>(a, m_tiles, stream);  // cache-hot loads
+    if (pick == 3 && abl == 6) return launch_variant<1, 1, 2, 2, 2, 6, 0>(a, m_tiles, stream);
+    if (pick == 0 && abl == 4) return launch_variant<2, 2, 2, 2, 2, 4, 0>(a, m_tiles, stream);  // loads, no ds_write
+    if (pick == 0 && abl == 5) return launch_variant<2, 2, 2, 2, 2, 5, 0>(a, m_tiles, stream);  // ds_write, no loads
+    if (pick == 3 && abl == 4) return launch_variant<1, 1, 2, 2, 2, 4, 0>(a, m_tiles, stream);
+    if (pick == 3 && abl == 5) return launch_variant<1, 1, 2, 2, 2, 5, 0>(a, m_tiles, stream);
+    if (pick == 0 && abl == 3) return launch_variant<2, 2, 2, 2, 2, 0, 0>(a, m_tiles, stream);  // burst staging
+    if (pick == 3 && abl == 3) return launch_variant<1, 1, 2, 2, 2, 0, 0>(a, m_tiles, stream);
+    return set_error(ST_ERR_INVALID, "conv: no ablation build for variant %d", force_variant);
+  }
   switch (pick) {
     case 0: return launch_variant<2, 2, 2, 2>(a, m_tiles, stream);
     case 1: return launch_variant<2, 2, 2, 1>(a, m_tiles, stream);
@@ -347,7 +469,10 @@ int conv2d_launch(const StConvDesc& d, hipStream_t stream, int force_variant, in
     case 5: return launch_variant<1, 2, 4, 1>(a, m_tiles, stream);
     case 6: return launch_variant<1, 1, 4, 1>(a, m_tiles, stream);
     case 7: return launch_variant<1, 2, 2, 2>(a, m_tiles, stream);
-    default: return launch_variant<2, 2, 4, 1>(a, m_tiles, stream);
+    case 8: return launch_variant<2, 2, 4, 1>(a, m_tiles, stream);
+    case 9: return launch_variant<2, 2, 1, 1, 1>(a, m_tiles, stream);
+    case 10: return launch_variant<2, 1, 1, 1, 1>(a, m_tiles, stream);
+    default: return launch_variant<1, 2, 1, 1, 1>(a, m_tiles, stream);
   }
 }
 

@@ -22,7 +22,7 @@ _SILU_VAR = 0.313
 
 
 def synthetic_state_dict(param_table, seed=0, img_stats=(127.5, 73.9), disp_stats=(24.0, 20.0),
-                         prior_prob=0.01, logit_std=1.0):
+                         prior_prob=0.01, logit_std=0.6):
     """param_table: iterable of (name, shape) in reference state_dict naming.
     Returns an OrderedDict name -> float32 tensor (BN `num_batches_tracked` not included)."""
     import zlib

@@ -116,7 +116,8 @@ def test_conv_matches_torch(case, cuda):
 
 
 @pytest.mark.parametrize('variant,cout', [(0, 128), (1, 64), (2, 32), (3, 64), (4, 32), (0, 256), (3, 128), (5, 64),
-                                          (6, 32), (7, 128), (8, 64), (5, 192), (6, 96)])
+                                          (6, 32), (7, 128), (8, 64), (5, 192), (6, 96), (9, 64), (10, 32), (11, 64),
+                                          (9, 128), (10, 96)])
 def test_conv_all_tile_variants(variant, cout, cuda):
     torch.manual_seed(variant)
     x = torch.randn(2, 64, 13, 21)
