@@ -79,7 +79,7 @@ def conv_roofline(pipe, img, right, steps):
         other['decode_nms'] += ev[2].elapsed_time(ev[3])
         other['box_depth'] += ev[3].elapsed_time(ev[4])
     check(lib.st_detector_set_timing(det.handle, 0))
-    VARIANT_TILES = {v: lib.st_conv_variant_name(v).decode() for v in range(16)}
+    VARIANT_TILES = {v: lib.st_conv_variant_name(v).decode() for v in range(64)}
     per_variant = {}
     for v in sorted(set(var[kind == 1].tolist())):
         sel = (kind == 1) & (var == v)

@@ -67,9 +67,27 @@ struct Window {
       for (int e = threadIdx.x; e < total; e += blockDim.x) f(cache[e]);
     } else {
       const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = blockDim.x >> 6;
-      for (int y = ys + wave; y < ye; y += nw) {
-        const float* row = disp + (size_t)y * W;
-        for (int x = xs + lane; x < xe; x += 64) f(to_depth(row[x], bf, is_depth));
+      // 2 rows x 4 column chunks = 8 independent loads in flight per lane (the loop is latency-bound)
+      for (int y = ys + 2 * wave; y < ye; y += 2 * nw) {
+        const float* row0 = disp + (size_t)y * W;
+        const bool two = y + 1 < ye;
+        const float* row1 = two ? row0 + W : row0;
+        for (int x = xs + lane; x < xe; x += 256) {
+          float v[8];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const int xx = min(x + 64 * u, xe - 1);
+            v[u] = row0[xx];
+            v[4 + u] = row1[xx];
+          }
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            if (x + 64 * u < xe) {
+              f(to_depth(v[u], bf, is_depth));
+              if (two) f(to_depth(v[4 + u], bf, is_depth));
+            }
+          }
+        }
       }
     }
   }

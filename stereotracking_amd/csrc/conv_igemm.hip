@@ -67,9 +67,17 @@ __device__ __forceinline__ float silu_f32(float v) {
 //           half the LDS (2 such waves per SIMD fit in 160 KiB).
 // ABL != 0: timing-only ablation builds (wrong results): 1 = no global loads / LDS stores after the first
 // chunk, 2 = additionally no barrier.
-template <int TM, int TN, int WM, int WN, int NBUF, int ABL = 0, int ILV = 1>
+// DMA = 1: tiles go global -> LDS directly (`buffer_load_dwordx4 ... lds`, 1 KiB per wave-instruction):
+//          no staging VGPRs, no ds_write, no address math between load and store.  The LDS image must be
+//          lane-linear (8 rows x 128 B per instruction, unpadded), so bank conflicts are removed by an XOR
+//          swizzle applied on the SOURCE side (lane (row, q) fetches k-group q ^ ((row>>1)&7)) and undone
+//          by the same XOR in the fragment reads (cdna_hip_programming.md rule 21): conflict-free for the
+//          ds_read_b128 lane groups.
+template <int TM, int TN, int WM, int WN, int NBUF, int ABL = 0, int ILV = 1, int DMA = 0>
 __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(ConvKArgs p) {
   static_assert(NBUF == 2 || (WM == 1 && WN == 1), "single LDS buffer needs a single-wave block");
+  static_assert(!DMA || (NBUF == 2 && 64 * WM * WN >= 128), "LDS-DMA variant: double buffer, >= 2 waves");
+  constexpr int LDK = DMA ? 32 : st::LDK;  // LDS row length in floats (DMA image is unpadded)
   constexpr int NT = 64 * WM * WN;
   constexpr int BM = 32 * TM * WM;
   constexpr int BN = 32 * TN * WN;
@@ -102,7 +110,10 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(ConvKArgs p) {
   // im2col zero fill (padding, ragged M, K tail) costs one v_cndmask instead of an exec-masked branch.
   // Per row: the byte offset of its window's (0,0) tap (may be "negative" at the border: only added to
   // in-range taps) and a bit mask of the KH*KW taps that fall inside the image.
-  const int kq = tid & 7, r0 = tid >> 3;
+  const int r0 = tid >> 3;
+  // DMA: lane (row, q) stages k-group q ^ ((row >> 1) & 7); (row >> 1) & 7 is the same for every pass
+  // because ROWS is a multiple of 16
+  const int kq = DMA ? ((tid & 7) ^ ((r0 >> 1) & 7)) : (tid & 7);
   const __amdgpu_buffer_rsrc_t rsrcA =
       __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in), 0, p.in_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsrcB =
@@ -168,6 +179,35 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(ConvKArgs p) {
   auto store_b = [&](int b, int buf) {
     *reinterpret_cast<f32x4*>(Bs + buf * BN * LDK + (r0 + b * ROWS) * LDK + kq * 4) = breg[b];
   };
+  // LDS-DMA items: wave-uniform LDS base (the hardware adds lane * 16 B), per-lane range-checked source
+  auto dma_a = [&](int a, bool vk, int buf) {
+    const bool v = vk && ((vmask[a] >> kc_tap) & 1u);
+    const unsigned off = v ? (unsigned)(rowoff[a] + kc_off) : 0x80000000u;
+#if defined(__HIP_DEVICE_COMPILE__)  // device-only builtin; the host pass only needs the kernel stub
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(
+        rsrcA, (__attribute__((address_space(3))) void*)(As + buf * BM * LDK + (wave * 8 + a * ROWS) * LDK), 16, off,
+        0, 0, 0);
+#else
+    (void)off; (void)buf;
+#endif
+  };
+  auto dma_b = [&](int b, int kc, int buf) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(
+        rsrcB, (__attribute__((address_space(3))) void*)(Bs + buf * BN * LDK + (wave * 8 + b * ROWS) * LDK), 16,
+        woff[b], kc * (BK * 4), 0, 0);
+#else
+    (void)b; (void)kc; (void)buf;
+#endif
+  };
+  auto dma_chunk = [&](int kc, int buf) {
+    const bool vk = kc_k < p.K;
+#pragma unroll
+    for (int a = 0; a < AP; ++a) dma_a(a, vk, buf);
+#pragma unroll
+    for (int b = 0; b < BP; ++b) dma_b(b, kc, buf);
+    advance();
+  };
   auto load_chunk = [&](int kc) {
     const bool vk = kc_k < p.K;
 #pragma unroll
@@ -192,9 +232,13 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(ConvKArgs p) {
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   const int nchunks = p.Kpad / BK;
-  load_chunk(0);
-  store_chunk(0);
-  __syncthreads();
+  if (DMA) {
+    dma_chunk(0, 0);
+  } else {
+    load_chunk(0);
+    store_chunk(0);
+  }
+  __syncthreads();  // (drains the DMA: hipcc emits vmcnt(0) in front of the barrier)
 
   // Main loop.  A K-chunk is 16 MFMA "slots" (4 fragment groups x 4 k-steps) per accumulator tile.  The
   // staging of chunk k+1 is threaded through the MFMA stream of chunk k, one 16-B item per slot: global
@@ -207,19 +251,22 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(ConvKArgs p) {
     const int nbuf = NBUF == 2 ? (buf ^ 1) : 0;
     const bool more = (ABL == 0 || ABL >= 4) && kc + 1 < nchunks;  // ABL 6: cache-hot re-loads
     const bool vk = kc_k < p.K;  // the lane state already describes chunk kc + 1
-    if (!ILV && more && ABL != 5) load_chunk(kc + 1);
+    if (!DMA && !ILV && more && ABL != 5) load_chunk(kc + 1);
+    if (DMA && !ILV && more) dma_chunk(kc + 1, nbuf);
 
-    const float* Ab = As + buf * BM * LDK + (wm * 32 * TM + l31) * LDK + 4 * lh;
-    const float* Bb = Bs + buf * BN * LDK + (wn * 32 * TN + l31) * LDK + 4 * lh;
+    const float* Ab = As + buf * BM * LDK + (wm * 32 * TM + l31) * LDK + (DMA ? 0 : 4 * lh);
+    const float* Bb = Bs + buf * BN * LDK + (wn * 32 * TN + l31) * LDK + (DMA ? 0 : 4 * lh);
+    const int sw = (l31 >> 1) & 7;  // DMA image: k-group g of a row lives in 16-B slot g ^ sw
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       f32x4 a[TM], b[TN];
+      const int koff = DMA ? (((2 * g + lh) ^ sw) * 4) : g * 8;
 #pragma unroll
       for (int i = 0; i < TM; ++i)
-        a[i] = *reinterpret_cast<const f32x4*>(Ab + i * 32 * LDK + g * 8);
+        a[i] = *reinterpret_cast<const f32x4*>(Ab + i * 32 * LDK + koff);
 #pragma unroll
       for (int j = 0; j < TN; ++j)
-        b[j] = *reinterpret_cast<const f32x4*>(Bb + j * 32 * LDK + g * 8);
+        b[j] = *reinterpret_cast<const f32x4*>(Bb + j * 32 * LDK + koff);
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
 #pragma unroll
@@ -227,7 +274,19 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(ConvKArgs p) {
 #pragma unroll
           for (int j = 0; j < TN; ++j)
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][s], b[j][s], acc[i][j], 0, 0, 0);
-        if (ILV && NBUF == 2) {
+        if (DMA && ILV) {
+          const int slot = g * 4 + s;
+          if (more) {  // one DMA item per slot, all issued in the first half of the chunk
+#pragma unroll
+            for (int it = 0; it < NI; ++it) {
+              if ((it * 8) / NI == slot) {
+                if (it < AP) dma_a(it, vk, nbuf); else dma_b(it - AP, kc + 1, nbuf);
+              }
+            }
+            if (slot == 7) advance();
+          }
+        }
+        if (!DMA && ILV && NBUF == 2) {
           const int slot = g * 4 + s;
           if (more) {
 #pragma unroll
@@ -245,7 +304,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(ConvKArgs p) {
       }
     }
 
-    if ((!ILV || NBUF != 2) && more) {
+    if (!DMA && (!ILV || NBUF != 2) && more) {
       if (ILV) load_chunk(kc + 1);  // single-buffer blocks: stage after the reads of this chunk
       if (ABL != 4) {
         store_chunk(nbuf);
@@ -339,12 +398,12 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(ConvKArgs p) {
   }
 }
 
-template <int TM, int TN, int WM, int WN, int NBUF = 2, int ABL = 0, int ILV = 1>
+template <int TM, int TN, int WM, int WN, int NBUF = 2, int ABL = 0, int ILV = 1, int DMA = 0>
 static int launch_variant(const ConvKArgs& a, int m_tiles, hipStream_t stream) {
   constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
-  constexpr size_t lds = (size_t)NBUF * (BM + BN) * LDK * sizeof(float);
+  constexpr size_t lds = (size_t)NBUF * (BM + BN) * (DMA ? 32 : LDK) * sizeof(float);
   static bool attr_set = false;
-  auto kern = conv_igemm_kernel<TM, TN, WM, WN, NBUF, ABL, ILV>;
+  auto kern = conv_igemm_kernel<TM, TN, WM, WN, NBUF, ABL, ILV, DMA>;
   if (!attr_set) {
     ST_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -361,11 +420,15 @@ static int launch_variant(const ConvKArgs& a, int m_tiles, hipStream_t stream) {
 //  3  64x64  (4 waves 32x32)   4  64x32 (2 waves 32x32)   5 128x64 (4 waves 32x64)
 //  6 128x32  (4 waves 32x32)   7  64x128 (4 waves 32x64)  8 256x64 (4 waves 64x64)
 //  9  64x64  (1 wave, barrier-free, single LDS buffer)   10 64x32 (1 wave)   11 32x64 (1 wave)
+// 12..16: LDS-DMA staging of 0 / 3 / 7 / 6 / 5 (DMA issue threaded through the MFMA stream);
+// 17, 18: LDS-DMA 128x128 / 64x64 with the DMA burst at the top of the chunk
 struct ConvVariant { int bm, bn, threads; };
 static const ConvVariant kVariants[] = {{128, 128, 256}, {128, 64, 128}, {128, 32, 128}, {64, 64, 256},
                                         {64, 32, 128},   {128, 64, 256}, {128, 32, 256}, {64, 128, 256},
-                                        {256, 64, 256},  {64, 64, 64},   {64, 32, 64},   {32, 64, 64}};
-constexpr int kNumVariants = 12;
+                                        {256, 64, 256},  {64, 64, 64},   {64, 32, 64},   {32, 64, 64},
+                                        {128, 128, 256}, {64, 64, 256},  {64, 128, 256}, {128, 32, 256},
+                                        {128, 64, 256},  {128, 128, 256}, {64, 64, 256}};
+constexpr int kNumVariants = 19;
 
 int conv_variant_count() { return kNumVariants; }
 bool conv_variant_valid(int id, int cout) {
@@ -373,7 +436,9 @@ bool conv_variant_valid(int id, int cout) {
 }
 const char* conv_variant_name(int id) {
   static const char* names[] = {"128x128", "128x64w2", "128x32w2", "64x64", "64x32w2",
-                                "128x64", "128x32", "64x128", "256x64", "64x64w1", "64x32w1", "32x64w1"};
+                                "128x64", "128x32", "64x128", "256x64", "64x64w1", "64x32w1", "32x64w1",
+                                "128x128dma", "64x64dma", "64x128dma", "128x32dma", "128x64dma",
+                                "128x128dmab", "64x64dmab"};
   return id >= 0 && id < kNumVariants ? names[id] : "-";
 }
 
@@ -472,7 +537,14 @@ int conv2d_launch(const StConvDesc& d, hipStream_t stream, int force_variant, in
     case 8: return launch_variant<2, 2, 4, 1>(a, m_tiles, stream);
     case 9: return launch_variant<2, 2, 1, 1, 1>(a, m_tiles, stream);
     case 10: return launch_variant<2, 1, 1, 1, 1>(a, m_tiles, stream);
-    default: return launch_variant<1, 2, 1, 1, 1>(a, m_tiles, stream);
+    case 11: return launch_variant<1, 2, 1, 1, 1>(a, m_tiles, stream);
+    case 12: return launch_variant<2, 2, 2, 2, 2, 0, 1, 1>(a, m_tiles, stream);
+    case 13: return launch_variant<1, 1, 2, 2, 2, 0, 1, 1>(a, m_tiles, stream);
+    case 14: return launch_variant<1, 2, 2, 2, 2, 0, 1, 1>(a, m_tiles, stream);
+    case 15: return launch_variant<1, 1, 4, 1, 2, 0, 1, 1>(a, m_tiles, stream);
+    case 16: return launch_variant<1, 2, 4, 1, 2, 0, 1, 1>(a, m_tiles, stream);
+    case 17: return launch_variant<2, 2, 2, 2, 2, 0, 0, 1>(a, m_tiles, stream);
+    default: return launch_variant<1, 1, 2, 2, 2, 0, 0, 1>(a, m_tiles, stream);
   }
 }
 

@@ -41,7 +41,7 @@ for _ in range(a.steps):
 tot /= a.steps
 buf = C.create_string_buffer(512)
 lines = []
-tiles = {v: lib.st_conv_variant_name(v).decode() for v in range(-1, 16)}
+tiles = {v: lib.st_conv_variant_name(v).decode() for v in range(-1, 64)}
 for i in range(n):
     lib.st_detector_op_desc(det.handle, i, buf, 512)
     tf = 2 * macs[i] / (tot[i] * 1e-3) / 1e12 if tot[i] > 0 and macs[i] > 0 else 0
