@@ -205,6 +205,7 @@ __global__ __launch_bounds__(512) void box_depth_kernel(const float* __restrict_
   w.xe = max(py_slice_index(x2, W), w.xs);
   w.cols = w.xe - w.xs;
   w.total = (w.ye - w.ys) * w.cols;
+  if ((x2 - x1) > 800) w.total = 0;  // the reference discards such boxes (`w > 800`): skip every pass
   const bool use_cache = w.total <= BD_CACHE;
   w.cache = nullptr;
 

@@ -207,16 +207,14 @@ __global__ __launch_bounds__(64) void nms_reduce_kernel(DecodeArgs a, float* out
         rem |= db;
       }
     }
-    // OR the rows of the boxes kept in this chunk into the later words (lane owns words w)
-    for (int w = c + 1 + lane; w < T; w += 64) {
-      u64 acc = removed[w];
-      u64 kb = keep;
-      while (kb) {
-        const int b = __builtin_ctzll(kb);
-        kb &= kb - 1ull;
-        acc |= mask[(size_t)(c * 64 + b) * a.Tcap + w];
+    // OR the rows of the boxes kept in this chunk into the later words: lane = kept row, streaming its own
+    // mask row (independent loads, deep memory-level parallelism) and ds_or-ing into the LDS bitmap
+    if ((keep >> lane) & 1ull) {
+      const u64* row = mask + (size_t)i * a.Tcap;
+      for (int w = c + 1; w < T; ++w) {
+        const u64 m = row[w];
+        if (m) atomicOr(reinterpret_cast<unsigned long long*>(&removed[w]), (unsigned long long)m);
       }
-      removed[w] = acc;
     }
     if ((keep >> lane) & 1ull) {
       const int pos = outcount + __builtin_popcountll(keep & ((1ull << lane) - 1ull));

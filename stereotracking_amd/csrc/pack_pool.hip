@@ -90,6 +90,52 @@ __global__ __launch_bounds__(256) void spp_pool_kernel(const float* __restrict__
   }
 }
 
+// SPP via the max-pool cascade mp9 = mp5(mp5), mp13 = mp5(mp9) (exact for max), each mp5 separable
+// (row max then column max), entirely in LDS: one workgroup owns a whole H x W map of CG channels.
+// 6 LDS sweeps instead of a 169-tap window per output.
+template <int CG>
+__global__ __launch_bounds__(256) void spp_pool_lds_kernel(const float* __restrict__ x, int x_ld, int x_off, int H,
+                                                           int W, int C, float* __restrict__ out, int out_ld,
+                                                           int out_off, int copy_x) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int HW = H * W, n = blockIdx.y, c0 = blockIdx.x * CG;
+  float* A = sm;
+  float* B = sm + HW * CG;
+  const int total = HW * CG;
+  for (int e = threadIdx.x; e < total; e += blockDim.x) {
+    const int pix = e / CG, c = e - pix * CG;
+    const float v = x[((size_t)n * HW + pix) * x_ld + x_off + c0 + c];
+    A[e] = v;
+    if (copy_x) out[((size_t)n * HW + pix) * out_ld + out_off + c0 + c] = v;
+  }
+  __syncthreads();
+  for (int level = 1; level <= 3; ++level) {
+    for (int e = threadIdx.x; e < total; e += blockDim.x) {  // row max (along x), A -> B
+      const int pix = e / CG, c = e - pix * CG, py = pix / W, px = pix - py * W;
+      float m = A[e];
+#pragma unroll
+      for (int d = 1; d <= 2; ++d) {
+        if (px - d >= 0) m = fmaxf(m, A[(pix - d) * CG + c]);
+        if (px + d < W) m = fmaxf(m, A[(pix + d) * CG + c]);
+      }
+      B[e] = m;
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < total; e += blockDim.x) {  // column max (along y), B -> A, and store
+      const int pix = e / CG, c = e - pix * CG, py = pix / W;
+      float m = B[e];
+#pragma unroll
+      for (int d = 1; d <= 2; ++d) {
+        if (py - d >= 0) m = fmaxf(m, B[(pix - d * W) * CG + c]);
+        if (py + d < H) m = fmaxf(m, B[(pix + d * W) * CG + c]);
+      }
+      A[e] = m;
+      out[((size_t)n * HW + pix) * out_ld + out_off + level * C + c0 + c] = m;
+    }
+    __syncthreads();
+  }
+}
+
 int focus_pack_launch(const float* img, int N, int C, int H, int W, float* out, hipStream_t stream) {
   ST_REQUIRE(img && out, "focus_pack: null pointer");
   ST_REQUIRE(N > 0 && H > 0 && W > 0 && (H % 2) == 0 && (W % 2) == 0, "focus_pack: H, W must be even");
@@ -111,6 +157,21 @@ int spp_pool_launch(const float* x, int x_ld, int x_off, int N, int H, int W, in
              "spp_pool: channel counts/offsets must be multiples of 4");
   ST_REQUIRE(out_off + 4 * C <= out_ld && x_off + C <= x_ld, "spp_pool: slice exceeds ld");
   const int copy_x = !(x == out && x_ld == out_ld && x_off == out_off);
+  // small maps (the stride-32 level of the path): whole-map LDS cascade, 8 channels per workgroup
+  const size_t lds = (size_t)2 * H * W * 8 * sizeof(float);
+  if (C % 8 == 0 && lds <= 150 * 1024 && N <= 65535) {
+    auto kern = spp_pool_lds_kernel<8>;
+    static bool attr_set = false;
+    if (!attr_set) {
+      ST_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       150 * 1024));
+      attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(C / 8, N), dim3(256), lds, stream, x, x_ld, x_off, H, W, C, out, out_ld, out_off,
+                       copy_x);
+    ST_CHECK_HIP(hipGetLastError());
+    return ST_OK;
+  }
   const long long total = (long long)N * H * W * (C / 4);
   const int blocks = (int)std::min<long long>((total + 255) / 256, 256 * 16);
   hipLaunchKernelGGL(spp_pool_kernel, dim3(blocks), dim3(256), 0, stream, x, x_ld, x_off, N, H, W, C,

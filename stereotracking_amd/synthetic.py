@@ -74,7 +74,11 @@ def synthetic_state_dict(param_table, seed=0, img_stats=(127.5, 73.9), disp_stat
             fan_in = shape[1] * shape[2] * shape[3]
             prefix = name[:-len('.weight')]
             if 'conv_reg' in prefix:
-                sd[name] = zero_sum(randn(shape, 0.15 / math.sqrt(fan_in * _SILU_VAR)))
+                w = zero_sum(randn(shape, 0.15 / math.sqrt(fan_in * _SILU_VAR)))
+                # log-size rows (w, h): keep exp(pred) within ~[0.4, 2.5] x stride, i.e. 4..80 px boxes like
+                # the drones of the AirDrone set (8-60 px rectangles), not 600 px outliers
+                w[2:4] *= 0.3
+                sd[name] = w
                 sd[prefix + '.bias'] = randn((shape[0],), 0.05)
             else:  # conv_cls / conv_obj
                 sd[name] = zero_sum(randn(shape, logit_std / math.sqrt(fan_in * _SILU_VAR)))

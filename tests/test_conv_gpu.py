@@ -182,3 +182,25 @@ def test_bn_folding_fp64(cuda):
     assert torch.equal(wpk, wref)
     assert torch.equal(bp[:cout], (beta.double() - mean.double() * scale).float())
     assert torch.all(bp[cout:] == 0) and torch.all(wp.view(-1, Kpad)[cout:] == 0)
+
+
+@pytest.mark.parametrize('N,H,W,Cc', [(2, 23, 40, 64), (1, 6, 10, 24), (1, 70, 90, 16)])  # last: > LDS, sweep kernel
+def test_spp_pool_matches_torch_maxpool(N, H, W, Cc, cuda):
+    lib = _lib.load()
+    torch.manual_seed(H)
+    x = torch.randn(N, Cc, H, W)
+    cat = torch.full((N, H, W, 4 * Cc + 8), -5.0)
+    cat[..., 8:8 + Cc] = x.permute(0, 2, 3, 1)
+    cat = cat.to(cuda)
+    check(lib.st_spp_pool(ptr(cat), 4 * Cc + 8, 8, N, H, W, Cc, ptr(cat), 4 * Cc + 8, 8, _lib.current_stream()))
+    torch.cuda.synchronize()
+    got = cat.cpu()
+    assert torch.all(got[..., :8] == -5.0)
+    ref = torch.cat([x] + [F.max_pool2d(x, k, 1, k // 2) for k in (5, 9, 13)], 1).permute(0, 2, 3, 1)
+    assert torch.equal(got[..., 8:], ref)
+    # separate input buffer (x is copied into the first C channels of out)
+    xin = x.permute(0, 2, 3, 1).contiguous().to(cuda)
+    out = torch.empty(N, H, W, 4 * Cc, device=cuda)
+    check(lib.st_spp_pool(ptr(xin), Cc, 0, N, H, W, Cc, ptr(out), 4 * Cc, 0, _lib.current_stream()))
+    torch.cuda.synchronize()
+    assert torch.equal(out.cpu(), ref)
