@@ -82,6 +82,7 @@ struct TRef {  // a channel slice of an NHWC buffer
   int N = 0, H = 0, W = 0, C = 0;
   int ld = 0, off = 0;
   size_t base = 0;  // extra float offset inside the buffer (head levels)
+  bool adv = false; // full-batch buffer viewed through a sub-batch window: pointer advances per sub-batch
   bool valid() const { return buf != BUF_NONE; }
   TRef slice(int o, int c) const {
     TRef t = *this;
@@ -106,6 +107,7 @@ struct Op {
   double macs = 0.0;   // conv MACs of this op
   int variant = -1;    // conv tile variant picked at the last launch
   int tuned = -1;      // measured best variant (st_detector_autotune), -1 = heuristic
+  int group = 0;       // sub-batch group (0 = whole batch in one launch)
 };
 
 }  // namespace
@@ -137,6 +139,26 @@ struct StDetector {
   bool timing = false;
   std::vector<hipEvent_t> events;  // 2 per op
   int force_variant = -1;          // autotune only
+  // Sub-batch groups: the high-resolution front of the network is run SB images at a time through
+  // SB-sized intermediate buffers that are REUSED by every sub-batch, so the intermediates of one
+  // sub-batch (~100 MB per image at 736x1280) stay in the 256 MiB Infinity Cache instead of
+  // streaming N x that through HBM.  groups[g] = {SB, count}; group 0 = none.
+  struct Group { int sb, count; };
+  std::vector<Group> groups{{0, 1}};
+  int cur_group = 0;
+  int max_group_count = 1;
+  int begin_group(int sb, int total) {
+    groups.push_back({sb, total / sb});
+    max_group_count = std::max(max_group_count, total / sb);
+    cur_group = (int)groups.size() - 1;
+    return cur_group;
+  }
+  void end_group() { cur_group = 0; }
+  static TRef window(TRef full, int sb) {  // sub-batch window of a full-batch tensor
+    full.N = sb;
+    full.adv = true;
+    return full;
+  }
 
   // ---- building blocks -------------------------------------------------------------------
   int add_param(const std::string& name, std::vector<int64_t> shape) {
@@ -204,9 +226,11 @@ struct StDetector {
     o.split = split < 0 ? convs[pc].cout : split;
     o.stride = stride; o.pad = convs[pc].k / 2; o.act = act; o.post_scale = post_scale;
     o.phase = cur_phase;
+    o.group = cur_group;
     const int Ho = (in.H + 2 * o.pad - convs[pc].k) / stride + 1;
     const int Wo = (in.W + 2 * o.pad - convs[pc].k) / stride + 1;
-    o.macs = (double)in.N * Ho * Wo * convs[pc].k * convs[pc].k * convs[pc].cin * convs[pc].cout;
+    o.macs = (double)in.N * groups[cur_group].count * Ho * Wo * convs[pc].k * convs[pc].k * convs[pc].cin *
+             convs[pc].cout;
     macs += o.macs;
     ops.push_back(o);
   }
@@ -259,7 +283,6 @@ int StDetector::build() {
             n4 = make_round(3, dpt), nn = make_round(3, dpt);
   const int H2 = H / 2, W2 = W / 2, H4 = H / 4, W4 = W / 4, H8 = H / 8, W8 = W / 8, H16 = H / 16,
             W16 = W / 16, H32 = H / 32, W32 = W / 32;
-  (void)H4; (void)W4;
 
   // neck concat buffers first: backbone stage outputs are stored straight into them
   TRef catTD0 = new_tensor(N, H16, W16, 2 * c4);  // [up(r2) | C4]
@@ -279,9 +302,20 @@ int StDetector::build() {
       ops.push_back(g);
     }
   }
-  TRef stem = convmodule("backbone.stem.conv", packed_rgb, c1, 3, 1);
-  TRef s1c = convmodule("backbone.stage1.0", stem, c2, 3, 2);
-  TRef s1 = csp_layer("backbone.stage1.1", s1c, c2, n1, true);
+  // images per sub-batch of the high-resolution front.  Measured on MI355X (bench.py, N=8): off 1135,
+  // SB=4 1110, SB=2 1066, SB=1 974 pairs/s - the smaller launches cost more than the Infinity-Cache
+  // residency buys, so the default is OFF (ST_SUBBATCH=k re-enables it for experiments).
+  int sbatch = 0;
+  if (const char* e = getenv("ST_SUBBATCH")) sbatch = atoi(e);
+  if (sbatch <= 0 || N % sbatch != 0) sbatch = N;  // one group covering the whole batch
+  TRef s1 = new_tensor(NB, H4, W4, c2);  // stage1 features of every (left | right) image: kept for the stereo module
+  begin_group(sbatch, NB);
+  {
+    TRef stem = convmodule("backbone.stem.conv", window(packed_rgb, sbatch), c1, 3, 1);
+    TRef s1c = convmodule("backbone.stage1.0", stem, c2, 3, 2);
+    csp_layer("backbone.stage1.1", s1c, c2, n1, true, window(s1, sbatch));
+  }
+  end_group();
   taps["stage1_rgb"] = s1;
 
   // ---- phase 1: disparity branch + everything after the fusion
@@ -293,14 +327,19 @@ int StDetector::build() {
     Op f; f.type = Op::FOCUS; f.focus_input = 1; f.out1 = packed_disp; f.focus_batch_off = 0; f.phase = 1;
     ops.push_back(f);
   }
-  TRef dstem = convmodule("backbone.disp_stem.conv", packed_disp, c1, 3, 1);
-  TRef d1c = convmodule("backbone.disp_stage1.0", dstem, c2, 3, 2);
-  // y = (o_stem + o_disp_stem) / 2   (csp_darknet_disparity_v1.py:184)
-  TRef y = csp_layer("backbone.disp_stage1.1", d1c, c2, n1, true, TRef(), s1_left, 0.5f);
+  TRef y = new_tensor(N, H4, W4, c2);
+  TRef C3 = catTD1.slice(c3, c3);
+  begin_group(sbatch, N);
+  {
+    TRef dstem = convmodule("backbone.disp_stem.conv", window(packed_disp, sbatch), c1, 3, 1);
+    TRef d1c = convmodule("backbone.disp_stage1.0", dstem, c2, 3, 2);
+    // y = (o_stem + o_disp_stem) / 2   (csp_darknet_disparity_v1.py:184)
+    csp_layer("backbone.disp_stage1.1", d1c, c2, n1, true, window(y, sbatch), window(s1_left, sbatch), 0.5f);
+    TRef s2c = convmodule("backbone.stage2.0", window(y, sbatch), c3, 3, 2);
+    csp_layer("backbone.stage2.1", s2c, c3, n2, true, window(C3, sbatch));
+  }
+  end_group();
   taps["stage1_fused"] = y;
-
-  TRef s2c = convmodule("backbone.stage2.0", y, c3, 3, 2);
-  TRef C3 = csp_layer("backbone.stage2.1", s2c, c3, n2, true, catTD1.slice(c3, c3));
   taps["stage2"] = C3;
   TRef s3c = convmodule("backbone.stage3.0", C3, c4, 3, 2);
   TRef C4 = csp_layer("backbone.stage3.1", s3c, c4, n3, true, catTD0.slice(c4, c4));
@@ -482,57 +521,78 @@ extern "C" int st_detector_level_info(const StDetector* det, int level, int* h, 
 
 namespace {
 
-float* resolve(const StDetector* det, const TRef& t, float* ws, float* head) {
+float* resolve(const StDetector* det, const TRef& t, float* ws, float* head, int img0 = 0) {
   if (t.buf == BUF_NONE) return nullptr;
   if (t.buf == BUF_HEAD) return head + t.base;
-  return ws + det->buf_off[t.buf] + t.base;
+  // `adv` tensors are sub-batch windows of a full-batch buffer: move to image img0
+  const size_t shift = t.adv ? (size_t)img0 * t.H * t.W * t.ld : 0;
+  return ws + det->buf_off[t.buf] + t.base + shift;
 }
 
+int launch_op(StDetector* det, Op& o, int img0, const float* const inputs[3], float* ws, float* head,
+              hipStream_t stream) {
+  switch (o.type) {
+    case Op::FOCUS: {
+      const float* src = inputs[o.focus_input];
+      ST_REQUIRE(src != nullptr, "detector: input %d not provided", o.focus_input);
+      float* dst = resolve(det, o.out1, ws, head) + (size_t)o.focus_batch_off * o.out1.H * o.out1.W * o.out1.ld;
+      return focus_pack_launch(src, det->cfg.batch, 3, det->cfg.height, det->cfg.width, dst, stream);
+    }
+    case Op::SPP: {
+      float* x = resolve(det, o.in, ws, head, img0);
+      float* out = resolve(det, o.out1, ws, head, img0);
+      return spp_pool_launch(x, o.in.ld, o.in.off, o.in.N, o.in.H, o.in.W, o.in.C, out, o.out1.ld, o.out1.off,
+                             stream);
+    }
+    case Op::CONV: {
+      const PackedConv& pc = det->convs[o.pc];
+      StConvDesc d{};
+      d.in_dev = resolve(det, o.in, ws, head, img0);
+      d.N = o.in.N; d.Hi = o.in.H; d.Wi = o.in.W; d.Cin = pc.cin; d.in_ld = o.in.ld; d.in_off = o.in.off;
+      d.wgt_dev = det->wgt_dev + pc.wgt_off;
+      d.bias_dev = det->wgt_dev + pc.bias_off;
+      d.Cout = pc.cout; d.KH = pc.k; d.KW = pc.k; d.stride = o.stride; d.pad = o.pad;
+      d.out1_dev = resolve(det, o.out1, ws, head, img0); d.out1_ld = o.out1.ld; d.out1_off = o.out1.off;
+      d.split = o.split;
+      d.out2_dev = resolve(det, o.out2, ws, head, img0); d.out2_ld = o.out2.ld; d.out2_off = o.out2.off;
+      d.up_dev = resolve(det, o.up, ws, head, img0); d.up_ld = o.up.ld; d.up_off = o.up.off;
+      d.res_dev = resolve(det, o.res, ws, head, img0); d.res_ld = o.res.ld; d.res_off = o.res.off;
+      d.post_scale = o.post_scale; d.act = o.act;
+      return conv2d_launch(d, stream, det->force_variant >= 0 ? det->force_variant : o.tuned, &o.variant);
+    }
+  }
+  return ST_OK;
+}
+
+// Runs the ops of phases [phase_lo, phase_hi].  Consecutive ops of one sub-batch group are executed
+// sub-batch-major (all ops on images [0,SB), then [SB,2SB), ...) so their SB-sized intermediates are
+// produced and consumed while still resident in the Infinity Cache.
 int run_ops(StDetector* det, int phase_lo, int phase_hi, const float* const inputs[3], float* ws,
             float* head, hipStream_t stream) {
-  if (det->timing && det->events.size() != 2 * det->ops.size()) {
-    det->events.resize(2 * det->ops.size());
+  const size_t ev_per_op = 2 * (size_t)det->max_group_count;
+  if (det->timing && det->events.size() != ev_per_op * det->ops.size()) {
+    for (auto& e : det->events) (void)hipEventDestroy(e);
+    det->events.resize(ev_per_op * det->ops.size());
     for (auto& e : det->events) ST_CHECK_HIP(hipEventCreate(&e));
   }
-  for (size_t oi = 0; oi < det->ops.size(); ++oi) {
-    Op& o = det->ops[oi];
-    if (o.phase < phase_lo || o.phase > phase_hi) continue;
-    if (det->timing) ST_CHECK_HIP(hipEventRecord(det->events[2 * oi], stream));
-    switch (o.type) {
-      case Op::FOCUS: {
-        const float* src = inputs[o.focus_input];
-        ST_REQUIRE(src != nullptr, "detector: input %d not provided", o.focus_input);
-        float* dst = resolve(det, o.out1, ws, head) +
-                     (size_t)o.focus_batch_off * o.out1.H * o.out1.W * o.out1.ld;
-        ST_CHECK(focus_pack_launch(src, det->cfg.batch, 3, det->cfg.height, det->cfg.width, dst, stream));
-        break;
-      }
-      case Op::SPP: {
-        float* x = resolve(det, o.in, ws, head);
-        float* out = resolve(det, o.out1, ws, head);
-        ST_CHECK(spp_pool_launch(x, o.in.ld, o.in.off, o.in.N, o.in.H, o.in.W, o.in.C, out, o.out1.ld,
-                                 o.out1.off, stream));
-        break;
-      }
-      case Op::CONV: {
-        const PackedConv& pc = det->convs[o.pc];
-        StConvDesc d{};
-        d.in_dev = resolve(det, o.in, ws, head);
-        d.N = o.in.N; d.Hi = o.in.H; d.Wi = o.in.W; d.Cin = pc.cin; d.in_ld = o.in.ld; d.in_off = o.in.off;
-        d.wgt_dev = det->wgt_dev + pc.wgt_off;
-        d.bias_dev = det->wgt_dev + pc.bias_off;
-        d.Cout = pc.cout; d.KH = pc.k; d.KW = pc.k; d.stride = o.stride; d.pad = o.pad;
-        d.out1_dev = resolve(det, o.out1, ws, head); d.out1_ld = o.out1.ld; d.out1_off = o.out1.off;
-        d.split = o.split;
-        d.out2_dev = resolve(det, o.out2, ws, head); d.out2_ld = o.out2.ld; d.out2_off = o.out2.off;
-        d.up_dev = resolve(det, o.up, ws, head); d.up_ld = o.up.ld; d.up_off = o.up.off;
-        d.res_dev = resolve(det, o.res, ws, head); d.res_ld = o.res.ld; d.res_off = o.res.off;
-        d.post_scale = o.post_scale; d.act = o.act;
-        ST_CHECK(conv2d_launch(d, stream, det->force_variant >= 0 ? det->force_variant : o.tuned, &o.variant));
-        break;
+  const size_t nops = det->ops.size();
+  size_t oi = 0;
+  while (oi < nops) {
+    Op& first = det->ops[oi];
+    if (first.phase < phase_lo || first.phase > phase_hi) { ++oi; continue; }
+    size_t oe = oi + 1;
+    if (first.group > 0)
+      while (oe < nops && det->ops[oe].group == first.group && det->ops[oe].phase == first.phase) ++oe;
+    const StDetector::Group g = det->groups[first.group];
+    for (int sbi = 0; sbi < g.count; ++sbi) {
+      for (size_t k = oi; k < oe; ++k) {
+        Op& o = det->ops[k];
+        if (det->timing) ST_CHECK_HIP(hipEventRecord(det->events[ev_per_op * k + 2 * sbi], stream));
+        ST_CHECK(launch_op(det, o, sbi * g.sb, inputs, ws, head, stream));
+        if (det->timing) ST_CHECK_HIP(hipEventRecord(det->events[ev_per_op * k + 2 * sbi + 1], stream));
       }
     }
-    if (det->timing) ST_CHECK_HIP(hipEventRecord(det->events[2 * oi + 1], stream));
+    oi = oe;
   }
   return ST_OK;
 }
@@ -593,12 +653,18 @@ extern "C" int st_detector_num_ops(const StDetector* det) { return det ? (int)de
 extern "C" int st_detector_op_times(StDetector* det, int cap, float* ms, int* kind, int* variant, double* macs,
                                     int* phase) {
   if (!det) return set_error(ST_ERR_INVALID, "st_detector_op_times: null detector");
-  ST_REQUIRE(det->events.size() == 2 * det->ops.size(), "st_detector_op_times: no timed forward has run");
+  const size_t ev_per_op = 2 * (size_t)det->max_group_count;
+  ST_REQUIRE(det->events.size() == ev_per_op * det->ops.size(), "st_detector_op_times: no timed forward has run");
   ST_REQUIRE(cap >= (int)det->ops.size(), "st_detector_op_times: capacity %d < %zu ops", cap, det->ops.size());
   for (size_t i = 0; i < det->ops.size(); ++i) {
-    ST_CHECK_HIP(hipEventSynchronize(det->events[2 * i + 1]));
     float t = 0.f;
-    ST_CHECK_HIP(hipEventElapsedTime(&t, det->events[2 * i], det->events[2 * i + 1]));
+    const int cnt = det->groups[det->ops[i].group].count;
+    for (int sbi = 0; sbi < cnt; ++sbi) {
+      ST_CHECK_HIP(hipEventSynchronize(det->events[ev_per_op * i + 2 * sbi + 1]));
+      float dt = 0.f;
+      ST_CHECK_HIP(hipEventElapsedTime(&dt, det->events[ev_per_op * i + 2 * sbi], det->events[ev_per_op * i + 2 * sbi + 1]));
+      t += dt;
+    }
     if (ms) ms[i] = t;
     if (kind) kind[i] = det->ops[i].type == Op::FOCUS ? 0 : det->ops[i].type == Op::CONV ? 1 : 2;
     if (variant) variant[i] = det->ops[i].variant;
@@ -698,9 +764,9 @@ extern "C" int st_detector_op_desc(const StDetector* det, int i, char* buf, int 
     snprintf(buf, (size_t)cap, "spp_pool N=%d H=%d W=%d C=%d", o.in.N, o.in.H, o.in.W, o.in.C);
   } else {
     const PackedConv& pc = det->convs[o.pc];
-    snprintf(buf, (size_t)cap, "conv k%d s%d N=%d Hi=%d Wi=%d Cin=%d Cout=%d%s%s%s  %s", pc.k, o.stride, o.in.N, o.in.H,
-             o.in.W, pc.cin, pc.cout, o.res.valid() ? " +res" : "", o.up.valid() ? " +up" : "",
-             o.out2.valid() ? " +split" : "", pc.srcs[0].conv_prefix.c_str());
+    snprintf(buf, (size_t)cap, "conv k%d s%d N=%dx%d Hi=%d Wi=%d Cin=%d Cout=%d%s%s%s  %s", pc.k, o.stride, o.in.N,
+             det->groups[o.group].count, o.in.H, o.in.W, pc.cin, pc.cout, o.res.valid() ? " +res" : "",
+             o.up.valid() ? " +up" : "", o.out2.valid() ? " +split" : "", pc.srcs[0].conv_prefix.c_str());
   }
   return ST_OK;
 }
