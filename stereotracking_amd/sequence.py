@@ -1,0 +1,122 @@
+"""Sequence-level drivers for BASELINE.json configs[2] / configs[3]:
+
+  configs[2]  one synthetic sequence on one GPU: the dense path runs batched (B frames per launch
+              plan), detections feed the CPU OC-SORT association in frame order
+  configs[3]  one long sequence sharded over the ranks of a node: every rank runs the dense path on its
+              contiguous chunk of frames, ONE all-gather of the fixed-size detection buffers (RCCL over
+              xGMI with backend 'nccl'), then the tracker consumes all frames in order
+
+Because the dense path is stateless per frame (reference mmtrack/models/mot/ocsort_disparity.py:73-83)
+the gathered detections - and therefore the track ids - equal those of the sequential run.
+"""
+import numpy as np
+import torch
+
+from . import dist as sdist
+from .mot import scale_bbox
+from .structures import InstanceData, TrackDataSample
+
+
+def synthetic_sequence(num_frames=64, num_objects=6, height=720, width=1280, max_disp=192, seed=0):
+    """`num_objects` rectangles (8-60 px) moving with constant velocity + noise
+    over a textured background, per-frame disparity consistent with per-object depth 5-60 m
+    (disp = 0.25 * 640 / Z).  Yields dicts with left/right uint8 (3,H,W), disp float32 (H,W), gt boxes."""
+    rng = np.random.RandomState(seed)
+    bg = rng.randint(0, 256, size=(3, height, width + max_disp)).astype(np.uint8)
+    tex = rng.randint(0, 256, size=(num_objects, 3, 64, 64)).astype(np.uint8)
+    pos = rng.uniform([100, 80], [width - 100, height - 80], (num_objects, 2))
+    vel = rng.uniform(-3, 3, (num_objects, 2))
+    size = rng.randint(8, 61, (num_objects, 2))
+    depth = rng.uniform(5, 60, num_objects)
+    bg_disp = 2
+    for t in range(num_frames):
+        left = bg[:, :, bg_disp:bg_disp + width].copy()   # background at a small constant disparity
+        right = bg[:, :, :width].copy()
+        disp = np.full((height, width), float(bg_disp), np.float32)
+        boxes = []
+        order = np.argsort(-depth)  # far objects first, near ones overwrite them
+        p = pos + vel * t + rng.normal(0, 0.3, (num_objects, 2))
+        for k in order:
+            w, h = int(size[k, 0]), int(size[k, 1])
+            x1, y1 = int(round(p[k, 0] - w / 2)), int(round(p[k, 1] - h / 2))
+            d = int(round(0.25 * 640 / depth[k]))
+            if x1 - d < 0 or y1 < 0 or x1 + w > width or y1 + h > height:
+                continue
+            patch = tex[k][:, :h, :w]
+            left[:, y1:y1 + h, x1:x1 + w] = patch
+            right[:, y1:y1 + h, x1 - d:x1 - d + w] = patch
+            disp[y1:y1 + h, x1:x1 + w] = d
+            boxes.append((k, x1, y1, x1 + w, y1 + h, depth[k]))
+        yield dict(frame_id=t, left=left, right=right, disp=disp, gt=np.array(boxes, np.float32).reshape(-1, 6))
+
+
+def frames_to_batch(frames, device, use_right=True):
+    """List of frame dicts -> padded float tensors in the detector's input layout."""
+    from .synthetic import pad_to_divisor
+    img = np.stack([pad_to_divisor(f['left'].astype(np.float32), 32, 114.0) for f in frames])
+    out = dict(img=torch.from_numpy(img).to(device))
+    if use_right:
+        right = np.stack([pad_to_divisor(f['right'].astype(np.float32), 32, 114.0) for f in frames])
+        out['right'] = torch.from_numpy(right).to(device)
+    else:
+        d = np.stack([np.repeat(pad_to_divisor(f['disp'], 32, 0.0)[None], 3, 0) for f in frames])
+        out['disp_postp'] = torch.from_numpy(d).to(device)
+    return out
+
+
+def detect_shard(pipe, frames, device):
+    """Dense path over this rank's frames, `pipe.batch` frames per launch plan.
+    -> (F_pad, max_det, 8) detection buffer with SCALED boxes (what the tracker consumes), counts."""
+    B = pipe.batch
+    bufs, counts = [], []
+    for i in range(0, len(frames), B):
+        chunk = list(frames[i:i + B])
+        n_real = len(chunk)
+        chunk = chunk + [chunk[-1]] * (B - n_real)  # pad the last batch with a repeated frame
+        batch = frames_to_batch(chunk, device, use_right=pipe.stereo)
+        out = pipe.run(batch['img'], right=batch.get('right'), disp_postp=batch.get('disp_postp'))
+        det = torch.cat([out['scaled_boxes'], out['scores'][..., None], out['labels'][..., None].float(),
+                         out['depth'][..., None], out['scales'][..., None]], dim=-1)
+        c = torch.minimum(out['counts'], torch.full_like(out['counts'], pipe.max_det))
+        c[n_real:] = 0
+        bufs.append(det.clone())
+        counts.append(c.clone())
+    return torch.cat(bufs), torch.cat(counts)
+
+
+def track_gathered(dets, counts, num_frames, tracker, model):
+    """CPU association over gathered detections in frame order -> list of InstanceData per frame
+    (boxes unscaled back, as OCSORT_Disparity.predict does at ocsort_disparity.py:95-97)."""
+    dets, counts = dets.cpu(), counts.cpu()
+    results = []
+    for t in range(num_frames):
+        f = sdist.unpack_frame(dets[t], counts[t])
+        sample = TrackDataSample(dict(frame_id=t))
+        sample.pred_det_instances = InstanceData(**f)
+        trk = tracker.track(model, None, None, sample)
+        trk['bboxes'] = scale_bbox(trk.bboxes, 1 / trk.scales)
+        results.append(trk)
+    return results
+
+
+def run_sharded_sequence(pipe, frames, tracker, model, device):
+    """configs[3]: shard `frames` over the ranks, detect, all-gather once, track everywhere."""
+    frames = list(frames)
+    T = len(frames)
+    start, stop, chunk = sdist.shard_frames(T)
+    per_rank = (chunk + pipe.batch - 1) // pipe.batch * pipe.batch   # equal padded length on every rank
+    mine = frames[start:stop]
+    if mine:
+        dets, counts = detect_shard(pipe, mine, device)
+    else:
+        dets = torch.zeros(0, pipe.max_det, 8, device=device)
+        counts = torch.zeros(0, dtype=torch.int32, device=device)
+    pad = per_rank - dets.shape[0]
+    if pad:
+        dets = torch.cat([dets, dets.new_zeros(pad, pipe.max_det, 8)])
+        counts = torch.cat([counts, counts.new_zeros(pad)])
+    all_dets, all_counts = sdist.gather_detections(dets, counts)
+    _, world = sdist.world()
+    # drop the per-rank padding: rank r holds frames [r*chunk, r*chunk + chunk) in its first `chunk` slots
+    idx = torch.cat([torch.arange(r * per_rank, r * per_rank + chunk) for r in range(world)])[:T]
+    return track_gathered(all_dets[idx.to(all_dets.device)], all_counts[idx.to(all_counts.device)], T, tracker, model)
