@@ -257,8 +257,10 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(ConvKArgs p) {
     const float* Ab = As + buf * BM * LDK + (wm * 32 * TM + l31) * LDK + (DMA ? 0 : 4 * lh);
     const float* Bb = Bs + buf * BN * LDK + (wn * 32 * TN + l31) * LDK + (DMA ? 0 : 4 * lh);
     const int sw = (l31 >> 1) & 7;  // DMA image: k-group g of a row lives in 16-B slot g ^ sw
+    const int gmax = (p.K - kc * BK + 7) >> 3;  // k-groups of this chunk that hold real data (K tail)
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
+      if (g >= gmax) break;
       f32x4 a[TM], b[TN];
       const int koff = DMA ? (((2 * g + lh) ^ sw) * 4) : g * 8;
 #pragma unroll
@@ -422,13 +424,15 @@ static int launch_variant(const ConvKArgs& a, int m_tiles, hipStream_t stream) {
 //  9  64x64  (1 wave, barrier-free, single LDS buffer)   10 64x32 (1 wave)   11 32x64 (1 wave)
 // 12..16: LDS-DMA staging of 0 / 3 / 7 / 6 / 5 (DMA issue threaded through the MFMA stream);
 // 17, 18: LDS-DMA 128x128 / 64x64 with the DMA burst at the top of the chunk
+// 19..21: 256x128 tiles, 8 waves of 64x64 (LDS-DMA threaded / LDS-DMA burst / register staging)
 struct ConvVariant { int bm, bn, threads; };
 static const ConvVariant kVariants[] = {{128, 128, 256}, {128, 64, 128}, {128, 32, 128}, {64, 64, 256},
                                         {64, 32, 128},   {128, 64, 256}, {128, 32, 256}, {64, 128, 256},
                                         {256, 64, 256},  {64, 64, 64},   {64, 32, 64},   {32, 64, 64},
                                         {128, 128, 256}, {64, 64, 256},  {64, 128, 256}, {128, 32, 256},
-                                        {128, 64, 256},  {128, 128, 256}, {64, 64, 256}};
-constexpr int kNumVariants = 19;
+                                        {128, 64, 256},  {128, 128, 256}, {64, 64, 256},
+                                        {256, 128, 512}, {256, 128, 512}, {256, 128, 512}};
+constexpr int kNumVariants = 22;
 
 int conv_variant_count() { return kNumVariants; }
 bool conv_variant_valid(int id, int cout) {
@@ -438,7 +442,7 @@ const char* conv_variant_name(int id) {
   static const char* names[] = {"128x128", "128x64w2", "128x32w2", "64x64", "64x32w2",
                                 "128x64", "128x32", "64x128", "256x64", "64x64w1", "64x32w1", "32x64w1",
                                 "128x128dma", "64x64dma", "64x128dma", "128x32dma", "128x64dma",
-                                "128x128dmab", "64x64dmab"};
+                                "128x128dmab", "64x64dmab", "256x128dma", "256x128dmab", "256x128"};
   return id >= 0 && id < kNumVariants ? names[id] : "-";
 }
 
@@ -544,7 +548,10 @@ int conv2d_launch(const StConvDesc& d, hipStream_t stream, int force_variant, in
     case 15: return launch_variant<1, 1, 4, 1, 2, 0, 1, 1>(a, m_tiles, stream);
     case 16: return launch_variant<1, 2, 4, 1, 2, 0, 1, 1>(a, m_tiles, stream);
     case 17: return launch_variant<2, 2, 2, 2, 2, 0, 0, 1>(a, m_tiles, stream);
-    default: return launch_variant<1, 1, 2, 2, 2, 0, 0, 1>(a, m_tiles, stream);
+    case 18: return launch_variant<1, 1, 2, 2, 2, 0, 0, 1>(a, m_tiles, stream);
+    case 19: return launch_variant<2, 2, 4, 2, 2, 0, 1, 1>(a, m_tiles, stream);
+    case 20: return launch_variant<2, 2, 4, 2, 2, 0, 0, 1>(a, m_tiles, stream);
+    default: return launch_variant<2, 2, 4, 2, 2, 0, 1, 0>(a, m_tiles, stream);
   }
 }
 

@@ -118,7 +118,7 @@ def test_conv_matches_torch(case, cuda):
 @pytest.mark.parametrize('variant,cout', [(0, 128), (1, 64), (2, 32), (3, 64), (4, 32), (0, 256), (3, 128), (5, 64),
                                           (6, 32), (7, 128), (8, 64), (5, 192), (6, 96), (9, 64), (10, 32), (11, 64),
                                           (9, 128), (10, 96), (12, 128), (13, 64), (14, 128), (15, 32), (16, 64),
-                                          (17, 256), (18, 192)])
+                                          (17, 256), (18, 192), (19, 128), (20, 256), (21, 128)])
 def test_conv_all_tile_variants(variant, cout, cuda):
     torch.manual_seed(variant)
     x = torch.randn(2, 64, 13, 21)
