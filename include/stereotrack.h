@@ -97,6 +97,16 @@ int st_conv_pack_weights(const float* w, const float* conv_bias, /* may be NULL 
 int st_focus_pack(const float* img_nchw_dev, int N, int C, int H, int W,
                   float* out_nhwc_dev, st_stream_t stream);
 
+/* Raw input packing: uint8 image (N,3,h,w) -> fp32 (N,3,H,W) padded with img_pad;
+ * uint16 disparity PNG codes (N,h,w) -> disp_postp fp32 px = code/16 (65535 -> 0) x3 channels padded with
+ * 0, and disp_mask (N,1,H,W) = code < 65535.  Replaces LoadDisparityFromFile._post_processing_v2
+ * (reference datasets/transforms/loading_disparity.py:82-86,129-134), Pad_Disparity
+ * (transforms_disparity.py:234-249) and the preprocessor's cast + pad
+ * (data_preprocessor_disparity_v1.py:38-51) for frames uploaded raw.  Any of the two halves may be NULL. */
+int st_pack_raw_inputs(const unsigned char* img_u8_dev, const unsigned short* disp_u16_dev, int N, int h, int w,
+                       int H, int W, float img_pad, float* img_out_dev, float* disp_postp_out_dev,
+                       float* disp_mask_out_dev, st_stream_t stream);
+
 /* SPP: out[..., 0:C]=x, [C:2C]=maxpool5, [2C:3C]=maxpool9, [3C:4C]=maxpool13
  * (stride 1, same pad, -inf padding).  x may alias out channels [0,C).
  * Replaces mmyolo SPPFBottleneck pooling, csp_darknet_disparity_v1.py:137-144 */

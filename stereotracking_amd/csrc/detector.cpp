@@ -684,7 +684,7 @@ extern "C" int st_detector_autotune(StDetector* det, void* workspace_dev, size_t
   ST_REQUIRE(workspace_dev && head_out_dev, "st_detector_autotune: null pointer");
   if (workspace_bytes < det->ws_floats * sizeof(float))
     return set_error(ST_ERR_WORKSPACE, "st_detector_autotune: workspace too small");
-  if (reps <= 0) reps = 3;
+  if (reps <= 0) reps = 5;
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   hipEvent_t e0, e1;
   ST_CHECK_HIP(hipEventCreate(&e0));
@@ -706,16 +706,21 @@ extern "C" int st_detector_autotune(StDetector* det, void* workspace_dev, size_t
       det->force_variant = v;
       rc = run_ops(det, 0, 0, inputs, static_cast<float*>(workspace_dev), head_out_dev, stream);  // warm
       if (rc != ST_OK) break;
-      if (hipEventRecord(e0, stream) != hipSuccess) { rc = set_error(ST_ERR_HIP, "autotune: event record"); break; }
-      for (int r = 0; r < reps && rc == ST_OK; ++r)
+      // min over `reps` individually timed launches (a mean over a burst is too noisy to rank 20 variants)
+      float ms = 1e30f;
+      for (int r = 0; r < reps && rc == ST_OK; ++r) {
+        if (hipEventRecord(e0, stream) != hipSuccess) { rc = set_error(ST_ERR_HIP, "autotune: event record"); break; }
         rc = run_ops(det, 0, 0, inputs, static_cast<float*>(workspace_dev), head_out_dev, stream);
-      if (rc != ST_OK) break;
-      if (hipEventRecord(e1, stream) != hipSuccess || hipEventSynchronize(e1) != hipSuccess) {
-        rc = set_error(ST_ERR_HIP, "autotune: event sync");
-        break;
+        if (rc != ST_OK) break;
+        if (hipEventRecord(e1, stream) != hipSuccess || hipEventSynchronize(e1) != hipSuccess) {
+          rc = set_error(ST_ERR_HIP, "autotune: event sync");
+          break;
+        }
+        float t = 0.f;
+        (void)hipEventElapsedTime(&t, e0, e1);
+        ms = std::min(ms, t);
       }
-      float ms = 0.f;
-      (void)hipEventElapsedTime(&ms, e0, e1);
+      if (rc != ST_OK) break;
       if (ms < best) { best = ms; best_v = v; }
     }
     saved[oi].tuned = best_v;

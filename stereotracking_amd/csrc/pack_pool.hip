@@ -192,3 +192,67 @@ extern "C" int st_spp_pool(const float* x, int x_ld, int x_off, int N, int H, in
   return st::spp_pool_launch(x, x_ld, x_off, N, H, W, C, out, out_ld, out_off,
                              static_cast<hipStream_t>(stream));
 }
+
+// ---- raw input packing -------------------------------------------------------------
+// Device-side restatement of the test-time input pipeline, so a frame crosses PCIe as uint8 pixels and
+// uint16 disparity codes (4.7 MB) instead of three fp32 tensors (15.1 MB):
+//   img  : uint8 (N,3,h,w) -> fp32 (N,3,H,W), bottom/right padding = img_pad (114, Pad_Disparity,
+//          reference transforms_disparity.py:234-249; then stack_batch pads with 0 - same extent here)
+//   disp : uint16 PNG code (N,h,w) -> fp32 px = code/16 with 65535 -> 0 (LoadDisparityFromFile
+//          ._post_processing_v2, reference loading_disparity.py:129-134), replicated to 3 channels
+//          (:85-86), padding 0; disp_mask = code < 65535 (:82).
+namespace st {
+
+__global__ __launch_bounds__(256) void pack_raw_inputs_kernel(const unsigned char* __restrict__ img,
+                                                              const unsigned short* __restrict__ disp, int N, int h,
+                                                              int w, int H, int W, float img_pad,
+                                                              float* __restrict__ img_out,
+                                                              float* __restrict__ disp_out,
+                                                              float* __restrict__ mask_out) {
+  const long long total = (long long)N * H * W;
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (long long)gridDim.x * blockDim.x) {
+    const int X = (int)(idx % W);
+    const long long t = idx / W;
+    const int Y = (int)(t % H);
+    const int n = (int)(t / H);
+    const bool inside = Y < h && X < w;
+    const size_t plane = (size_t)H * W;
+    if (img_out) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const float v = inside ? (float)img[(((size_t)n * 3 + c) * h + Y) * w + X] : img_pad;
+        img_out[((size_t)n * 3 + c) * plane + (size_t)Y * W + X] = v;
+      }
+    }
+    if (disp_out) {
+      float d = 0.f, m = 0.f;
+      if (inside) {
+        const unsigned code = disp[((size_t)n * h + Y) * w + X];
+        m = code < 65535u ? 1.f : 0.f;
+        d = (code == 65535u ? 0.f : (float)code) / 16.0f;
+      }
+#pragma unroll
+      for (int c = 0; c < 3; ++c) disp_out[((size_t)n * 3 + c) * plane + (size_t)Y * W + X] = d;
+      if (mask_out) mask_out[(size_t)n * plane + (size_t)Y * W + X] = m;
+    }
+  }
+}
+
+}  // namespace st
+
+extern "C" int st_pack_raw_inputs(const unsigned char* img_u8_dev, const unsigned short* disp_u16_dev, int N, int h,
+                                  int w, int H, int W, float img_pad, float* img_out_dev, float* disp_postp_out_dev,
+                                  float* disp_mask_out_dev, st_stream_t stream) {
+  using namespace st;
+  ST_REQUIRE(N > 0 && h > 0 && w > 0 && H >= h && W >= w, "st_pack_raw_inputs: bad geometry");
+  ST_REQUIRE((img_u8_dev && img_out_dev) || (disp_u16_dev && disp_postp_out_dev), "st_pack_raw_inputs: nothing to do");
+  ST_REQUIRE(!img_out_dev || img_u8_dev, "st_pack_raw_inputs: img output without img input");
+  ST_REQUIRE(!disp_postp_out_dev || disp_u16_dev, "st_pack_raw_inputs: disparity output without disparity input");
+  const long long total = (long long)N * H * W;
+  const int blocks = (int)std::min<long long>((total + 255) / 256, 256 * 16);
+  hipLaunchKernelGGL(pack_raw_inputs_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), img_u8_dev,
+                     disp_u16_dev, N, h, w, H, W, img_pad, img_out_dev, disp_postp_out_dev, disp_mask_out_dev);
+  ST_CHECK_HIP(hipGetLastError());
+  return ST_OK;
+}

@@ -87,7 +87,7 @@ class HipDetector:
         check(self.lib.st_detector_finalize(self.handle), 'st_detector_finalize')
         self._finalized = True
 
-    def autotune(self, device=None, reps=3):
+    def autotune(self, device=None, reps=5):
         """Pick the fastest conv tile variant per layer by measurement (st_detector_autotune)."""
         device = torch.device(device) if device is not None else torch.device('cuda', torch.cuda.current_device())
         ws = self._workspace(device)

@@ -87,6 +87,33 @@ class TrackDataPreprocessor_Disparity_V1(nn.Module):
         return dict(inputs=out, data_samples=samples)
 
 
+def pack_raw_inputs(img_u8=None, disp_u16=None, pad_size_divisor=32, img_pad=114.0):
+    """Device-side input pipeline for frames uploaded raw: uint8 (N,3,h,w) image and/or
+    uint16 (N,h,w) disparity PNG codes, both CUDA tensors -> dict(img, disp_postp, disp_mask) fp32 padded to
+    `pad_size_divisor`, exactly what LoadDisparityFromFile + Pad_Disparity + the preprocessor produce."""
+    src = img_u8 if img_u8 is not None else disp_u16
+    if src is None or not src.is_cuda:
+        raise RuntimeError('pack_raw_inputs needs CUDA tensors (HIP path only)')
+    N, h, w = src.shape[0], src.shape[-2], src.shape[-1]
+    d = pad_size_divisor
+    H, W = (h + d - 1) // d * d, (w + d - 1) // d * d
+    dev = src.device
+    out = {}
+    if img_u8 is not None:
+        assert img_u8.dtype == torch.uint8 and tuple(img_u8.shape) == (N, 3, h, w)
+        img_u8 = img_u8.contiguous()
+        out['img'] = torch.empty(N, 3, H, W, dtype=torch.float32, device=dev)
+    if disp_u16 is not None:
+        assert disp_u16.dtype in (torch.uint16, torch.int16) and tuple(disp_u16.shape) == (N, h, w)
+        disp_u16 = disp_u16.contiguous()
+        out['disp_postp'] = torch.empty(N, 3, H, W, dtype=torch.float32, device=dev)
+        out['disp_mask'] = torch.empty(N, 1, H, W, dtype=torch.float32, device=dev)
+    check(_lib.load().st_pack_raw_inputs(ptr(img_u8), ptr(disp_u16), N, h, w, H, W, float(img_pad), ptr(out.get('img')),
+                                         ptr(out.get('disp_postp')), ptr(out.get('disp_mask')), current_stream()),
+          'st_pack_raw_inputs')
+    return out
+
+
 def scale_bbox(bboxes, scales):
     """Scale boxes about their centres (reference mmtrack/models/trackers/utils.py:58-73)."""
     cx, cy = (bboxes[:, 0] + bboxes[:, 2]) / 2, (bboxes[:, 1] + bboxes[:, 3]) / 2

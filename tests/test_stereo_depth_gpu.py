@@ -171,3 +171,33 @@ def test_box_depth_large_box_and_w_gt_800(cuda):
         assert abs(depth[0, i] - float(ref_d[i])) <= 1e-3 * max(1.0, abs(float(ref_d[i])))
     assert np.abs(scale[0] - ref_s.numpy()).max() <= 1e-3
     assert np.abs(sb[0] - ref_sb.numpy()).max() <= 1e-3 * 1280
+
+
+def test_pack_raw_inputs_matches_reference_pipeline(cuda):
+    """uint8 image + uint16 disparity codes -> the tensors LoadDisparityFromFile._post_processing_v2
+    (loading_disparity.py:82-86,129-134), Pad_Disparity (transforms_disparity.py:234-249) and the
+    preprocessor (data_preprocessor_disparity_v1.py:38-51) produce; bit-exact."""
+    from stereotracking_amd.mot import pack_raw_inputs
+    rng = np.random.RandomState(5)
+    N, h, w = 2, 50, 70
+    img = rng.randint(0, 256, (N, 3, h, w)).astype(np.uint8)
+    code = rng.randint(0, 48 * 16, (N, h, w)).astype(np.uint16)
+    code[rng.uniform(size=code.shape) < 0.1] = 65535
+    out = pack_raw_inputs(torch.from_numpy(img).to(cuda), torch.from_numpy(code.view(np.int16)).to(cuda))
+    torch.cuda.synchronize()
+    H, W = 64, 96
+    # numpy restatement of the reference transforms
+    disp = code.astype(np.float32)
+    disp[code == 65535] = 0
+    disp = disp / 16.
+    ref_img = np.full((N, 3, H, W), 0, np.float32)
+    ref_img[:, :, :h, :w] = img
+    ref_img[:, :, h:, :] = 114.0
+    ref_img[:, :, :, w:] = 114.0
+    ref_disp = np.zeros((N, 3, H, W), np.float32)
+    ref_disp[:, :, :h, :w] = disp[:, None]
+    ref_mask = np.zeros((N, 1, H, W), np.float32)
+    ref_mask[:, 0, :h, :w] = code < 65535
+    assert np.array_equal(out['img'].cpu().numpy(), ref_img)
+    assert np.array_equal(out['disp_postp'].cpu().numpy(), ref_disp)
+    assert np.array_equal(out['disp_mask'].cpu().numpy(), ref_mask)
