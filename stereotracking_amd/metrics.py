@@ -1,0 +1,162 @@
+"""MOTChallenge writer + CLEAR-MOT / Identity metrics for the AirDrone evaluation.
+
+Behavioural spec: reference mmtrack/evaluation/metrics/mot_drone_metrics.py
+  process()                 :155-221  per-frame rows, depth-range filters
+                                      (pred kept iff depth_thr >= depth > 0, gt iff location[-1] <= depth_thr)
+  _save_one_video_gts_preds :223-253  MOTChallenge txt formats
+The reference delegates the scores to TrackEval (un-vendored, absent here): CLEAR (MOTA, MOTP, IDSW) and
+Identity (IDF1, IDP, IDR) are restated from their published definitions (Bernardin & Stiefelhagen 2008;
+Ristani et al. 2016) the way TrackEval computes them: per-frame Hungarian matching on IoU >= 0.5 with
+priority for the previous frame's match; one global bipartite matching for the identity scores.
+"""
+import os
+from collections import defaultdict
+
+import numpy as np
+from scipy.optimize import linear_sum_assignment
+
+
+def box_iou_xywh(a, b):
+    """IoU of (n,4) and (m,4) boxes in MOTChallenge x,y,w,h form."""
+    if len(a) == 0 or len(b) == 0:
+        return np.zeros((len(a), len(b)))
+    ax2, ay2 = a[:, 0] + a[:, 2], a[:, 1] + a[:, 3]
+    bx2, by2 = b[:, 0] + b[:, 2], b[:, 1] + b[:, 3]
+    iw = np.clip(np.minimum(ax2[:, None], bx2[None]) - np.maximum(a[:, None, 0], b[None, :, 0]), 0, None)
+    ih = np.clip(np.minimum(ay2[:, None], by2[None]) - np.maximum(a[:, None, 1], b[None, :, 1]), 0, None)
+    inter = iw * ih
+    union = (a[:, 2] * a[:, 3])[:, None] + (b[:, 2] * b[:, 3])[None] - inter
+    return np.where(union > 0, inter / np.maximum(union, 1e-12), 0.0)
+
+
+def clear_identity(gt_rows, pred_rows, iou_thr=0.5):
+    """gt_rows / pred_rows: arrays of (frame, id, x, y, w, h, ...).  Returns a dict with the CLEAR counts
+    (TP, FN, FP, IDSW, MOTA, MOTP) and Identity scores (IDTP, IDFN, IDFP, IDF1, IDP, IDR)."""
+    gt_rows = np.asarray(gt_rows, dtype=np.float64)
+    pred_rows = np.asarray(pred_rows, dtype=np.float64)
+    if gt_rows.size == 0:
+        gt_rows = np.zeros((0, 6))
+    if pred_rows.size == 0:
+        pred_rows = np.zeros((0, 6))
+    gt_ids = {v: i for i, v in enumerate(sorted(set(gt_rows[:, 1].astype(int).tolist())))}
+    tr_ids = {v: i for i, v in enumerate(sorted(set(pred_rows[:, 1].astype(int).tolist())))}
+    frames = sorted(set(gt_rows[:, 0].astype(int).tolist()) | set(pred_rows[:, 0].astype(int).tolist()))
+    ng, nt = len(gt_ids), len(tr_ids)
+    tp = fn = fp = idsw = 0
+    motp_sum = 0.0
+    prev_tracker = np.full(ng, np.nan)       # last tracker id matched to each gt (ever)
+    prev_step_tracker = np.full(ng, np.nan)  # tracker id matched in the previous frame
+    potential = np.zeros((ng, nt))
+    gt_count, tr_count = np.zeros(ng), np.zeros(nt)
+    eps = np.finfo(float).eps
+    for f in frames:
+        g = gt_rows[gt_rows[:, 0].astype(int) == f]
+        p = pred_rows[pred_rows[:, 0].astype(int) == f]
+        gi = np.array([gt_ids[int(v)] for v in g[:, 1]], dtype=int)
+        ti = np.array([tr_ids[int(v)] for v in p[:, 1]], dtype=int)
+        gt_count[gi] += 1
+        tr_count[ti] += 1
+        if len(g) == 0:
+            fp += len(p)
+            continue
+        if len(p) == 0:
+            fn += len(g)
+            prev_step_tracker[:] = np.nan
+            continue
+        sim = box_iou_xywh(g[:, 2:6], p[:, 2:6])
+        rr, cc = np.nonzero(sim >= iou_thr - eps)
+        potential[gi[rr], ti[cc]] += 1
+        score = (ti[None, :] == prev_step_tracker[gi][:, None]) * 1000.0 + sim
+        score[sim < iou_thr - eps] = 0
+        rows, cols = linear_sum_assignment(-score)
+        ok = score[rows, cols] > eps
+        rows, cols = rows[ok], cols[ok]
+        mg, mt = gi[rows], ti[cols]
+        prev = prev_tracker[mg]
+        idsw += int(np.sum(~np.isnan(prev) & (prev != mt)))
+        prev_tracker[mg] = mt
+        prev_step_tracker[:] = np.nan
+        prev_step_tracker[mg] = mt
+        tp += len(rows)
+        fn += len(g) - len(rows)
+        fp += len(p) - len(rows)
+        motp_sum += float(sim[rows, cols].sum())
+    # identity: one global assignment minimising IDFN + IDFP
+    fn_mat = np.zeros((ng + nt, ng + nt))
+    fp_mat = np.zeros((ng + nt, ng + nt))
+    fp_mat[ng:, :nt] = 1e10
+    fn_mat[:ng, nt:] = 1e10
+    for i in range(ng):
+        fn_mat[i, :nt] = gt_count[i]
+        fn_mat[i, nt + i] = gt_count[i]
+    for j in range(nt):
+        fp_mat[:ng, j] = tr_count[j]
+        fp_mat[j + ng, j] = tr_count[j]
+    fn_mat[:ng, :nt] -= potential
+    fp_mat[:ng, :nt] -= potential
+    r, c = linear_sum_assignment(fn_mat + fp_mat)
+    idfn, idfp = float(fn_mat[r, c].sum()), float(fp_mat[r, c].sum())
+    idtp = float(gt_count.sum() - idfn)
+    return dict(TP=tp, FN=fn, FP=fp, IDSW=idsw,
+                MOTA=(tp - fp - idsw) / max(1.0, tp + fn), MOTP=motp_sum / max(1.0, tp),
+                IDTP=idtp, IDFN=idfn, IDFP=idfp,
+                IDF1=idtp / max(1.0, idtp + 0.5 * idfp + 0.5 * idfn),
+                IDP=idtp / max(1.0, idtp + idfp), IDR=idtp / max(1.0, idtp + idfn))
+
+
+class MOTDroneMetrics:
+    """Collects per-frame tracks, writes MOTChallenge files, scores them (depth-range filtered)."""
+
+    def __init__(self, depth_thr=80, ignore_depth=False, iou_thr=0.5):
+        self.depth_thr, self.ignore_depth, self.iou_thr = depth_thr, ignore_depth, iou_thr
+        self.pred = defaultdict(list)
+        self.gt = defaultdict(list)
+
+    def process(self, video, data_sample, gt_instances=None):
+        """data_sample: TrackDataSample with pred_track_instances (+ metainfo frame_id);
+        gt_instances: list of dicts with instance_id, bbox (xyxy), mot_conf, category_id, visibility, location."""
+        frame_id = data_sample.metainfo['frame_id']
+        if gt_instances is not None:
+            for ins in gt_instances:
+                if self.ignore_depth or ins['location'][-1] <= self.depth_thr:
+                    x1, y1, x2, y2 = ins['bbox']
+                    self.gt[video].append([frame_id + 1, ins['instance_id'], x1, y1, x2 - x1, y2 - y1,
+                                           ins.get('mot_conf', 1), ins.get('category_id', 1),
+                                           ins.get('visibility', 1.0)])
+        trk = data_sample.pred_track_instances
+        ids = trk['instances_id'].cpu().numpy()
+        boxes = trk['bboxes'].cpu().numpy()
+        scores = trk['scores'].cpu().numpy()
+        depth = trk['depth'].cpu().numpy() if 'depth' in trk else np.ones(len(ids))
+        for i in range(len(ids)):
+            if self.ignore_depth or self.depth_thr >= depth[i] > 0:
+                b = boxes[i]
+                self.pred[video].append([frame_id + 1, int(ids[i]), b[0], b[1], b[2] - b[0], b[3] - b[1], scores[i]])
+
+    def write_motchallenge(self, out_dir):
+        """pred: frame,id,x,y,w,h,score,-1,-1,-1   gt: frame,id,x,y,w,h,conf,class,visibility (reference :223-253)."""
+        os.makedirs(os.path.join(out_dir, 'pred'), exist_ok=True)
+        os.makedirs(os.path.join(out_dir, 'gt'), exist_ok=True)
+        for video, rows in self.pred.items():
+            with open(os.path.join(out_dir, 'pred', video + '.txt'), 'wt') as f:
+                for t in rows:
+                    f.write('%d,%d,%.3f,%.3f,%.3f,%.3f,%.3f,-1,-1,-1\n' % tuple(t[:7]))
+        for video, rows in self.gt.items():
+            with open(os.path.join(out_dir, 'gt', video + '.txt'), 'wt') as f:
+                for t in rows:
+                    f.write('%d,%d,%d,%d,%d,%d,%d,%d,%.5f\n' % tuple(t[:9]))
+
+    def evaluate(self):
+        """Per-video and combined (count-summed, like TrackEval's COMBINED_SEQ) scores."""
+        per_video = {v: clear_identity(self.gt.get(v, []), self.pred.get(v, []), self.iou_thr)
+                     for v in sorted(set(self.gt) | set(self.pred))}
+        tot = defaultdict(float)
+        for r in per_video.values():
+            for k in ('TP', 'FN', 'FP', 'IDSW', 'IDTP', 'IDFN', 'IDFP'):
+                tot[k] += r[k]
+            tot['motp_sum'] += r['MOTP'] * r['TP']
+        combined = dict(tot)
+        combined['MOTA'] = (tot['TP'] - tot['FP'] - tot['IDSW']) / max(1.0, tot['TP'] + tot['FN'])
+        combined['MOTP'] = tot['motp_sum'] / max(1.0, tot['TP'])
+        combined['IDF1'] = tot['IDTP'] / max(1.0, tot['IDTP'] + 0.5 * tot['IDFP'] + 0.5 * tot['IDFN'])
+        return dict(per_video=per_video, combined=combined)
