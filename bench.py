@@ -92,9 +92,20 @@ def conv_roofline(pipe, img, right, steps):
     conv_ms = float(tot_ms[kind == 1].sum() / steps)
     conv_fl = 2.0 * float(macs[kind == 1].sum())
     d = per_variant[dom]
-    roof = dict(bound='mfma', kernel=f'conv_igemm_kernel<{dom}>',
+    # HBM bytes per launch of that kernel instance from the committed rocprofv3 PMC passes (FETCH_SIZE x2
+    # gfx950 correction + WRITE_SIZE, separate passes; tools/pmc_summary.py), if the profile has the row
+    dom_id = next(v for v, n in VARIANT_TILES.items() if n == dom)
+    kname = 'st::conv_igemm_kernel<%s>' % lib.st_conv_variant_signature(dom_id).decode()
+    traffic, traffic_src = None, None
+    tpath = os.path.join(ROOT, 'profiles', 'r01_hbm_traffic.json')
+    if os.path.exists(tpath):
+        row = json.load(open(tpath)).get(kname)
+        if row and row.get('fetch_bytes_corrected_per_launch') is not None:
+            traffic = int(row['fetch_bytes_corrected_per_launch'] + (row.get('write_bytes_per_launch') or 0))
+            traffic_src = 'profiles/r01_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)'
+    roof = dict(bound='mfma', kernel=f'conv_igemm_kernel<{dom}>', kernel_symbol=kname,
                 achieved=d['tflops'], peak=PEAK_FP32_MFMA_TFLOPS, unit='TFLOP/s',
-                frac=round(d['tflops'] / PEAK_FP32_MFMA_TFLOPS, 4), traffic=None,
+                frac=round(d['tflops'] / PEAK_FP32_MFMA_TFLOPS, 4), traffic=traffic, traffic_source=traffic_src,
                 flop_per_launch=round(d['gflop_per_step'] * 1e9 / d['launches']),
                 avg_launch_us=round(d['ms_per_step'] * 1e3 / d['launches'], 2),
                 launches_per_step=d['launches'],
@@ -167,13 +178,21 @@ def main():
         raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}')
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a GPU (the HIP path is the only product path)')
-    torch.cuda.set_device(local_rank)
-    dev = torch.device('cuda', local_rank)
+    # one rank per GPU; ST_BENCH_BACKEND=gloo is a single-GPU REHEARSAL of the multi-rank code path (ranks share
+    # cuda:0, the detection buffers are gathered through host memory) - never used for reported numbers
+    backend = os.environ.get('ST_BENCH_BACKEND', 'nccl')
+    dev_index = local_rank if backend == 'nccl' else local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev_index)
+    dev = torch.device('cuda', dev_index)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+        if backend == 'nccl':
+            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+    cdev = dev if backend == 'nccl' else torch.device('cpu')  # where collectives run
 
     from stereotracking_amd.pipeline import StereoDensePipeline
     from stereotracking_amd.synthetic import synthetic_batch, synthetic_state_dict
@@ -185,13 +204,13 @@ def main():
     # every rank gets its own 8 pairs (weak scaling: frames shard across ranks)
     batch_cpu = synthetic_batch([rank * B + i for i in range(B)], 720, 1280, args.max_disp)
     img, right = batch_cpu['img'].to(dev), batch_cpu['right'].to(dev)
-    gathered = torch.empty(world * B, pipe.max_det, 8, device=dev) if world > 1 else None
+    gathered = torch.empty(world * B, pipe.max_det, 8, device=cdev) if world > 1 else None
 
     def step():
         out = pipe.run(img, right)
         dets = pipe.pack_detections(out)
-        if world > 1:
-            dist.all_gather_into_tensor(gathered, dets)
+        if world > 1:  # ONE collective per shard of frames: the fixed-size detection buffers (76.8 KB / rank)
+            dist.all_gather_into_tensor(gathered, dets if backend == 'nccl' else dets.cpu())
         return out
 
     for _ in range(args.warmup):
@@ -209,7 +228,7 @@ def main():
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        t = torch.tensor([dt], device=cdev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
@@ -222,7 +241,8 @@ def main():
         'config': {'workload': f'configs[1]: batch={B} synthetic 1280x720 stereo pairs per GPU, D={args.max_disp}, '
                                'full YOLOX-s two-branch backbone+PAFPN+head, cost volume at 1/4 res '
                                f'({args.max_disp // 4} levels) + soft-argmin, decode+NMS, per-box depth',
-                   'global_batch': world * B, 'parallelism': f'frames sharded x{world}, all-gather of detections',
+                   'global_batch': world * B,
+                   'parallelism': f'frames sharded x{world}, one all-gather of detections per step ({backend})',
                    'detections_kept_rank0': counts},
     }
     if rank == 0:

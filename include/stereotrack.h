@@ -185,6 +185,7 @@ int st_detector_op_desc(const StDetector* det, int i, char* buf, int cap);
 int st_detector_autotune(StDetector* det, void* workspace_dev, size_t workspace_bytes,
                          float* head_out_dev, st_stream_t stream, int reps);
 const char* st_conv_variant_name(int id);
+const char* st_conv_variant_signature(int id); /* template args of the variant's kernel (profiler row matching) */
 /* Per-op tile choice (one int per op of st_detector_num_ops, -1 = heuristic): read it after an
  * autotune, restore it in another process to skip the measurement. */
 int st_detector_get_tuning(const StDetector* det, int* variants, int cap);

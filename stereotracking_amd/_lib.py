@@ -84,6 +84,7 @@ _PROTOS = {
     'st_detector_op_times': (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp]),
     'st_detector_autotune': (_i, [_vp, _vp, _sz, _vp, _vp, _i]),
     'st_conv_variant_name': (C.c_char_p, [_i]),
+    'st_conv_variant_signature': (C.c_char_p, [_i]),
     'st_detector_get_tuning': (_i, [_vp, _vp, _i]),
     'st_detector_set_tuning': (_i, [_vp, _vp, _i]),
     'st_detector_op_desc': (_i, [_vp, _i, C.c_char_p, _i]),

@@ -446,6 +446,20 @@ const char* conv_variant_name(int id) {
   return id >= 0 && id < kNumVariants ? names[id] : "-";
 }
 
+// template arguments <TM, TN, WM, WN, NBUF, ABL, ILV, DMA> of each variant's kernel instance (so profiler
+// rows "st::conv_igemm_kernel<...>" can be matched to variants)
+const char* conv_variant_signature(int id) {
+  static const char* sigs[] = {"2, 2, 2, 2, 2, 0, 1, 0", "2, 2, 2, 1, 2, 0, 1, 0", "2, 1, 2, 1, 2, 0, 1, 0",
+                               "1, 1, 2, 2, 2, 0, 1, 0", "1, 1, 2, 1, 2, 0, 1, 0", "1, 2, 4, 1, 2, 0, 1, 0",
+                               "1, 1, 4, 1, 2, 0, 1, 0", "1, 2, 2, 2, 2, 0, 1, 0", "2, 2, 4, 1, 2, 0, 1, 0",
+                               "2, 2, 1, 1, 1, 0, 1, 0", "2, 1, 1, 1, 1, 0, 1, 0", "1, 2, 1, 1, 1, 0, 1, 0",
+                               "2, 2, 2, 2, 2, 0, 1, 1", "1, 1, 2, 2, 2, 0, 1, 1", "1, 2, 2, 2, 2, 0, 1, 1",
+                               "1, 1, 4, 1, 2, 0, 1, 1", "1, 2, 4, 1, 2, 0, 1, 1", "2, 2, 2, 2, 2, 0, 0, 1",
+                               "1, 1, 2, 2, 2, 0, 0, 1", "2, 2, 4, 2, 2, 0, 1, 1", "2, 2, 4, 2, 2, 0, 0, 1",
+                               "2, 2, 4, 2, 2, 0, 1, 0"};
+  return id >= 0 && id < kNumVariants ? sigs[id] : "";
+}
+
 int conv2d_launch(const StConvDesc& d, hipStream_t stream, int force_variant, int* picked_variant) {
   ST_REQUIRE(d.in_dev && d.wgt_dev && d.bias_dev && d.out1_dev, "conv: null pointer");
   ST_REQUIRE(d.Cin % 4 == 0 && d.in_ld % 4 == 0 && d.in_off % 4 == 0,

@@ -34,6 +34,7 @@ int conv2d_launch(const StConvDesc& d, hipStream_t stream, int force_variant, in
 int conv_variant_count();
 bool conv_variant_valid(int id, int cout);
 const char* conv_variant_name(int id);
+const char* conv_variant_signature(int id);
 int focus_pack_launch(const float* img, int N, int C, int H, int W, float* out, hipStream_t stream);
 int spp_pool_launch(const float* x, int x_ld, int x_off, int N, int H, int W, int C, float* out,
                     int out_ld, int out_off, hipStream_t stream);
@@ -734,6 +735,7 @@ extern "C" int st_detector_autotune(StDetector* det, void* workspace_dev, size_t
 }
 
 extern "C" const char* st_conv_variant_name(int id) { return conv_variant_name(id); }
+extern "C" const char* st_conv_variant_signature(int id) { return conv_variant_signature(id); }
 
 // Read / restore the per-op tile choice (one int per op, -1 = heuristic) so a tuning result can be
 // cached across processes (e.g. to keep autotune launches out of a rocprofv3 trace).
