@@ -61,6 +61,91 @@ __device__ __forceinline__ float silu_f32(float v) {
   return v * __builtin_amdgcn_rcpf(1.0f + __expf(-v));
 }
 
+// Fused epilogue shared by all conv kernels: bias, SiLU, residual / branch average, split and
+// channel-offset stores, nearest x2 upsampled store.
+template <int TM, int TN>
+__device__ __forceinline__ void conv_epilogue(const ConvKArgs& p, f32x16 (&acc)[TM][TN], int m0, int n0, int wm,
+                                              int wn, int l31, int lh, int BM, int BN) {
+  // ---- epilogue: lane holds column j = lane&31, rows (r&3) + 8*(r>>2) + 4*(lane>>5)
+  // All element offsets fit 32 bits (checked on the host), bases are wave-uniform: stores/loads use
+  // the SGPR-base + 32-bit VGPR-offset form.  The common case (tile fully inside, no split / upsample)
+  // runs without per-element predicates.
+  const bool full_tile = (m0 + BM <= p.M) && (n0 + BN <= p.Cout);
+  const bool simple = full_tile && !p.up && !p.out2;
+  if (simple) {
+    float* __restrict__ o1 = p.out1 + p.out1_off;
+    const float* __restrict__ rs = p.res ? p.res + p.res_off : nullptr;
+#pragma unroll
+    for (int tj = 0; tj < TN; ++tj) {
+      const unsigned j = n0 + wn * 32 * TN + tj * 32 + l31;
+      const float bj = p.bias[j];
+#pragma unroll
+      for (int ti = 0; ti < TM; ++ti) {
+        const unsigned mb = m0 + wm * 32 * TM + ti * 32 + 4 * lh;
+        float rv[16];
+        if (rs) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            rv[r] = rs[(mb + (r & 3) + 8 * (r >> 2)) * (unsigned)p.res_ld + j];
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          float v = acc[ti][tj][r] + bj;
+          if (p.act) v = silu_f32(v);
+          if (rs) v = (v + rv[r]) * p.post_scale;
+          o1[(mb + (r & 3) + 8 * (r >> 2)) * (unsigned)p.out1_ld + j] = v;
+        }
+      }
+    }
+    return;
+  }
+#pragma unroll
+  for (int tj = 0; tj < TN; ++tj) {
+    const int j = n0 + wn * 32 * TN + tj * 32 + l31;
+    const float bj = p.bias[j];  // bias is padded to the tile grid
+    const bool vj = j < p.Cout;
+#pragma unroll
+    for (int ti = 0; ti < TM; ++ti) {
+      // residual: issue all 16 loads of this 32x32 tile before the first use (one wait, not 16
+      // dependent HBM round trips)
+      float rv[16];
+      if (p.res) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = m0 + wm * 32 * TM + ti * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          rv[r] = (m < p.M && vj) ? p.res[(unsigned)m * (unsigned)p.res_ld + p.res_off + j] : 0.f;
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wm * 32 * TM + ti * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (m < p.M && vj) {
+          float v = acc[ti][tj][r] + bj;
+          if (p.act) v = silu_f32(v);
+          if (p.res) v = (v + rv[r]) * p.post_scale;
+          if (j < p.split)
+            p.out1[(unsigned)m * (unsigned)p.out1_ld + p.out1_off + j] = v;
+          else
+            p.out2[(unsigned)m * (unsigned)p.out2_ld + p.out2_off + (j - p.split)] = v;
+          if (p.up) {
+            const int n = m / p.HoWo;
+            const int rem = m - n * p.HoWo;
+            const int oy = rem / p.Wo;
+            const int ox = rem - oy * p.Wo;
+            const unsigned W2 = 2u * p.Wo;
+            const unsigned base = ((unsigned)n * 2u * p.Ho + 2u * oy) * W2 + 2u * ox;
+            float* u = p.up + p.up_off + j;
+            u[base * (unsigned)p.up_ld] = v;
+            u[(base + 1) * (unsigned)p.up_ld] = v;
+            u[(base + W2) * (unsigned)p.up_ld] = v;
+            u[(base + W2 + 1) * (unsigned)p.up_ld] = v;
+          }
+        }
+      }
+    }
+  }
+}
+
 // NBUF = 2: LDS double buffer, one barrier per K-chunk (multi-wave blocks).
 // NBUF = 1: single-wave blocks (WM = WN = 1) only - the wave's own in-order LDS queue orders the
 //           write of chunk k+1 behind the reads of chunk k, so there is no cross-wave barrier at all and
@@ -320,84 +405,179 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(ConvKArgs p) {
     if (ABL < 2) __syncthreads();
   }
 
-  // ---- epilogue: lane holds column j = lane&31, rows (r&3) + 8*(r>>2) + 4*(lane>>5)
-  // All element offsets fit 32 bits (checked on the host), bases are wave-uniform: stores/loads use
-  // the SGPR-base + 32-bit VGPR-offset form.  The common case (tile fully inside, no split / upsample)
-  // runs without per-element predicates.
-  const bool full_tile = (m0 + BM <= p.M) && (n0 + BN <= p.Cout);
-  const bool simple = full_tile && !p.up && !p.out2;
-  if (simple) {
-    float* __restrict__ o1 = p.out1 + p.out1_off;
-    const float* __restrict__ rs = p.res ? p.res + p.res_off : nullptr;
+  conv_epilogue<TM, TN>(p, acc, m0, n0, wm, wn, l31, lh, BM, BN);
+}
+
+// ---- wave-specialised variant ---------------------------------------------------------------------------
+// WM*WN MFMA waves + ONE loader wave per block.  The ablations (tools/conv_ablation.py) show that what the
+// staged kernel loses against its no-load build is the ISSUE cost of the staging instructions inside the
+// MFMA waves' in-order streams, not memory latency or bandwidth.  Here the MFMA waves run nothing but
+// ds_read_b128 + v_mfma (+ one barrier per K-chunk); the loader wave computes all im2col addresses and
+// issues every `buffer_load_dwordx4 ... lds` (LDS-DMA, source-side XOR swizzle as in DMA = 1) for the next
+// chunk, waits for them (vmcnt(0)) and joins the same barrier.
+template <int TM, int TN, int WM, int WN, int NL>
+__global__ __launch_bounds__(64 * (WM * WN + NL)) void conv_igemm_ws_kernel(ConvKArgs p) {
+  constexpr int NW = WM * WN;  // MFMA waves (+ NL loader waves: loader l issues the DMA instructions j = l mod NL)
+  constexpr int BM = 32 * TM * WM;
+  constexpr int BN = 32 * TN * WN;
+  constexpr int LDK = 32;
+  constexpr int AI = BM / 8, BI = BN / 8;  // DMA wave-instructions per chunk (8 rows x 128 B each)
+
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* As = smem;                 // [2][BM][32]
+  float* Bs = smem + 2 * BM * LDK;  // [2][BN][32]
+
+  const int nblk = gridDim.x, bid = blockIdx.x;
+  const int q8 = nblk >> 3, r8 = nblk & 7, xcd = bid & 7, slot = bid >> 3;
+  const int logical = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + slot;
+  const int mt = logical / p.n_tiles;
+  const int nt = logical - mt * p.n_tiles;
+  const int m0 = mt * BM, n0 = nt * BN;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int nchunks = p.Kpad / BK;
+
+  if (wave >= NW) {
+    // =============================== loader waves ===============================
+    const int lw = wave - NW;
+    const int a8 = lane >> 3, q = lane & 7;
+    const __amdgpu_buffer_rsrc_t rsrcA =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in), 0, p.in_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrcB =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.wgt), 0, p.wgt_bytes, 0x00020000);
+    int rowoff[AI];
+    unsigned vmask[AI];
 #pragma unroll
-    for (int tj = 0; tj < TN; ++tj) {
-      const unsigned j = n0 + wn * 32 * TN + tj * 32 + l31;
-      const float bj = p.bias[j];
+    for (int j = 0; j < AI; ++j) {
+      const int m = m0 + 8 * j + a8;
+      const bool vm = m < p.M;
+      const int mm = vm ? m : 0;
+      const int n = mm / p.HoWo;
+      const int rem = mm - n * p.HoWo;
+      const int oy = rem / p.Wo;
+      const int ox = rem - oy * p.Wo;
+      const int iy0 = oy * p.stride - p.pad, ix0 = ox * p.stride - p.pad;
+      rowoff[j] = (((n * p.Hi + iy0) * p.Wi + ix0) * p.in_ld + p.in_off) * 4;
+      unsigned msk = 0;
+      for (int kh = 0; kh < p.KH; ++kh)
+        for (int kw = 0; kw < p.KW; ++kw)
+          if (vm && (unsigned)(iy0 + kh) < (unsigned)p.Hi && (unsigned)(ix0 + kw) < (unsigned)p.Wi)
+            msk |= 1u << (kh * p.KW + kw);
+      vmask[j] = msk;
+    }
+    // swizzle: row r = 8j + a8 stores k-group g in slot g ^ ((r >> 1) & 7) = g ^ ((4j + (a8 >> 1)) & 7): the lane
+    // fetches k-group kq[j & 1]; two running (tap, c, offset) states, one per parity of j
+    int st_c[2], st_kh[2], st_kw[2], st_k[2], st_tap[2], st_off[2];
+    unsigned woff[2];
 #pragma unroll
-      for (int ti = 0; ti < TM; ++ti) {
-        const unsigned mb = m0 + wm * 32 * TM + ti * 32 + 4 * lh;
-        float rv[16];
-        if (rs) {
-#pragma unroll
-          for (int r = 0; r < 16; ++r)
-            rv[r] = rs[(mb + (r & 3) + 8 * (r >> 2)) * (unsigned)p.res_ld + j];
-        }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          float v = acc[ti][tj][r] + bj;
-          if (p.act) v = silu_f32(v);
-          if (rs) v = (v + rv[r]) * p.post_scale;
-          o1[(mb + (r & 3) + 8 * (r >> 2)) * (unsigned)p.out1_ld + j] = v;
-        }
+    for (int e = 0; e < 2; ++e) {
+      const int kq = q ^ ((4 * e + (a8 >> 1)) & 7);
+      st_c[e] = kq * 4; st_kh[e] = 0; st_kw[e] = 0; st_k[e] = kq * 4;
+      while (st_c[e] >= p.Cin) {
+        st_c[e] -= p.Cin;
+        if (++st_kw[e] == p.KW) { st_kw[e] = 0; ++st_kh[e]; }
       }
+      st_tap[e] = st_kh[e] * p.KW + st_kw[e];
+      st_off[e] = ((st_kh[e] * p.Wi + st_kw[e]) * p.in_ld + st_c[e]) * 4;
+      woff[e] = ((unsigned)(n0 + a8) * (unsigned)p.Kpad + kq * 4) * 4u;  // + 8 j rows, added per instruction
+    }
+    auto dma_chunk = [&](int kc, int buf) {
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+      for (int j = 0; j < AI; ++j) {
+        if (j % NL != lw) continue;  // wave-uniform
+        const int e = j & 1;
+        const bool v = (st_k[e] < p.K) && ((vmask[j] >> st_tap[e]) & 1u);
+        const unsigned off = v ? (unsigned)(rowoff[j] + st_off[e]) : 0x80000000u;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(
+            rsrcA, (__attribute__((address_space(3))) void*)(As + buf * BM * LDK + 8 * j * LDK), 16, off, 0, 0, 0);
+      }
+#pragma unroll
+      for (int j = 0; j < BI; ++j) {
+        if (j % NL != lw) continue;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(
+            rsrcB, (__attribute__((address_space(3))) void*)(Bs + buf * BN * LDK + 8 * j * LDK), 16,
+            woff[j & 1] + (unsigned)(8 * j) * (unsigned)p.Kpad * 4u, kc * (BK * 4), 0, 0);
+      }
+#else
+      (void)kc; (void)buf;
+#endif
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        st_k[e] += BK;
+        st_c[e] += BK;
+        while (st_c[e] >= p.Cin) {
+          st_c[e] -= p.Cin;
+          if (++st_kw[e] == p.KW) { st_kw[e] = 0; ++st_kh[e]; }
+        }
+        st_tap[e] = st_kh[e] * p.KW + st_kw[e];
+        st_off[e] = ((st_kh[e] * p.Wi + st_kw[e]) * p.in_ld + st_c[e]) * 4;
+      }
+    };
+    dma_chunk(0, 0);
+    __syncthreads();  // vmcnt(0) + barrier: chunk 0 landed
+    for (int kc = 0; kc < nchunks; ++kc) {
+      if (kc + 1 < nchunks) dma_chunk(kc + 1, (kc + 1) & 1);
+      __syncthreads();  // my DMAs landed (vmcnt(0)) and the MFMA waves are done with chunk kc
     }
     return;
   }
+
+  // =============================== MFMA waves ===============================
+  const int wm = wave / WN, wn = wave - wm * WN;
+  const int l31 = lane & 31, lh = lane >> 5;
+  f32x16 acc[TM][TN];
 #pragma unroll
-  for (int tj = 0; tj < TN; ++tj) {
-    const int j = n0 + wn * 32 * TN + tj * 32 + l31;
-    const float bj = p.bias[j];  // bias is padded to the tile grid
-    const bool vj = j < p.Cout;
+  for (int i = 0; i < TM; ++i)
 #pragma unroll
-    for (int ti = 0; ti < TM; ++ti) {
-      // residual: issue all 16 loads of this 32x32 tile before the first use (one wait, not 16
-      // dependent HBM round trips)
-      float rv[16];
-      if (p.res) {
+    for (int j = 0; j < TN; ++j)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int m = m0 + wm * 32 * TM + ti * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-          rv[r] = (m < p.M && vj) ? p.res[(unsigned)m * (unsigned)p.res_ld + p.res_off + j] : 0.f;
-        }
-      }
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  const int sw = (l31 >> 1) & 7;
+  __syncthreads();  // chunk 0 landed
+  for (int kc = 0; kc < nchunks; ++kc) {
+    const int buf = kc & 1;
+    const float* Ab = As + buf * BM * LDK + (wm * 32 * TM + l31) * LDK;
+    const float* Bb = Bs + buf * BN * LDK + (wn * 32 * TN + l31) * LDK;
+    const int gmax = (p.K - kc * BK + 7) >> 3;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = m0 + wm * 32 * TM + ti * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        if (m < p.M && vj) {
-          float v = acc[ti][tj][r] + bj;
-          if (p.act) v = silu_f32(v);
-          if (p.res) v = (v + rv[r]) * p.post_scale;
-          if (j < p.split)
-            p.out1[(unsigned)m * (unsigned)p.out1_ld + p.out1_off + j] = v;
-          else
-            p.out2[(unsigned)m * (unsigned)p.out2_ld + p.out2_off + (j - p.split)] = v;
-          if (p.up) {
-            const int n = m / p.HoWo;
-            const int rem = m - n * p.HoWo;
-            const int oy = rem / p.Wo;
-            const int ox = rem - oy * p.Wo;
-            const unsigned W2 = 2u * p.Wo;
-            const unsigned base = ((unsigned)n * 2u * p.Ho + 2u * oy) * W2 + 2u * ox;
-            float* u = p.up + p.up_off + j;
-            u[base * (unsigned)p.up_ld] = v;
-            u[(base + 1) * (unsigned)p.up_ld] = v;
-            u[(base + W2) * (unsigned)p.up_ld] = v;
-            u[(base + W2 + 1) * (unsigned)p.up_ld] = v;
-          }
-        }
-      }
+    for (int g = 0; g < 4; ++g) {
+      if (g >= gmax) break;
+      const int koff = ((2 * g + lh) ^ sw) * 4;
+      f32x4 a[TM], b[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const f32x4*>(Ab + i * 32 * LDK + koff);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) b[j] = *reinterpret_cast<const f32x4*>(Bb + j * 32 * LDK + koff);
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][s], b[j][s], acc[i][j], 0, 0, 0);
     }
+    __syncthreads();
   }
+  conv_epilogue<TM, TN>(p, acc, m0, n0, wm, wn, l31, lh, BM, BN);
+}
+
+template <int TM, int TN, int WM, int WN, int NL = 1>
+static int launch_ws(const ConvKArgs& a, int m_tiles, hipStream_t stream) {
+  constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
+  constexpr size_t lds = (size_t)2 * (BM + BN) * 32 * sizeof(float);
+  static bool attr_set = false;
+  auto kern = conv_igemm_ws_kernel<TM, TN, WM, WN, NL>;
+  if (!attr_set) {
+    ST_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_set = true;
+  }
+  dim3 grid((unsigned)(m_tiles * a.n_tiles)), block(64 * (WM * WN + NL));
+  hipLaunchKernelGGL(kern, grid, block, lds, stream, a);
+  ST_CHECK_HIP(hipGetLastError());
+  return ST_OK;
 }
 
 template <int TM, int TN, int WM, int WN, int NBUF = 2, int ABL = 0, int ILV = 1, int DMA = 0>
@@ -425,14 +605,17 @@ static int launch_variant(const ConvKArgs& a, int m_tiles, hipStream_t stream) {
 // 12..16: LDS-DMA staging of 0 / 3 / 7 / 6 / 5 (DMA issue threaded through the MFMA stream);
 // 17, 18: LDS-DMA 128x128 / 64x64 with the DMA burst at the top of the chunk
 // 19..21: 256x128 tiles, 8 waves of 64x64 (LDS-DMA threaded / LDS-DMA burst / register staging)
+// 22..26: wave-specialised (4 MFMA waves + 1 LDS-DMA loader wave): 128x128, 64x64, 64x128, 128x32, 128x64
 struct ConvVariant { int bm, bn, threads; };
 static const ConvVariant kVariants[] = {{128, 128, 256}, {128, 64, 128}, {128, 32, 128}, {64, 64, 256},
                                         {64, 32, 128},   {128, 64, 256}, {128, 32, 256}, {64, 128, 256},
                                         {256, 64, 256},  {64, 64, 64},   {64, 32, 64},   {32, 64, 64},
                                         {128, 128, 256}, {64, 64, 256},  {64, 128, 256}, {128, 32, 256},
                                         {128, 64, 256},  {128, 128, 256}, {64, 64, 256},
-                                        {256, 128, 512}, {256, 128, 512}, {256, 128, 512}};
-constexpr int kNumVariants = 22;
+                                        {256, 128, 512}, {256, 128, 512}, {256, 128, 512},
+                                        {128, 128, 320}, {64, 64, 320},   {64, 128, 320}, {128, 32, 320},
+                                        {128, 64, 320},  {128, 128, 384}, {64, 128, 384}, {128, 128, 512}};
+constexpr int kNumVariants = 30;
 
 int conv_variant_count() { return kNumVariants; }
 bool conv_variant_valid(int id, int cout) {
@@ -442,7 +625,9 @@ const char* conv_variant_name(int id) {
   static const char* names[] = {"128x128", "128x64w2", "128x32w2", "64x64", "64x32w2",
                                 "128x64", "128x32", "64x128", "256x64", "64x64w1", "64x32w1", "32x64w1",
                                 "128x128dma", "64x64dma", "64x128dma", "128x32dma", "128x64dma",
-                                "128x128dmab", "64x64dmab", "256x128dma", "256x128dmab", "256x128"};
+                                "128x128dmab", "64x64dmab", "256x128dma", "256x128dmab", "256x128",
+                                "128x128ws", "64x64ws", "64x128ws", "128x32ws", "128x64ws", "128x128ws2",
+                                "64x128ws2", "128x128ws4"};
   return id >= 0 && id < kNumVariants ? names[id] : "-";
 }
 
@@ -456,7 +641,9 @@ const char* conv_variant_signature(int id) {
                                "2, 2, 2, 2, 2, 0, 1, 1", "1, 1, 2, 2, 2, 0, 1, 1", "1, 2, 2, 2, 2, 0, 1, 1",
                                "1, 1, 4, 1, 2, 0, 1, 1", "1, 2, 4, 1, 2, 0, 1, 1", "2, 2, 2, 2, 2, 0, 0, 1",
                                "1, 1, 2, 2, 2, 0, 0, 1", "2, 2, 4, 2, 2, 0, 1, 1", "2, 2, 4, 2, 2, 0, 0, 1",
-                               "2, 2, 4, 2, 2, 0, 1, 0"};
+                               "2, 2, 4, 2, 2, 0, 1, 0", "ws 2, 2, 2, 2", "ws 1, 1, 2, 2", "ws 1, 2, 2, 2",
+                               "ws 1, 1, 4, 1", "ws 1, 2, 4, 1", "ws 2, 2, 2, 2, 2", "ws 1, 2, 2, 2, 2",
+                               "ws 2, 2, 2, 2, 4"};
   return id >= 0 && id < kNumVariants ? sigs[id] : "";
 }
 
@@ -565,7 +752,15 @@ int conv2d_launch(const StConvDesc& d, hipStream_t stream, int force_variant, in
     case 18: return launch_variant<1, 1, 2, 2, 2, 0, 0, 1>(a, m_tiles, stream);
     case 19: return launch_variant<2, 2, 4, 2, 2, 0, 1, 1>(a, m_tiles, stream);
     case 20: return launch_variant<2, 2, 4, 2, 2, 0, 0, 1>(a, m_tiles, stream);
-    default: return launch_variant<2, 2, 4, 2, 2, 0, 1, 0>(a, m_tiles, stream);
+    case 21: return launch_variant<2, 2, 4, 2, 2, 0, 1, 0>(a, m_tiles, stream);
+    case 22: return launch_ws<2, 2, 2, 2>(a, m_tiles, stream);
+    case 23: return launch_ws<1, 1, 2, 2>(a, m_tiles, stream);
+    case 24: return launch_ws<1, 2, 2, 2>(a, m_tiles, stream);
+    case 25: return launch_ws<1, 1, 4, 1>(a, m_tiles, stream);
+    case 26: return launch_ws<1, 2, 4, 1>(a, m_tiles, stream);
+    case 27: return launch_ws<2, 2, 2, 2, 2>(a, m_tiles, stream);
+    case 28: return launch_ws<1, 2, 2, 2, 2>(a, m_tiles, stream);
+    default: return launch_ws<2, 2, 2, 2, 4>(a, m_tiles, stream);
   }
 }
 

@@ -702,7 +702,9 @@ extern "C" int st_detector_autotune(StDetector* det, void* workspace_dev, size_t
     det->ops[0].phase = 0;
     float best = 1e30f;
     int best_v = -1;
-    for (int v = 0; v < conv_variant_count() && rc == ST_OK; ++v) {
+    // candidates: every staged variant; the wave-specialised ones (>= 22) measured slower on every layer
+    // shape of this network and are left out of the search
+    for (int v = 0; v < std::min(conv_variant_count(), 22) && rc == ST_OK; ++v) {
       if (!conv_variant_valid(v, det->convs[saved[oi].pc].cout)) continue;
       det->force_variant = v;
       rc = run_ops(det, 0, 0, inputs, static_cast<float*>(workspace_dev), head_out_dev, stream);  // warm

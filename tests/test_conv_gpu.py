@@ -118,7 +118,8 @@ def test_conv_matches_torch(case, cuda):
 @pytest.mark.parametrize('variant,cout', [(0, 128), (1, 64), (2, 32), (3, 64), (4, 32), (0, 256), (3, 128), (5, 64),
                                           (6, 32), (7, 128), (8, 64), (5, 192), (6, 96), (9, 64), (10, 32), (11, 64),
                                           (9, 128), (10, 96), (12, 128), (13, 64), (14, 128), (15, 32), (16, 64),
-                                          (17, 256), (18, 192), (19, 128), (20, 256), (21, 128)])
+                                          (17, 256), (18, 192), (19, 128), (20, 256), (21, 128), (22, 128), (23, 64),
+                                          (24, 128), (25, 32), (26, 64), (23, 192)])
 def test_conv_all_tile_variants(variant, cout, cuda):
     torch.manual_seed(variant)
     x = torch.randn(2, 64, 13, 21)
@@ -128,13 +129,13 @@ def test_conv_all_tile_variants(variant, cout, cuda):
     assert_close(got, ref_conv(x, w, b, 1, 1, 1))
 
 
-@pytest.mark.parametrize('variant', [12, 13, 15, 18])
+@pytest.mark.parametrize('variant', [12, 13, 15, 18, 22, 23, 25])
 @pytest.mark.parametrize('case', [(2, 12, 20, 36, 128, 3, 1), (1, 32, 23, 41, 64, 3, 2), (1, 24, 10, 12, 64, 3, 2),
                                   (2, 64, 7, 9, 192, 1, 1)])
 def test_conv_lds_dma_variants_zero_fill_and_ragged(variant, case, cuda):
     """LDS-DMA staging: padding taps, ragged M tiles and the K tail must read as zeros."""
     N, Cin, H, W, Cout, k, stride = case
-    bn = {12: 128, 13: 64, 15: 32, 18: 64}[variant]
+    bn = {12: 128, 13: 64, 15: 32, 18: 64, 22: 128, 23: 64, 25: 32}[variant]
     if ((Cout + 31) // 32 * 32) % bn:
         pytest.skip('tile does not divide Cout')
     torch.manual_seed(variant + sum(case))

@@ -43,7 +43,7 @@ def bench(N, H, W, Cin, Cout, k, stride, variant, reps=20):
 
 
 for shape in [(8, 92, 160, 128, 256, 3, 1), (8, 92, 160, 64, 64, 3, 1), (8, 46, 80, 128, 128, 3, 1), (8, 92, 160, 128, 128, 1, 1)]:
-    for v in (0, 17, 3, 14, 19, 20, 21):
+    for v in (3, 14, 22, 27, 28, 29):
         try:
             ms, tf = bench(*shape, v)
             print(f'shape {shape} variant {v:3d}: {ms * 1e3:8.1f} us  {tf:7.1f} TF/s')
