@@ -35,6 +35,7 @@ def parse():
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--batch', type=int, default=8, help='stereo pairs per GPU per step')
     ap.add_argument('--max-disp', type=int, default=192)
+    ap.add_argument('--agg-layers', type=int, default=2, help='3x3 aggregation convs over the cost volume')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-seconds', type=float, default=15.0, help='budget of the CPU oracle leg')
     return ap.parse_args()
@@ -56,7 +57,10 @@ def conv_roofline(pipe, img, right, steps):
     macs = np.zeros(nops, np.float64)
     phase = np.zeros(nops, np.int32)
     tot_ms = np.zeros(nops, np.float64)
-    other = {'costvolume+upsample': 0.0, 'decode_nms': 0.0, 'box_depth': 0.0}
+    other = {'costvolume+softargmin+upsample': 0.0, 'decode_nms': 0.0, 'box_depth': 0.0}
+    sm = pipe.stereo_module
+    sm.timing = True
+    agg = {}   # variant -> [launches, ms]
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
     for _ in range(steps):
         b = pipe._buffers(img.device)
@@ -75,22 +79,31 @@ def conv_roofline(pipe, img, right, steps):
         check(lib.st_detector_op_times(det.handle, nops, p(ms), p(kind), p(var), p(macs), p(phase)))
         tot_ms += ms
         ph0 = float(ms[phase == 0].sum())
-        other['costvolume+upsample'] += ev[0].elapsed_time(ev[1]) - ph0
+        for v, t in sm.pop_times():   # aggregation convs: the same conv kernel, launched by the stereo module
+            a = agg.setdefault(int(v), [0, 0.0])
+            a[0] += 1
+            a[1] += t
+            ph0 += t
+        other['costvolume+softargmin+upsample'] += ev[0].elapsed_time(ev[1]) - ph0
         other['decode_nms'] += ev[2].elapsed_time(ev[3])
         other['box_depth'] += ev[3].elapsed_time(ev[4])
     check(lib.st_detector_set_timing(det.handle, 0))
+    sm.timing = False
+    Hf, Wf = pipe.height // pipe.feat_stride, pipe.width // pipe.feat_stride
+    agg_macs = sm.agg_macs(pipe.batch, Hf, Wf)   # per aggregation layer
     VARIANT_TILES = {v: lib.st_conv_variant_name(v).decode() for v in range(64)}
     per_variant = {}
-    for v in sorted(set(var[kind == 1].tolist())):
+    for v in sorted(set(var[kind == 1].tolist()) | set(agg)):
         sel = (kind == 1) & (var == v)
-        t = tot_ms[sel].sum() / steps
-        fl = 2.0 * macs[sel].sum()
-        per_variant[VARIANT_TILES[v]] = dict(launches=int(sel.sum()), ms_per_step=round(float(t), 4),
+        n_agg, ms_agg = agg.get(v, [0, 0.0])
+        t = (tot_ms[sel].sum() + ms_agg) / steps
+        fl = 2.0 * (macs[sel].sum() + agg_macs * n_agg / steps)
+        per_variant[VARIANT_TILES[v]] = dict(launches=int(sel.sum()) + n_agg // steps, ms_per_step=round(float(t), 4),
                                              gflop_per_step=round(fl / 1e9, 3),
                                              tflops=round(fl / (t * 1e-3) / 1e12, 3) if t > 0 else 0.0)
     dom = max(per_variant, key=lambda k: per_variant[k]['ms_per_step'])
-    conv_ms = float(tot_ms[kind == 1].sum() / steps)
-    conv_fl = 2.0 * float(macs[kind == 1].sum())
+    conv_ms = float((tot_ms[kind == 1].sum() + sum(a[1] for a in agg.values())) / steps)
+    conv_fl = 2.0 * float(macs[kind == 1].sum() + agg_macs * sum(a[0] for a in agg.values()) / steps)
     d = per_variant[dom]
     # HBM bytes per launch of that kernel instance from the committed rocprofv3 PMC passes (FETCH_SIZE x2
     # gfx950 correction + WRITE_SIZE, separate passes; tools/pmc_summary.py), if the profile has the row
@@ -117,11 +130,11 @@ def conv_roofline(pipe, img, right, steps):
     return roof
 
 
-def cpu_baseline(sd, batch_cpu, max_disp, seconds):
+def cpu_baseline(sd, batch_cpu, max_disp, seconds, agg_layers):
     """The CPU oracle (kind 'port': this repo's restatement of the reference path; the reference itself
     cannot be imported) timed on the host cores over whole stereo pairs."""
     import numpy as np
-    from oracle import c_oracle, depth as odepth
+    from oracle import c_oracle, depth as odepth, stereo as ostereo
     from oracle.torch_model import OracleDetector, head_to_rows
     # a 1-GPU box shares its host: use its CPU share (16), not every core the OS reports
     torch.set_num_threads(min(os.cpu_count() or 1, 16))
@@ -136,9 +149,8 @@ def cpu_baseline(sd, batch_cpu, max_disp, seconds):
         with torch.no_grad():
             fl = ora.backbone.stage1_features(img).permute(0, 2, 3, 1).contiguous().numpy()
             fr = ora.backbone.stage1_features(right).permute(0, 2, 3, 1).contiguous().numpy()
-            cost = c_oracle.costvolume(fl, fr, fl.shape[-1], D)
-            lr = c_oracle.softargmin(cost, 32.0)
-            disp = torch.from_numpy(c_oracle.disp_upsample(lr, 4, ori_h, ori_w))
+            disp = torch.from_numpy(ostereo.disparity(fl, fr, fl.shape[-1], D, 32.0, sd, agg_layers,
+                                                      valid_hw=(ori_h, ori_w))[2])
             rows = head_to_rows(*ora(dict(img=img, disp_postp=disp)))
         levels, off, flat = [], 0, []
         for r, s in zip(rows, (8, 16, 32)):
@@ -165,7 +177,8 @@ def cpu_baseline(sd, batch_cpu, max_disp, seconds):
             break
     dt = time.perf_counter() - t0
     return dict(value=round(n / dt, 4), unit='stereo frame-pairs/s', cores=torch.get_num_threads(), kind='port',
-                sample=f'{n} x 1 synthetic 1280x720 pair (D={max_disp}, full YOLOX-s two-branch), CPU oracle '
+                sample=f'{n} x 1 synthetic 1280x720 pair (D={max_disp}, {agg_layers} aggregation convs, full YOLOX-s '
+                       'two-branch), CPU oracle '
                        f'(PyTorch fp32 + C oracle), {dt:.1f} s', host_cpus=os.cpu_count())
 
 
@@ -198,7 +211,8 @@ def main():
     from stereotracking_amd.synthetic import synthetic_batch, synthetic_state_dict
 
     B = args.batch
-    pipe = StereoDensePipeline(B, (720, 1280), 0.5, 0.33, 1, stereo=True, max_disp=args.max_disp, max_det=300)
+    pipe = StereoDensePipeline(B, (720, 1280), 0.5, 0.33, 1, stereo=True, max_disp=args.max_disp, max_det=300,
+                               agg_layers=args.agg_layers)
     sd = synthetic_state_dict(pipe.param_table(), seed=0)
     pipe.load_state_dict(sd, tuning_cache=os.environ.get('ST_TUNE_CACHE'))
     # every rank gets its own 8 pairs (weak scaling: frames shard across ranks)
@@ -240,17 +254,20 @@ def main():
         'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
         'config': {'workload': f'configs[1]: batch={B} synthetic 1280x720 stereo pairs per GPU, D={args.max_disp}, '
                                'full YOLOX-s two-branch backbone+PAFPN+head, cost volume at 1/4 res '
-                               f'({args.max_disp // 4} levels) + soft-argmin, decode+NMS, per-box depth',
+                               f'({args.max_disp // 4} levels) + {args.agg_layers} 3x3 aggregation convs + soft-argmin, '
+                               'decode+NMS, per-box depth',
                    'global_batch': world * B,
                    'parallelism': f'frames sharded x{world}, one all-gather of detections per step ({backend})',
                    'detections_kept_rank0': counts},
     }
     if rank == 0:
         roof = conv_roofline(pipe, img, right, max(3, min(args.steps, 10)))
-        roof['gflop_per_pair_conv'] = round(2.0 * pipe.det.macs / B / 1e9, 3)
+        Hf, Wf = pipe.height // pipe.feat_stride, pipe.width // pipe.feat_stride
+        roof['gflop_per_pair_conv'] = round(
+            2.0 * (pipe.det.macs + pipe.agg_layers * pipe.stereo_module.agg_macs(B, Hf, Wf)) / B / 1e9, 3)
         line['roofline'] = roof
         if world == 1 and not args.no_cpu_baseline:
-            line['cpu_baseline'] = cpu_baseline(sd, batch_cpu, args.max_disp, args.cpu_seconds)
+            line['cpu_baseline'] = cpu_baseline(sd, batch_cpu, args.max_disp, args.cpu_seconds, args.agg_layers)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

@@ -9,4 +9,4 @@ model = dict(
         max_disp=192,        # full-resolution disparity range
         feat_stride=4,       # correlate stage1 features: D' = 48 levels at 184x320
         temperature=32.0,    # soft-argmin sharpness
-        agg_layers=0))
+        agg_layers=2))       # 3x3 aggregation convs over the D' x H/4 x W/4 volume (d as channels)

@@ -1,0 +1,41 @@
+"""TEST INFRASTRUCTURE — CPU oracle of the stereo module (cost volume -> 2-D aggregation -> soft-argmin ->
+x4 upsample).  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this.
+
+Parity status: "parity unpinned" — the reference ships NO stereo matcher (its disparity is an offline OpenCV
+SGBM product, reproducibility.md:166-194), so there is no reference output to pin against; the module is
+specified by BASELINE.json's north_star and frozen in stereotracking_amd/stereo.py's docstring.  What IS
+pinned is the consumer contract (disp_postp layout / units / zero padding: reference
+mmtrack/datasets/transforms/loading_disparity.py:85-86,129-134 and transforms_disparity.py:234-249).
+
+Pieces: cost volume, soft-argmin and upsample are the plain-C loops of oracle/st_oracle.c (same fmaf order as
+the kernels, so those stages are compared bit-exactly); the aggregation convs are torch fp32 conv2d on CPU
+(floating-point kernel => torch fp32 reference, tolerance 1e-3 as north_star states).
+"""
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from . import c_oracle
+
+
+def aggregate(cost, sd, agg_layers, prefix='stereo.'):
+    """cost: float32 numpy (N,Hf,Wf,D) -> aggregated volume, same layout.
+    cost <- conv3x3(cost; agg.l.weight, agg.l.bias) over d-as-channels, SiLU after all but the last layer."""
+    if agg_layers == 0:
+        return cost
+    x = torch.from_numpy(np.ascontiguousarray(cost)).permute(0, 3, 1, 2).contiguous()
+    with torch.no_grad():
+        for l in range(agg_layers):
+            x = F.conv2d(x, sd[f'{prefix}agg.{l}.weight'].float(), sd[f'{prefix}agg.{l}.bias'].float(), padding=1)
+            if l < agg_layers - 1:
+                x = F.silu(x)
+    return np.ascontiguousarray(x.permute(0, 2, 3, 1).numpy())
+
+
+def disparity(featL, featR, C_, D, temperature, sd=None, agg_layers=0, scale=4, valid_hw=None, prefix='stereo.'):
+    """featL/featR: float32 numpy (N,Hf,Wf,ld) stage-1 features.
+    Returns (cost, disp_lr, disp_postp[N,3,Hf*scale,Wf*scale]) — zero outside valid_hw."""
+    cost = aggregate(c_oracle.costvolume(featL, featR, C_, D), sd, agg_layers, prefix)
+    lr = c_oracle.softargmin(cost, temperature)
+    vh, vw = valid_hw if valid_hw is not None else (featL.shape[1] * scale, featL.shape[2] * scale)
+    return cost, lr, c_oracle.disp_upsample(lr, scale, vh, vw)

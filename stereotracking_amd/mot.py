@@ -133,7 +133,7 @@ class OCSORT_Disparity(nn.Module):
         self.baseline, self.focal_length = baseline, focal_length
         self.stereo = MODELS.build(stereo) if stereo is not None else None  # StereoCostVolume (new module)
         if self.stereo is not None and self.detector is not None:
-            self.detector.stereo = self.stereo
+            self.detector.__dict__['stereo'] = self.stereo   # plain reference: registered once, under the shell
         self.lib = _lib.load()
 
     # ---- reference plumbing (mot/base.py:68-113) -----------------------------------------------------

@@ -24,7 +24,7 @@ class StereoDensePipeline:
 
     def __init__(self, batch, ori_shape=(720, 1280), widen_factor=0.5, deepen_factor=0.33, num_classes=1,
                  stereo=True, max_disp=192, feat_stride=4, temperature=32.0, score_thr=0.01, iou_thr=0.5,
-                 max_det=300, baseline=0.25, focal_length=640, pad_size_divisor=32):
+                 max_det=300, baseline=0.25, focal_length=640, pad_size_divisor=32, agg_layers=0):
         self.lib = _lib.load()
         self.batch = int(batch)
         self.ori_h, self.ori_w = int(ori_shape[0]), int(ori_shape[1])
@@ -32,7 +32,8 @@ class StereoDensePipeline:
         self.height = (self.ori_h + d - 1) // d * d
         self.width = (self.ori_w + d - 1) // d * d
         self.stereo = bool(stereo)
-        self.stereo_module = StereoCostVolume(max_disp, feat_stride, temperature)
+        self.stereo_module = StereoCostVolume(max_disp, feat_stride, temperature, agg_layers if stereo else 0)
+        self.agg_layers = self.stereo_module.agg_layers
         self.max_disp, self.feat_stride = int(max_disp), int(feat_stride)
         self.D = self.stereo_module.levels
         self.temperature = float(temperature)
@@ -44,7 +45,8 @@ class StereoDensePipeline:
 
     # ---- parameters ------------------------------------------------------------------------------
     def param_table(self):
-        return self.det.param_table()
+        """Detector parameters (reference state_dict names) + `stereo.agg.*` of the stereo module."""
+        return self.det.param_table() + [('stereo.' + n, shp) for n, shp in self.stereo_module.param_table()]
 
     def load_state_dict(self, sd, prefix='', autotune=True, tuning_cache=None):
         """Upload weights; then pick conv tile variants by measurement, or restore them from
@@ -52,21 +54,32 @@ class StereoDensePipeline:
         import json
         import os
         self.det.load_state_dict(sd, prefix)
+        pre = prefix + 'stereo.'
+        self.stereo_module.load_state_dict({k[len(pre):]: v for k, v in sd.items() if k.startswith(pre)})
         if not autotune:
             return
-        key = f'b{self.batch}_{self.height}x{self.width}_s{int(self.stereo)}_ops{self.det.lib.st_detector_num_ops(self.det.handle)}'
+        key = (f'b{self.batch}_{self.height}x{self.width}_s{int(self.stereo)}_a{self.agg_layers}'
+               f'_ops{self.det.lib.st_detector_num_ops(self.det.handle)}')
         cache = {}
         if tuning_cache and os.path.exists(tuning_cache):
             try:
                 cache = json.load(open(tuning_cache))
             except (OSError, ValueError):
                 cache = {}
-        if key in cache:
+        if key in cache and (not self.agg_layers or key + '_agg' in cache):
             self.det.set_tuning(cache[key])
+            if self.agg_layers:
+                self.stereo_module.variant = int(cache[key + '_agg'])
             return
         self.det.autotune()
+        if self.agg_layers:
+            s = self.feat_stride
+            dev = torch.device('cuda', torch.cuda.current_device())
+            self.stereo_module.autotune(dev, self.batch, self.height // s, self.width // s)
         if tuning_cache:
             cache[key] = self.det.get_tuning()
+            if self.agg_layers:
+                cache[key + '_agg'] = self.stereo_module.variant
             os.makedirs(os.path.dirname(os.path.abspath(tuning_cache)), exist_ok=True)
             json.dump(cache, open(tuning_cache, 'w'))
 

@@ -6,47 +6,149 @@ which this module honours: `disp_postp` (N,3,H,W) float32 pixels, 0 = invalid / 
 (loading_disparity.py:85-86,129-134; transforms_disparity.py:234-249), channel 0 feeding
 disp2depth (mmtrack/models/mot/ocsort_disparity.py:115,132-134).
 
-Specification (frozen; the executable spec is oracle/st_oracle.c):
+Specification (frozen; the executable spec is oracle/st_oracle.c + oracle/stereo.py):
   features   F_L, F_R = stem+stage1 of the detector's RGB branch on left / right (C x H/4 x W/4),
              shared weights, computed as one stacked batch of 2N
   cost       cost[d,y,x] = (1/C) sum_c F_L[c,y,x] * F_R[c,y,x-d], d in [0, max_disp/4); 0 where x-d < 0
-  (agg)      optional 2-D aggregation convs over d-as-channels (agg_layers; 0 in this round)
+  aggregate  `agg_layers` 2-D convolutions over d-as-channels: cost <- conv3x3(cost; W_l, b_l), SiLU after
+             every layer but the last (parameters `agg.{l}.weight` (D',D',3,3), `agg.{l}.bias` (D',))
   disparity  d_lr = sum_d d * softmax_d(temperature * cost);  disp = 4 * bilinear_x4(d_lr)
              inside the original image, 0 in the padding
 """
 import ctypes as C
 
 import torch
+from torch import nn
 
 from . import _lib
-from ._lib import check, current_stream, ptr
+from ._lib import StConvDesc, check, current_stream, ptr
 from .registry import MODELS
 
 
 @MODELS.register_module()
-class StereoCostVolume:
+class StereoCostVolume(nn.Module):
+    """Parameter holder + launcher (like the detector modules: no CPU forward).  Parameters are named
+    `agg.{l}.weight` / `agg.{l}.bias`, so under the MOT shell a checkpoint carries `stereo.agg.{l}.*`."""
+
     def __init__(self, max_disp=192, feat_stride=4, temperature=32.0, agg_layers=0):
+        super().__init__()
         if feat_stride != 4:
             raise NotImplementedError('only feat_stride=4 (stage1 features) is wired up')
         if max_disp % feat_stride:
             raise ValueError('max_disp must be a multiple of feat_stride')
-        if agg_layers != 0:
-            raise NotImplementedError('aggregation layers are not built yet (agg_layers=0)')
         self.max_disp, self.feat_stride = int(max_disp), int(feat_stride)
         self.levels = self.max_disp // self.feat_stride
+        if self.levels % 4 and agg_layers:
+            raise ValueError('aggregation needs max_disp / feat_stride to be a multiple of 4')
         self.temperature = float(temperature)
-        self.agg_layers = 0
+        self.agg_layers = int(agg_layers)
+        D = self.levels
+        self.agg = nn.ModuleList(nn.Conv2d(D, D, 3, padding=1) for _ in range(self.agg_layers))
+        with torch.no_grad():   # identity until a checkpoint is loaded: behaves like agg_layers=0
+            for conv in self.agg:
+                conv.weight.zero_()
+                conv.weight[torch.arange(D), torch.arange(D), 1, 1] = 1.0
+                conv.bias.zero_()
+        for p in self.parameters():
+            p.requires_grad_(False)
         self.lib = _lib.load()
+        self._packed = None    # (device, weights version, [(wgt, bias)])
+        self._vol = None
+        self.variant = -1      # conv tile variant of the aggregation layers (-1 = library default, or autotune())
+        self.timing = False    # record events around every aggregation conv (bench.py roofline accounting)
+        self._events = []
 
+    def forward(self, *args, **kwargs):
+        raise RuntimeError('StereoCostVolume has no CPU forward: use compute() with a HipDetector context')
+
+    # ---- parameters (aggregation convs) ---------------------------------------------------------------
+    def param_table(self):
+        return [(n, tuple(p.shape)) for n, p in self.named_parameters()]
+
+    def _pack(self, dev):
+        ver = tuple(p._version for p in self.parameters())
+        if self._packed is not None and self._packed[0] == dev and self._packed[1] == ver:
+            return self._packed[2]
+        D = self.levels
+        packed = []
+        for conv in self.agg:
+            w = conv.weight.detach().to('cpu', torch.float32).contiguous()
+            b = conv.bias.detach().to('cpu', torch.float32).contiguous()
+            nf = self.lib.st_conv_packed_floats(D, D, 3, 3)
+            wp = torch.empty(nf, dtype=torch.float32)
+            bp = torch.empty((D + 31) // 32 * 32, dtype=torch.float32)
+            check(self.lib.st_conv_pack_weights(ptr(w), ptr(b), None, None, None, None, 0.0, D, D, 3, 3, ptr(wp),
+                                                ptr(bp)), 'st_conv_pack_weights')
+            packed.append((wp.to(dev), bp.to(dev)))
+        self._packed = (dev, ver, packed)
+        return packed
+
+    def _agg_desc(self, l, src, dst, wp, bp):
+        N, Hf, Wf, D = src.shape
+        d = StConvDesc()
+        d.in_dev = src.data_ptr(); d.N, d.Hi, d.Wi, d.Cin, d.in_ld, d.in_off = N, Hf, Wf, D, D, 0
+        d.wgt_dev = wp.data_ptr(); d.bias_dev = bp.data_ptr()
+        d.Cout, d.KH, d.KW, d.stride, d.pad = D, 3, 3, 1, 1
+        d.out1_dev = dst.data_ptr(); d.out1_ld, d.out1_off, d.split = D, 0, D
+        d.act = 1 if l < self.agg_layers - 1 else 0
+        return d
+
+    def _volumes(self, dev, N, Hf, Wf):
+        D = self.levels
+        if self._vol is None or self._vol[0].device != dev or self._vol[0].shape != (N, Hf, Wf, D):
+            self._vol = (torch.zeros(N, Hf, Wf, D, dtype=torch.float32, device=dev),
+                         torch.zeros(N, Hf, Wf, D, dtype=torch.float32, device=dev))
+        return self._vol
+
+    def autotune(self, dev, N, Hf, Wf, reps=5, candidates=range(22)):
+        """Pick the aggregation convs' tile variant by measurement (same policy as st_detector_autotune:
+        min over `reps` individually timed launches).  Returns the chosen variant id."""
+        if not self.agg_layers:
+            return -1
+        packed = self._pack(dev)
+        va, vb = self._volumes(dev, N, Hf, Wf)
+        d = self._agg_desc(0, va, vb, *packed[0])
+        stream = current_stream()
+        best, best_ms = -1, float('inf')
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        for v in candidates:
+            if self.lib.st_conv2d_nhwc_variant(C.byref(d), stream, int(v)) != 0:
+                continue   # tile does not divide the padded Cout
+            ms = float('inf')
+            for _ in range(reps):
+                e0.record()
+                self.lib.st_conv2d_nhwc_variant(C.byref(d), stream, int(v))
+                e1.record()
+                e1.synchronize()
+                ms = min(ms, e0.elapsed_time(e1))
+            if ms < best_ms:
+                best, best_ms = int(v), ms
+        self.variant = best
+        return best
+
+    def agg_macs(self, N, Hf, Wf):
+        return float(N) * Hf * Wf * self.levels * self.levels * 9
+
+    def pop_times(self):
+        """[(variant, ms)] of the aggregation convs recorded since the last call (timing=True; syncs)."""
+        out = []
+        for v, e0, e1 in self._events:
+            e1.synchronize()
+            out.append((v, e0.elapsed_time(e1)))
+        self._events = []
+        return out
+
+    # ---- compute ------------------------------------------------------------------------------------------
     def compute(self, engine, img, right, valid_hw, disp_lr=None, disp_postp=None, cost_out=None):
         """engine: a HipDetector built with stereo=True.  img/right: (N,3,H,W) fp32 CUDA.
-        Runs phase 0 (features of left+right) then cost volume + soft-argmin + upsample.
+        Runs phase 0 (features of left+right) then cost volume (+ aggregation) + soft-argmin + upsample.
         Returns disp_postp (N,3,H,W); phase-0 activations stay in the engine workspace for phase 1."""
         if not engine.stereo:
             raise ValueError('StereoCostVolume needs a detector context built with stereo=True')
         N, H, W = engine.batch, engine.height, engine.width
         s = self.feat_stride
         dev = img.device
+        D = self.levels
         engine.forward_phase(0, img=img, right=right)
         feat = engine.tap('stage1_rgb')  # (2N, H/4, W/4, C): [left | right]
         Hf, Wf, Cf, ld = feat.shape[1], feat.shape[2], feat.shape[3], feat.stride(2)
@@ -56,9 +158,32 @@ class StereoCostVolume:
             disp_lr = torch.empty(N, Hf, Wf, dtype=torch.float32, device=dev)
         if disp_postp is None:
             disp_postp = torch.empty(N, 3, H, W, dtype=torch.float32, device=dev)
-        check(self.lib.st_costvolume_softargmin(C.c_void_p(fl), C.c_void_p(fr), N, Hf, Wf, Cf, ld, self.levels,
-                                                self.temperature, ptr(cost_out), ptr(disp_lr), current_stream()),
-              'st_costvolume_softargmin')
+        stream = current_stream()
+        if self.agg_layers == 0:
+            check(self.lib.st_costvolume_softargmin(C.c_void_p(fl), C.c_void_p(fr), N, Hf, Wf, Cf, ld, D,
+                                                    self.temperature, ptr(cost_out), ptr(disp_lr), stream),
+                  'st_costvolume_softargmin')
+        else:
+            packed = self._pack(dev)
+            va, vb = self._volumes(dev, N, Hf, Wf)
+            # materialise the D' x Hf x Wf volume (d innermost = NHWC), aggregate it with the conv kernel
+            check(self.lib.st_costvolume_softargmin(C.c_void_p(fl), C.c_void_p(fr), N, Hf, Wf, Cf, ld, D,
+                                                    self.temperature, ptr(va), None, stream),
+                  'st_costvolume_softargmin')
+            for l, (wp, bp) in enumerate(packed):
+                d = self._agg_desc(l, va, vb, wp, bp)
+                if self.timing:
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                check(self.lib.st_conv2d_nhwc_variant(C.byref(d), stream, self.variant), 'st_conv2d_nhwc(agg)')
+                if self.timing:
+                    e1.record()
+                    self._events.append((self.variant, e0, e1))
+                va, vb = vb, va
+            if cost_out is not None:
+                cost_out.copy_(va)
+            check(self.lib.st_softargmin(ptr(va), N, Hf, Wf, D, self.temperature, ptr(disp_lr), stream),
+                  'st_softargmin')
         check(self.lib.st_disp_upsample_pack(ptr(disp_lr), N, Hf, Wf, s, H, W, int(valid_hw[0]), int(valid_hw[1]),
-                                             ptr(disp_postp), current_stream()), 'st_disp_upsample_pack')
+                                             ptr(disp_postp), stream), 'st_disp_upsample_pack')
         return disp_postp

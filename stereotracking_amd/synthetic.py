@@ -70,6 +70,14 @@ def synthetic_state_dict(param_table, seed=0, img_stats=(127.5, 73.9), disp_stat
             sd[prefix + '.bn.bias'] = beta
             sd[prefix + '.bn.running_mean'] = rmean
             sd[prefix + '.bn.running_var'] = rvar
+        elif '.agg.' in '.' + name and name.endswith('.weight') and len(shape) == 4:
+            # cost-volume aggregation conv: centre tap passes each disparity plane through, small random
+            # mixing of neighbouring planes / pixels on top (keeps the known-shift answer recoverable)
+            w = randn(shape, 0.02)
+            idx = torch.arange(min(shape[0], shape[1]))
+            w[idx, idx, shape[2] // 2, shape[3] // 2] += 1.0
+            sd[name] = w
+            sd[name[:-len('.weight')] + '.bias'] = randn((shape[0],), 0.01)
         elif name.endswith('.weight') and len(shape) == 4:  # bare prediction Conv2d
             fan_in = shape[1] * shape[2] * shape[3]
             prefix = name[:-len('.weight')]

@@ -271,3 +271,27 @@ def test_shard_frames_single_process():
     assert sdist.shard_frames(2, 3, 4) == (2, 2, 1)
     x = torch.zeros(2, 3, 8)
     assert sdist.gather_detections(x) is x
+
+
+def test_stereo_config_builds_cost_volume_module_with_aggregation():
+    """The stereo config (north_star's new module under configs/stereo_tracking) builds a StereoCostVolume with
+    two aggregation convs; its parameters live once in the shell's state_dict (`stereo.agg.*`), start as the
+    identity, and the module refuses a CPU forward (the HIP path is the only product path)."""
+    from stereotracking_amd import mot  # noqa: F401
+    from stereotracking_amd.config import Config
+    from stereotracking_amd.registry import MODELS
+    cfg = Config.fromfile(os.path.join(os.path.dirname(CFG), 'stereo_yolox_s_mot_airdrone_costvolume.py'))
+    assert cfg.model.stereo.agg_layers == 2 and cfg.model.stereo.max_disp == 192
+    model = MODELS.build(cfg.model)
+    st = model.stereo
+    assert type(st).__name__ == 'StereoCostVolume' and st.levels == 48 and model.detector.stereo is st
+    assert st.param_table() == [('agg.0.weight', (48, 48, 3, 3)), ('agg.0.bias', (48,)),
+                                ('agg.1.weight', (48, 48, 3, 3)), ('agg.1.bias', (48,))]
+    keys = list(model.state_dict().keys())
+    assert 'stereo.agg.1.bias' in keys and not any(k.startswith('detector.stereo') for k in keys)
+    w = st.agg[0].weight
+    assert float(w.sum()) == 48.0 and float(w[5, 5, 1, 1]) == 1.0 and float(st.agg[1].bias.abs().sum()) == 0.0
+    with pytest.raises(RuntimeError, match='no CPU forward'):
+        st(torch.zeros(1, 48, 4, 4))
+    with pytest.raises(ValueError):
+        MODELS.build(dict(type='StereoCostVolume', max_disp=40, agg_layers=1))   # 10 levels: not a multiple of 4

@@ -7,6 +7,7 @@ import pytest
 import torch
 
 from oracle import c_oracle
+from oracle import stereo as ostereo
 from oracle import depth as odepth
 from oracle.torch_model import OracleDetector, head_to_rows
 from stereotracking_amd import _lib
@@ -102,8 +103,15 @@ def build_model(cfg_path, cuda, widen=0.375, seed=5, prior_prob=0.2):
     cfg.model.tracker['obj_score_thr'] = 0.02
     model = MODELS.build(cfg.model)
     # confident synthetic head so that tracks get started (score > init_track_thr = 0.7)
-    sd = synthetic_state_dict(model.detector._table, seed=seed, prior_prob=prior_prob, logit_std=2.5)
+    table = list(model.detector._table)
+    if model.stereo is not None:
+        table += [('stereo.' + n, shp) for n, shp in model.stereo.param_table()]
+    sd = synthetic_state_dict(table, seed=seed, prior_prob=prior_prob, logit_std=2.5)
     model.detector.load_state_dict(sd, strict=False)
+    if model.stereo is not None:
+        model.stereo.load_state_dict({k[len('stereo.'):]: v for k, v in sd.items() if k.startswith('stereo.')})
+        assert any(k.startswith('stereo.agg.') for k in model.state_dict()) == (model.stereo.agg_layers > 0)
+        assert not any(k.startswith('detector.stereo.') for k in model.state_dict())
     return model, sd, cfg
 
 
@@ -197,8 +205,9 @@ def test_batched_predict_equals_sequential_and_stereo_module(cuda):
     with torch.no_grad():
         fl = ora.backbone.stage1_features(fr['img']).permute(0, 2, 3, 1).contiguous().numpy()
         frr = ora.backbone.stage1_features(fr['right']).permute(0, 2, 3, 1).contiguous().numpy()
-    lr = c_oracle.softargmin(c_oracle.costvolume(fl, frr, fl.shape[-1], model.stereo.levels), model.stereo.temperature)
-    ref = c_oracle.disp_upsample(lr, 4, ori[0], ori[1])
+    assert model.stereo.agg_layers == 2   # the shipped stereo config aggregates the volume with two 3x3 convs
+    ref = ostereo.disparity(fl, frr, fl.shape[-1], model.stereo.levels, model.stereo.temperature, sd,
+                            model.stereo.agg_layers, valid_hw=ori)[2]
     data = dict(img=inputs['img'][:, 0], right=inputs['right'][:, 0])
     model.detector._run(data, ori)
     torch.cuda.synchronize()

@@ -201,3 +201,39 @@ def test_pack_raw_inputs_matches_reference_pipeline(cuda):
     assert np.array_equal(out['img'].cpu().numpy(), ref_img)
     assert np.array_equal(out['disp_postp'].cpu().numpy(), ref_disp)
     assert np.array_equal(out['disp_mask'].cpu().numpy(), ref_mask)
+
+
+@pytest.mark.parametrize('agg_layers,tuned', [(1, False), (2, False), (2, True)])
+def test_stereo_module_with_aggregation_matches_oracle(agg_layers, tuned, cuda):
+    """Full stereo module (stage-1 features of both views -> cost volume -> `agg_layers` 3x3 convs over
+    d-as-channels -> soft-argmin -> x4 upsample) against oracle/stereo.py on the GPU's own features:
+    aggregated volume and disparity within 1e-3 (float kernel, north_star tolerance), padding exactly 0."""
+    from oracle import stereo as ostereo
+    from stereotracking_amd.pipeline import StereoDensePipeline
+    from stereotracking_amd.synthetic import synthetic_batch, synthetic_state_dict
+    N, H, W, D = 2, 88, 152, 32            # padded to 96 x 160 by the pipeline
+    pipe = StereoDensePipeline(N, (H, W), 0.375, 0.33, 1, stereo=True, max_disp=D, max_det=32,
+                               agg_layers=agg_layers)
+    names = [n for n, _ in pipe.param_table()]
+    assert f'stereo.agg.{agg_layers - 1}.weight' in names and f'stereo.agg.{agg_layers}.weight' not in names
+    sd = synthetic_state_dict(pipe.param_table(), seed=1)
+    pipe.load_state_dict(sd, autotune=tuned)
+    assert (pipe.stereo_module.variant >= 0) == tuned
+    batch = synthetic_batch([3, 4], H, W, D)
+    img, right = batch['img'].to(cuda), batch['right'].to(cuda)
+    Hf, Wf, Dl = pipe.height // 4, pipe.width // 4, D // 4
+    vol = torch.full((N, Hf, Wf, Dl), float('nan'), device=cuda)
+    lr = torch.full((N, Hf, Wf), float('nan'), device=cuda)
+    out = torch.full((N, 3, pipe.height, pipe.width), float('nan'), device=cuda)
+    pipe.stereo_module.compute(pipe.det, img, right, (H, W), lr, out, cost_out=vol)
+    torch.cuda.synchronize()
+    feat = pipe.det.tap('stage1_rgb').cpu().numpy()
+    Cf = feat.shape[-1]
+    ref_vol, ref_lr, ref_out = ostereo.disparity(feat[:N], feat[N:], Cf, Dl, pipe.temperature, sd, agg_layers,
+                                                 valid_hw=(H, W))
+    assert np.abs(vol.cpu().numpy() - ref_vol).max() <= 1e-3 * max(1.0, np.abs(ref_vol).max())
+    assert np.abs(lr.cpu().numpy() - ref_lr).max() <= 1e-3 * Dl
+    got = out.cpu().numpy()
+    assert np.abs(got - ref_out).max() <= 1e-3 * D
+    assert (got[:, :, H:, :] == 0).all() and (got[:, :, :, W:] == 0).all()
+    assert got.min() >= 0.0 and got.max() <= D          # soft-argmin is a convex combination of the levels

@@ -20,8 +20,8 @@ ap.add_argument('--steps', type=int, default=5)
 ap.add_argument('--out', default='')
 a = ap.parse_args()
 dev = torch.device('cuda:0')
-pipe = StereoDensePipeline(a.batch, (720, 1280), 0.5, 0.33, 1, stereo=True, max_disp=192)
-pipe.load_state_dict(synthetic_state_dict(pipe.param_table(), 0))
+pipe = StereoDensePipeline(a.batch, (720, 1280), 0.5, 0.33, 1, stereo=True, max_disp=192, agg_layers=2)
+pipe.load_state_dict(synthetic_state_dict(pipe.param_table(), 0), tuning_cache=os.environ.get('ST_TUNE_CACHE'))
 b = synthetic_batch(list(range(a.batch)), 720, 1280, 192)
 img, right = b['img'].to(dev), b['right'].to(dev)
 det, lib = pipe.det, pipe.det.lib
@@ -33,9 +33,13 @@ ms, kind, var, macs, ph = (np.zeros(n, np.float32), np.zeros(n, np.int32), np.ze
                            np.zeros(n, np.float64), np.zeros(n, np.int32))
 tot = np.zeros(n)
 p = lambda x: x.ctypes.data_as(C.c_void_p)
+sm = pipe.stereo_module
+sm.timing = True
+agg_ms = []
 for _ in range(a.steps):
     pipe.run(img, right)
     torch.cuda.synchronize()
+    agg_ms.append([t for _, t in sm.pop_times()])
     check(lib.st_detector_op_times(det.handle, n, p(ms), p(kind), p(var), p(macs), p(ph)))
     tot += ms
 tot /= a.steps
@@ -46,6 +50,11 @@ for i in range(n):
     lib.st_detector_op_desc(det.handle, i, buf, 512)
     tf = 2 * macs[i] / (tot[i] * 1e-3) / 1e12 if tot[i] > 0 and macs[i] > 0 else 0
     lines.append(f'{i:3d} {tot[i] * 1e3:9.1f} us  {tiles[int(var[i])]:>8s} {2 * macs[i] / 1e9:8.2f} GF {tf:7.1f} TF/s  {buf.value.decode()}')
+agg_ms = np.asarray(agg_ms).mean(0) if agg_ms and agg_ms[0] else np.zeros(0)
+am = sm.agg_macs(a.batch, pipe.height // 4, pipe.width // 4)
+for l, t in enumerate(agg_ms):
+    lines.append(f'agg{l} {t * 1e3:8.1f} us  {tiles[int(sm.variant)]:>8s} {2 * am / 1e9:8.2f} GF {2 * am / (t * 1e-3) / 1e12:7.1f} TF/s  '
+                 f'stereo aggregation conv3x3 48->48 @{pipe.height // 4}x{pipe.width // 4}')
 lines.append(f'total {tot.sum():.3f} ms, conv {tot[kind == 1].sum():.3f} ms, {2 * macs.sum() / 1e9:.1f} GFLOP')
 txt = '\n'.join(lines)
 print(txt)
