@@ -108,7 +108,8 @@ def conv_roofline(pipe, img, right, steps):
     # HBM bytes per launch of that kernel instance from the committed rocprofv3 PMC passes (FETCH_SIZE x2
     # gfx950 correction + WRITE_SIZE, separate passes; tools/pmc_summary.py), if the profile has the row
     dom_id = next(v for v, n in VARIANT_TILES.items() if n == dom)
-    kname = 'st::conv_igemm_kernel<%s>' % lib.st_conv_variant_signature(dom_id).decode()
+    sig = lib.st_conv_variant_signature(dom_id).decode()
+    kname = 'st::conv_igemm_kernel<%s>' % sig if dom_id != 40 else 'st::stem_focus_conv_kernel<1>'
     traffic, traffic_src = None, None
     tpath = os.path.join(ROOT, 'profiles', 'r01_hbm_traffic.json')
     if os.path.exists(tpath):

@@ -97,6 +97,22 @@ int st_conv_pack_weights(const float* w, const float* conv_bias, /* may be NULL 
 int st_focus_pack(const float* img_nchw_dev, int N, int C, int H, int W,
                   float* out_nhwc_dev, st_stream_t stream);
 
+/* Fused Focus + stem ConvModule: Focus(x) followed by the 3x3/s1/p1 ConvModule over its 12 channels is a
+ * 6x6/s2/p2 convolution of the planar 3-channel image, computed here in one kernel (no NHWC 12-channel
+ * intermediate).  Replaces csp_darknet_disparity_v1.py:104-111 (`Focus(3, c, kernel_size=3)`, both the RGB
+ * `stem` and the `disp_stem`) as run at :176-179.  Cout <= 64; H even, W a multiple of 4, image 16-byte aligned.
+ *   w            stem conv weight [Cout][12][3][3], channels in Focus order (TL,BL,TR,BR groups of 3)
+ *   wgt_out      st_stem_packed_floats(Cout) floats, bias_out round_up(Cout,32) floats (host buffers)
+ *   out_nhwc_dev [N][H/2][W/2][out_ld], channels written at [out_off, out_off + Cout)          */
+size_t st_stem_packed_floats(int Cout);
+int st_stem_pack_weights(const float* w, const float* conv_bias, /* may be NULL */
+                         const float* bn_gamma, const float* bn_beta,
+                         const float* bn_mean, const float* bn_var, /* NULL = no BN */
+                         double bn_eps, int Cout, float* wgt_out, float* bias_out);
+int st_stem_focus_conv(const float* img_nchw_dev, int N, int H, int W, const float* wgt_dev,
+                       const float* bias_dev, int Cout, float* out_nhwc_dev, int out_ld, int out_off,
+                       int act /* 1 = SiLU */, st_stream_t stream);
+
 /* Raw input packing: uint8 image (N,3,h,w) -> fp32 (N,3,H,W) padded with img_pad;
  * uint16 disparity PNG codes (N,h,w) -> disp_postp fp32 px = code/16 (65535 -> 0) x3 channels padded with
  * 0, and disp_mask (N,1,H,W) = code < 65535.  Replaces LoadDisparityFromFile._post_processing_v2

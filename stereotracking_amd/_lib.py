@@ -64,6 +64,9 @@ _PROTOS = {
     'st_conv_packed_floats': (_sz, [_i, _i, _i, _i]),
     'st_conv_pack_weights': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, C.c_double, _i, _i, _i, _i, _vp, _vp]),
     'st_focus_pack': (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
+    'st_stem_packed_floats': (_sz, [_i]),
+    'st_stem_pack_weights': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, C.c_double, _i, _vp, _vp]),
+    'st_stem_focus_conv': (_i, [_vp, _i, _i, _i, _vp, _vp, _i, _vp, _i, _i, _i, _vp]),
     'st_pack_raw_inputs': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp]),
     'st_spp_pool': (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _i, _i, _vp]),
     'st_detector_create': (_i, [C.POINTER(StDetectorConfig), C.POINTER(_vp)]),

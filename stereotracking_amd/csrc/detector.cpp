@@ -36,6 +36,8 @@ bool conv_variant_valid(int id, int cout);
 const char* conv_variant_name(int id);
 const char* conv_variant_signature(int id);
 int focus_pack_launch(const float* img, int N, int C, int H, int W, float* out, hipStream_t stream);
+int stem_focus_conv_launch(const float* in, int N, int H, int W, const float* wgt, const float* bias, int Cout,
+                           float* out, int out_ld, int out_off, int act, hipStream_t stream);
 int spp_pool_launch(const float* x, int x_ld, int x_off, int N, int H, int W, int C, float* out,
                     int out_ld, int out_off, hipStream_t stream);
 
@@ -73,6 +75,7 @@ struct PackedConv {
   std::vector<ConvSrc> srcs;
   int cin = 0, k = 1, cout = 0;
   size_t wgt_off = 0, bias_off = 0;  // float offsets inside the packed weight arena
+  bool stem = false;                 // fused Focus+stem layout (st_stem_pack_weights), cin = 12, k = 3
 };
 
 constexpr int BUF_HEAD = -2;   // caller's head_out buffer
@@ -94,8 +97,9 @@ struct TRef {  // a channel slice of an NHWC buffer
 };
 
 struct Op {
-  enum Type { FOCUS, CONV, SPP } type;
-  // FOCUS: src input index (0 = img/left, 1 = disp, 2 = right), dst tensor, dst batch offset
+  enum Type { FOCUS, CONV, SPP, STEM } type;
+  // FOCUS / STEM: src input index (0 = img/left, 1 = disp, 2 = right), dst tensor, dst batch offset
+  // (STEM = fused Focus + stem ConvModule, stem_focus_conv.hip; uses pc and out1)
   int focus_input = 0;
   int focus_batch_off = 0;
   // CONV
@@ -235,6 +239,17 @@ struct StDetector {
     macs += o.macs;
     ops.push_back(o);
   }
+  // Fused Focus + stem ConvModule on input `input_idx`, written to images [batch_off, batch_off + cfg.batch) of out
+  void op_stem(int pc, int input_idx, int batch_off, const TRef& out) {
+    Op o;
+    o.type = Op::STEM;
+    o.pc = pc; o.focus_input = input_idx; o.focus_batch_off = batch_off; o.out1 = out;
+    o.phase = cur_phase;
+    o.macs = (double)cfg.batch * out.H * out.W * 108.0 * convs[pc].cout;
+    o.variant = 40;
+    macs += o.macs;
+    ops.push_back(o);
+  }
   // ConvModule helper: allocates the output unless `out` is given
   TRef convmodule(const std::string& p, const TRef& in, int cout, int k, int stride, TRef out = TRef()) {
     const int pc = packed_convmodules({p}, in.C, {cout}, k);
@@ -294,8 +309,19 @@ int StDetector::build() {
   // ---- phase 0: RGB branch stem + stage1 (left, and right when stereo: same weights, batch 2N)
   cur_phase = 0;
   const int NB = stereo ? 2 * N : N;
-  TRef packed_rgb = new_tensor(NB, H2, W2, 12);
-  {
+  // Focus + stem ConvModule as ONE kernel reading the planar image (stem_focus_conv.hip) whenever the stem is
+  // at most 64 channels wide (widen_factor <= 1); otherwise focus_pack + the generic conv.  ST_NO_FUSED_STEM=1
+  // forces the two-kernel path (A/B measurements).
+  const bool fused_stem = c1 <= 64 && !getenv("ST_NO_FUSED_STEM");
+  TRef packed_rgb, stem_rgb;
+  if (fused_stem) {
+    stem_rgb = new_tensor(NB, H2, W2, c1);
+    const int pcs = packed_convmodules({"backbone.stem.conv"}, 12, {c1}, 3);
+    convs[pcs].stem = true;
+    op_stem(pcs, 0, 0, stem_rgb);
+    if (stereo) op_stem(pcs, 2, N, stem_rgb);
+  } else {
+    packed_rgb = new_tensor(NB, H2, W2, 12);
     Op f; f.type = Op::FOCUS; f.focus_input = 0; f.out1 = packed_rgb; f.focus_batch_off = 0; f.phase = 0;
     ops.push_back(f);
     if (stereo) {
@@ -312,7 +338,8 @@ int StDetector::build() {
   TRef s1 = new_tensor(NB, H4, W4, c2);  // stage1 features of every (left | right) image: kept for the stereo module
   begin_group(sbatch, NB);
   {
-    TRef stem = convmodule("backbone.stem.conv", window(packed_rgb, sbatch), c1, 3, 1);
+    TRef stem = fused_stem ? window(stem_rgb, sbatch)
+                           : convmodule("backbone.stem.conv", window(packed_rgb, sbatch), c1, 3, 1);
     TRef s1c = convmodule("backbone.stage1.0", stem, c2, 3, 2);
     csp_layer("backbone.stage1.1", s1c, c2, n1, true, window(s1, sbatch));
   }
@@ -323,8 +350,14 @@ int StDetector::build() {
   cur_phase = 1;
   TRef s1_left = s1;
   s1_left.N = N;  // first N images of the stacked batch
-  TRef packed_disp = new_tensor(N, H2, W2, 12);
-  {
+  TRef packed_disp, stem_disp;
+  if (fused_stem) {
+    stem_disp = new_tensor(N, H2, W2, c1);
+    const int pcs = packed_convmodules({"backbone.disp_stem.conv"}, 12, {c1}, 3);
+    convs[pcs].stem = true;
+    op_stem(pcs, 1, 0, stem_disp);
+  } else {
+    packed_disp = new_tensor(N, H2, W2, 12);
     Op f; f.type = Op::FOCUS; f.focus_input = 1; f.out1 = packed_disp; f.focus_batch_off = 0; f.phase = 1;
     ops.push_back(f);
   }
@@ -332,7 +365,8 @@ int StDetector::build() {
   TRef C3 = catTD1.slice(c3, c3);
   begin_group(sbatch, N);
   {
-    TRef dstem = convmodule("backbone.disp_stem.conv", window(packed_disp, sbatch), c1, 3, 1);
+    TRef dstem = fused_stem ? window(stem_disp, sbatch)
+                            : convmodule("backbone.disp_stem.conv", window(packed_disp, sbatch), c1, 3, 1);
     TRef d1c = convmodule("backbone.disp_stage1.0", dstem, c2, 3, 2);
     // y = (o_stem + o_disp_stem) / 2   (csp_darknet_disparity_v1.py:184)
     csp_layer("backbone.disp_stage1.1", d1c, c2, n1, true, window(y, sbatch), window(s1_left, sbatch), 0.5f);
@@ -415,7 +449,8 @@ int StDetector::build() {
   wgt_floats = 0;
   for (auto& pc : convs) {
     pc.wgt_off = wgt_floats;
-    wgt_floats += (size_t)round_up(pc.cout, 32) * round_up(pc.k * pc.k * pc.cin, 32);
+    wgt_floats += pc.stem ? st_stem_packed_floats(pc.cout)
+                          : (size_t)round_up(pc.cout, 32) * round_up(pc.k * pc.k * pc.cin, 32);
     pc.bias_off = wgt_floats;
     wgt_floats += round_up(pc.cout, 32);
     wgt_floats = (wgt_floats + 63) & ~(size_t)63;
@@ -483,6 +518,14 @@ extern "C" int st_detector_finalize(StDetector* det) {
   std::vector<float> host(det->wgt_floats, 0.f);
   auto get = [&](const std::string& n) -> const float* { return det->params[det->pindex.at(n)].data.data(); };
   for (const PackedConv& pc : det->convs) {
+    if (pc.stem) {
+      const ConvSrc& s = pc.srcs[0];
+      ST_CHECK(st_stem_pack_weights(get(s.conv_prefix + ".weight"), nullptr, get(s.bn_prefix + ".weight"),
+                                    get(s.bn_prefix + ".bias"), get(s.bn_prefix + ".running_mean"),
+                                    get(s.bn_prefix + ".running_var"), det->cfg.bn_eps, pc.cout,
+                                    host.data() + pc.wgt_off, host.data() + pc.bias_off));
+      continue;
+    }
     const int Kpad = round_up(pc.k * pc.k * pc.cin, 32);
     int row = 0;
     for (const ConvSrc& s : pc.srcs) {
@@ -538,6 +581,14 @@ int launch_op(StDetector* det, Op& o, int img0, const float* const inputs[3], fl
       ST_REQUIRE(src != nullptr, "detector: input %d not provided", o.focus_input);
       float* dst = resolve(det, o.out1, ws, head) + (size_t)o.focus_batch_off * o.out1.H * o.out1.W * o.out1.ld;
       return focus_pack_launch(src, det->cfg.batch, 3, det->cfg.height, det->cfg.width, dst, stream);
+    }
+    case Op::STEM: {
+      const float* src = inputs[o.focus_input];
+      ST_REQUIRE(src != nullptr, "detector: input %d not provided", o.focus_input);
+      const PackedConv& pc = det->convs[o.pc];
+      float* dst = resolve(det, o.out1, ws, head) + (size_t)o.focus_batch_off * o.out1.H * o.out1.W * o.out1.ld;
+      return stem_focus_conv_launch(src, det->cfg.batch, det->cfg.height, det->cfg.width, det->wgt_dev + pc.wgt_off,
+                                    det->wgt_dev + pc.bias_off, pc.cout, dst, o.out1.ld, o.out1.off, 1, stream);
     }
     case Op::SPP: {
       float* x = resolve(det, o.in, ws, head, img0);
@@ -667,7 +718,7 @@ extern "C" int st_detector_op_times(StDetector* det, int cap, float* ms, int* ki
       t += dt;
     }
     if (ms) ms[i] = t;
-    if (kind) kind[i] = det->ops[i].type == Op::FOCUS ? 0 : det->ops[i].type == Op::CONV ? 1 : 2;
+    if (kind) kind[i] = det->ops[i].type == Op::FOCUS ? 0 : det->ops[i].type == Op::SPP ? 2 : 1;  // STEM counts as conv
     if (variant) variant[i] = det->ops[i].variant;
     if (macs) macs[i] = det->ops[i].macs;
     if (phase) phase[i] = det->ops[i].phase;
@@ -736,8 +787,11 @@ extern "C" int st_detector_autotune(StDetector* det, void* workspace_dev, size_t
   return rc;
 }
 
-extern "C" const char* st_conv_variant_name(int id) { return conv_variant_name(id); }
-extern "C" const char* st_conv_variant_signature(int id) { return conv_variant_signature(id); }
+// id 40 = the fused Focus+stem kernel (stem_focus_conv.hip), reported with the conv ops
+extern "C" const char* st_conv_variant_name(int id) { return id == 40 ? "stem6x6s2" : conv_variant_name(id); }
+extern "C" const char* st_conv_variant_signature(int id) {
+  return id == 40 ? "stem_focus_conv" : conv_variant_signature(id);
+}
 
 // Read / restore the per-op tile choice (one int per op, -1 = heuristic) so a tuning result can be
 // cached across processes (e.g. to keep autotune launches out of a rocprofv3 trace).
@@ -769,6 +823,10 @@ extern "C" int st_detector_op_desc(const StDetector* det, int i, char* buf, int 
   const Op& o = det->ops[i];
   if (o.type == Op::FOCUS) {
     snprintf(buf, (size_t)cap, "focus_pack input=%d", o.focus_input);
+  } else if (o.type == Op::STEM) {
+    snprintf(buf, (size_t)cap, "stem focus+conv6x6 s2 input=%d N=%d Hi=%d Wi=%d Cin=3 Cout=%d  %s", o.focus_input,
+             det->cfg.batch, det->cfg.height, det->cfg.width, det->convs[o.pc].cout,
+             det->convs[o.pc].srcs[0].conv_prefix.c_str());
   } else if (o.type == Op::SPP) {
     snprintf(buf, (size_t)cap, "spp_pool N=%d H=%d W=%d C=%d", o.in.N, o.in.H, o.in.W, o.in.C);
   } else {
