@@ -22,6 +22,8 @@
 // sum over k does not care about.
 #include <algorithm>
 
+#include <type_traits>
+
 #include "st_common.h"
 
 namespace st {
@@ -331,10 +333,16 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(ConvKArgs p) {
   // they ride in the shadow of the 64-cycle matrix instructions instead of forming a load burst at the
   // top and a vmcnt-wait + ds_write burst at the bottom of every chunk.
   constexpr int NI = AP + BP;
-  for (int kc = 0; kc < nchunks; ++kc) {
+  // One K-chunk.  MORE = "a chunk follows" is a compile-time tag: the steady-state body is straight-line code
+  // (no uniform branches around the staging items, no K-tail test), only the final chunk looks at the K tail.
+  // The A/W fragments of k-group g+1 are read from LDS BEFORE the 4*TM*TN MFMAs of group g are issued
+  // (two fragment register sets), so the ds_read latency is covered by a full group of MFMAs instead of being
+  // exposed four times per chunk.
+  auto do_chunk = [&](int kc, auto more_tag) {
+    constexpr bool MORE = decltype(more_tag)::value;
     const int buf = NBUF == 2 ? (kc & 1) : 0;
     const int nbuf = NBUF == 2 ? (buf ^ 1) : 0;
-    const bool more = (ABL == 0 || ABL >= 4) && kc + 1 < nchunks;  // ABL 6: cache-hot re-loads
+    constexpr bool more = (ABL == 0 || ABL >= 4) && MORE;  // ABL 6: cache-hot re-loads
     const bool vk = kc_k < p.K;  // the lane state already describes chunk kc + 1
     if (!DMA && !ILV && more && ABL != 5) load_chunk(kc + 1);
     if (DMA && !ILV && more) dma_chunk(kc + 1, nbuf);
@@ -342,25 +350,32 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(ConvKArgs p) {
     const float* Ab = As + buf * BM * LDK + (wm * 32 * TM + l31) * LDK + (DMA ? 0 : 4 * lh);
     const float* Bb = Bs + buf * BN * LDK + (wn * 32 * TN + l31) * LDK + (DMA ? 0 : 4 * lh);
     const int sw = (l31 >> 1) & 7;  // DMA image: k-group g of a row lives in 16-B slot g ^ sw
-    const int gmax = (p.K - kc * BK + 7) >> 3;  // k-groups of this chunk that hold real data (K tail)
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      if (g >= gmax) break;
-      f32x4 a[TM], b[TN];
+    // k-groups of this chunk that hold real data (K tail): only the final chunk can be short
+    const int gmax = MORE ? 4 : (p.K - kc * BK + 7) >> 3;
+    f32x4 a[2][TM], b[2][TN];
+    auto read_frags = [&](int g, int set) {
       const int koff = DMA ? (((2 * g + lh) ^ sw) * 4) : g * 8;
 #pragma unroll
       for (int i = 0; i < TM; ++i)
-        a[i] = *reinterpret_cast<const f32x4*>(Ab + i * 32 * LDK + koff);
+        a[set][i] = *reinterpret_cast<const f32x4*>(Ab + i * 32 * LDK + koff);
 #pragma unroll
       for (int j = 0; j < TN; ++j)
-        b[j] = *reinterpret_cast<const f32x4*>(Bb + j * 32 * LDK + koff);
+        b[set][j] = *reinterpret_cast<const f32x4*>(Bb + j * 32 * LDK + koff);
+    };
+    read_frags(0, 0);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      if (!MORE && g >= gmax) break;
+      const int set = g & 1;
+      if (g + 1 < 4) read_frags(g + 1, set ^ 1);   // (zero padding beyond the K tail: harmless to read)
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
           for (int j = 0; j < TN; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][s], b[j][s], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[set][i][s], b[set][j][s], acc[i][j], 0, 0, 0);
         if (DMA && ILV) {
           const int slot = g * 4 + s;
           if (more) {  // one DMA item per slot, all issued in the first half of the chunk
@@ -397,13 +412,15 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(ConvKArgs p) {
         store_chunk(nbuf);
       } else {
 #pragma unroll
-        for (int a = 0; a < AP; ++a) asm volatile("" ::"v"(areg[a]));
+        for (int a_ = 0; a_ < AP; ++a_) asm volatile("" ::"v"(areg[a_]));
 #pragma unroll
-        for (int b = 0; b < BP; ++b) asm volatile("" ::"v"(breg[b]));
+        for (int b_ = 0; b_ < BP; ++b_) asm volatile("" ::"v"(breg[b_]));
       }
     }
     if (ABL < 2) __syncthreads();
-  }
+  };
+  for (int kc = 0; kc + 1 < nchunks; ++kc) do_chunk(kc, std::true_type{});
+  do_chunk(nchunks - 1, std::false_type{});
 
   conv_epilogue<TM, TN>(p, acc, m0, n0, wm, wn, l31, lh, BM, BN);
 }
