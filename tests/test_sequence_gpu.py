@@ -7,7 +7,7 @@ import torch
 from stereotracking_amd.motion import KalmanFilter
 from stereotracking_amd.pipeline import StereoDensePipeline
 from stereotracking_amd.sequence import detect_shard, run_sharded_sequence, synthetic_sequence, track_gathered
-from stereotracking_amd.synthetic import synthetic_state_dict
+from stereotracking_amd.synthetic import synthetic_batch, synthetic_state_dict
 from stereotracking_amd.trackers import OCSORTTracker_Disparity
 
 pytestmark = pytest.mark.gpu
@@ -61,3 +61,33 @@ def test_sharded_driver_world1(cuda):
     for a, b in zip(res, ref):
         assert a.instances_id.tolist() == b.instances_id.tolist()
         assert set(a.keys()) >= {'bboxes', 'labels', 'scores', 'scales', 'depth', 'instances_id'}
+
+
+def test_inflight_contexts_match_serial_results(cuda):
+    """InflightPipelines (3 contexts, 3 HIP streams, batches overlapping on the GPU) returns for every batch
+    exactly what a single serial pipeline returns: same kernels, same inputs, no shared scratch."""
+    from stereotracking_amd.pipeline import InflightPipelines
+    H, W, D, B = 80, 160, 32, 2
+    args = (B, (H, W), 0.375, 0.33, 1)
+    kw = dict(stereo=True, max_disp=D, max_det=64, agg_layers=1)
+    runner = InflightPipelines(3, *args, **kw)
+    serial = StereoDensePipeline(*args, **kw)
+    sd = synthetic_state_dict(runner.param_table(), seed=2, prior_prob=0.2, logit_std=2.5)
+    runner.load_state_dict(sd, autotune=False)
+    serial.load_state_dict(sd, autotune=False)
+    batches = [synthetic_batch([10 * i, 10 * i + 1], H, W, D) for i in range(7)]
+    dev_in = [(b['img'].to(cuda), b['right'].to(cuda)) for b in batches]
+    got = []
+    for img, right in dev_in:
+        out, ev = runner.submit(img, right, post=lambda o, ctx: {k: v.clone() for k, v in o.items()})
+        got.append((out, ev))
+    runner.synchronize()
+    assert all(ev.query() for _, ev in got)
+    kept = 0
+    for (out, _), (img, right) in zip(got, dev_in):
+        ref = serial.run(img, right)
+        torch.cuda.synchronize()
+        for k in ('counts', 'prior_idx', 'boxes', 'scores', 'depth', 'scaled_boxes', 'disp_postp', 'head'):
+            assert torch.equal(out[k].nan_to_num(-7.0), ref[k].nan_to_num(-7.0)), k
+        kept += int(ref['counts'].sum())
+    assert kept > 0
