@@ -64,6 +64,15 @@ def conv_roofline(pipe, img, right, steps):
     sm.timing = True
     agg = {}   # variant -> [launches, ms]
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
+    # an event pair with nothing in between already measures ~4.6 us on this stack (two barrier packets); that
+    # overhead is measured live and removed from every per-launch duration, otherwise the HIP-event averages sit
+    # ~6 % above rocprofv3's kernel durations (profiles/r01_kernel_stats_inflight1.csv)
+    pairs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(101)]
+    for a_, b_ in pairs:
+        a_.record()
+        b_.record()
+    torch.cuda.synchronize()
+    null_ms = sorted(a_.elapsed_time(b_) for a_, b_ in pairs)[50]
     for _ in range(steps):
         b = pipe._buffers(img.device)
         ev[0].record()
@@ -79,12 +88,12 @@ def conv_roofline(pipe, img, right, steps):
         torch.cuda.synchronize()
         p = lambda a: a.ctypes.data_as(C.c_void_p)
         check(lib.st_detector_op_times(det.handle, nops, p(ms), p(kind), p(var), p(macs), p(phase)))
-        tot_ms += ms
-        ph0 = float(ms[phase == 0].sum())
+        ph0 = float(ms[phase == 0].sum())     # raw: what the bracketing events of the stereo module saw
+        tot_ms += np.maximum(ms - null_ms, 0.0)
         for v, t in sm.pop_times():   # aggregation convs: the same conv kernel, launched by the stereo module
             a = agg.setdefault(int(v), [0, 0.0])
             a[0] += 1
-            a[1] += t
+            a[1] += max(t - null_ms, 0.0)
             ph0 += t
         other['costvolume+softargmin+upsample'] += ev[0].elapsed_time(ev[1]) - ph0
         other['decode_nms'] += ev[2].elapsed_time(ev[3])
@@ -103,30 +112,48 @@ def conv_roofline(pipe, img, right, steps):
         per_variant[VARIANT_TILES[v]] = dict(launches=int(sel.sum()) + n_agg // steps, ms_per_step=round(float(t), 4),
                                              gflop_per_step=round(fl / 1e9, 3),
                                              tflops=round(fl / (t * 1e-3) / 1e12, 3) if t > 0 else 0.0)
-    dom = max(per_variant, key=lambda k: per_variant[k]['ms_per_step'])
+    # The dominant kernel of the path is conv_igemm_kernel (every tile instance is the same kernel template; which
+    # instance a layer uses is an autotune outcome that varies from run to run, so the roofline entry aggregates
+    # all instances: algorithmic flop of all its launches / their summed duration).  The fused stem kernel and the
+    # per-instance table are listed next to it.
+    STEM = 'stem6x6s2'
+    inst = {k: v for k, v in per_variant.items() if k != STEM}
+    n_launch = sum(v['launches'] for v in inst.values())
+    ms_inst = sum(v['ms_per_step'] for v in inst.values())
+    gf_inst = sum(v['gflop_per_step'] for v in inst.values())
+    tf_inst = gf_inst / ms_inst                      # GFLOP / ms = TFLOP/s
+    dom = max(inst, key=lambda k: inst[k]['ms_per_step'])
     conv_ms = float((tot_ms[kind == 1].sum() + sum(a[1] for a in agg.values())) / steps)
     conv_fl = 2.0 * float(macs[kind == 1].sum() + agg_macs * sum(a[0] for a in agg.values()) / steps)
-    d = per_variant[dom]
-    # HBM bytes per launch of that kernel instance from the committed rocprofv3 PMC passes (FETCH_SIZE x2
-    # gfx950 correction + WRITE_SIZE, separate passes; tools/pmc_summary.py), if the profile has the row
-    dom_id = next(v for v, n in VARIANT_TILES.items() if n == dom)
-    sig = lib.st_conv_variant_signature(dom_id).decode()
-    kname = 'st::conv_igemm_kernel<%s>' % sig if dom_id != 40 else 'st::stem_focus_conv_kernel<1>'
+    # HBM bytes per launch from the committed rocprofv3 PMC passes (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE,
+    # separate passes; tools/pmc_summary.py): launch-weighted mean over the instances of this run
     traffic, traffic_src = None, None
     tpath = os.path.join(ROOT, 'profiles', 'r01_hbm_traffic.json')
     if os.path.exists(tpath):
-        row = json.load(open(tpath)).get(kname)
-        if row and row.get('fetch_bytes_corrected_per_launch') is not None:
-            traffic = int(row['fetch_bytes_corrected_per_launch'] + (row.get('write_bytes_per_launch') or 0))
-            traffic_src = 'profiles/r01_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)'
-    roof = dict(bound='mfma', kernel=f'conv_igemm_kernel<{dom}>', kernel_symbol=kname,
-                achieved=d['tflops'], peak=PEAK_FP32_MFMA_TFLOPS, unit='TFLOP/s',
-                frac=round(d['tflops'] / PEAK_FP32_MFMA_TFLOPS, 4), traffic=traffic, traffic_source=traffic_src,
-                flop_per_launch=round(d['gflop_per_step'] * 1e9 / d['launches']),
-                avg_launch_us=round(d['ms_per_step'] * 1e3 / d['launches'], 2),
-                launches_per_step=d['launches'],
-                all_conv=dict(ms_per_step=round(conv_ms, 4), tflops=round(conv_fl / (conv_ms * 1e-3) / 1e12, 3),
-                              frac=round(conv_fl / (conv_ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4)),
+        tj = json.load(open(tpath))
+        tot_b, ok = 0.0, True
+        for name, v in inst.items():
+            vid = next(i for i, n in VARIANT_TILES.items() if n == name)
+            row = tj.get('st::conv_igemm_kernel<%s>' % lib.st_conv_variant_signature(vid).decode())
+            if not row or row.get('fetch_bytes_corrected_per_launch') is None:
+                ok = ok and v['gflop_per_step'] < 0.5    # tiny instances (1x1 prediction convs) may be absent
+                continue
+            tot_b += v['launches'] * (row['fetch_bytes_corrected_per_launch'] + (row.get('write_bytes_per_launch') or 0))
+        if ok and tot_b > 0:
+            traffic = int(tot_b / n_launch)
+            traffic_src = 'profiles/r01_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE), launch-weighted'
+    roof = dict(bound='mfma', kernel='st::conv_igemm_kernel<...> (all tile instances)',
+                achieved=round(tf_inst, 3), peak=PEAK_FP32_MFMA_TFLOPS, unit='TFLOP/s',
+                frac=round(tf_inst / PEAK_FP32_MFMA_TFLOPS, 4), traffic=traffic, traffic_source=traffic_src,
+                flop_per_launch=round(gf_inst * 1e9 / n_launch),
+                avg_launch_us=round(ms_inst * 1e3 / n_launch, 2),
+                launches_per_step=n_launch, event_pair_overhead_us=round(null_ms * 1e3, 2),
+                largest_instance=dict(tile=dom, **inst[dom],
+                                      symbol='st::conv_igemm_kernel<%s>' % lib.st_conv_variant_signature(
+                                          next(i for i, n in VARIANT_TILES.items() if n == dom)).decode()),
+                all_conv_incl_stem=dict(ms_per_step=round(conv_ms, 4),
+                                        tflops=round(conv_fl / (conv_ms * 1e-3) / 1e12, 3),
+                                        frac=round(conv_fl / (conv_ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4)),
                 per_variant=per_variant,
                 other_kernels_ms_per_step={k: round(v / steps, 4) for k, v in other.items()},
                 focus_spp_ms_per_step=round(float(tot_ms[kind != 1].sum() / steps), 4))

@@ -166,6 +166,11 @@ class InflightPipelines:
     def __len__(self):
         return len(self.pipes)
 
+    def __getattr__(self, name):   # geometry / thresholds of the (identical) contexts: batch, max_det, stereo, ...
+        if name in ('batch', 'max_det', 'stereo', 'height', 'width', 'ori_h', 'ori_w', 'agg_layers'):
+            return getattr(self.pipes[0], name)
+        raise AttributeError(name)
+
     def param_table(self):
         return self.pipes[0].param_table()
 
@@ -188,6 +193,9 @@ class InflightPipelines:
         self._next += 1
         s = self.streams[j]
         s.wait_stream(torch.cuda.current_stream(img.device))
+        for t in (img, right, disp_postp):   # the caller may drop its references while the batch is still running
+            if t is not None:
+                t.record_stream(s)
         with torch.cuda.stream(s):
             out = self.pipes[j].run(img, right, disp_postp)
             if post is not None:

@@ -65,22 +65,36 @@ def frames_to_batch(frames, device, use_right=True):
 
 
 def detect_shard(pipe, frames, device):
-    """Dense path over this rank's frames, `pipe.batch` frames per launch plan.
+    """Dense path over this rank's frames, `pipe.batch` frames per launch plan.  `pipe` is a StereoDensePipeline
+    (strictly serial batches) or an InflightPipelines runner (consecutive batches overlap on its streams).
     -> (F_pad, max_det, 8) detection buffer with SCALED boxes (what the tracker consumes), counts."""
-    B = pipe.batch
+    runner = pipe if hasattr(pipe, 'submit') else None
+    one = runner.pipes[0] if runner is not None else pipe
+    B = one.batch
     bufs, counts = [], []
+
+    def pack(out, n_real):
+        det = torch.cat([out['scaled_boxes'], out['scores'][..., None], out['labels'][..., None].float(),
+                         out['depth'][..., None], out['scales'][..., None]], dim=-1)   # fresh tensor
+        c = torch.minimum(out['counts'], torch.full_like(out['counts'], one.max_det))  # fresh tensor
+        c[n_real:] = 0
+        return det, c
+
     for i in range(0, len(frames), B):
         chunk = list(frames[i:i + B])
         n_real = len(chunk)
         chunk = chunk + [chunk[-1]] * (B - n_real)  # pad the last batch with a repeated frame
-        batch = frames_to_batch(chunk, device, use_right=pipe.stereo)
-        out = pipe.run(batch['img'], right=batch.get('right'), disp_postp=batch.get('disp_postp'))
-        det = torch.cat([out['scaled_boxes'], out['scores'][..., None], out['labels'][..., None].float(),
-                         out['depth'][..., None], out['scales'][..., None]], dim=-1)
-        c = torch.minimum(out['counts'], torch.full_like(out['counts'], pipe.max_det))
-        c[n_real:] = 0
-        bufs.append(det.clone())
-        counts.append(c.clone())
+        batch = frames_to_batch(chunk, device, use_right=one.stereo)
+        if runner is not None:   # packed under the context's stream, before that context is reused
+            (det, c), _ = runner.submit(batch['img'], right=batch.get('right'), disp_postp=batch.get('disp_postp'),
+                                        post=lambda out, ctx, n=n_real: pack(out, n))
+        else:
+            det, c = pack(pipe.run(batch['img'], right=batch.get('right'), disp_postp=batch.get('disp_postp')),
+                          n_real)
+        bufs.append(det)
+        counts.append(c)
+    if runner is not None:
+        runner.synchronize()
     return torch.cat(bufs), torch.cat(counts)
 
 
@@ -104,7 +118,8 @@ def run_sharded_sequence(pipe, frames, tracker, model, device):
     frames = list(frames)
     T = len(frames)
     start, stop, chunk = sdist.shard_frames(T)
-    per_rank = (chunk + pipe.batch - 1) // pipe.batch * pipe.batch   # equal padded length on every rank
+    B = (pipe.pipes[0] if hasattr(pipe, 'submit') else pipe).batch
+    per_rank = (chunk + B - 1) // B * B   # equal padded length on every rank
     mine = frames[start:stop]
     if mine:
         dets, counts = detect_shard(pipe, mine, device)

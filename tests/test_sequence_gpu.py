@@ -51,6 +51,24 @@ def test_batched_sequence_equals_frame_by_frame(cuda):
         assert torch.equal(a.bboxes, b.bboxes)
 
 
+def test_sequence_through_inflight_contexts_equals_serial(cuda):
+    """configs[2] driver on overlapping contexts: same detections and track ids as the serial pipeline."""
+    from stereotracking_amd.pipeline import InflightPipelines
+    frames = list(synthetic_sequence(14, 4, 80, 160, 32, seed=6))   # 4 + 4 + 4 + 2 over 3 contexts
+    pipe, sd = make_pipe(4)
+    runner = InflightPipelines(3, 4, (80, 160), 0.375, 0.33, 1, stereo=True, max_disp=32, max_det=64)
+    runner.load_state_dict(sd, autotune=False)
+    d0, c0 = detect_shard(pipe, frames, cuda)
+    d1, c1 = detect_shard(runner, frames, cuda)
+    torch.cuda.synchronize()
+    assert torch.equal(c0, c1) and int(c0.sum()) > 0
+    assert torch.equal(d0.nan_to_num(-7.0), d1.nan_to_num(-7.0))
+    res = run_sharded_sequence(runner, frames, make_tracker(), _Model(), cuda)
+    ref = track_gathered(d0, c0, 14, make_tracker(), _Model())
+    for a, b in zip(res, ref):
+        assert a.instances_id.tolist() == b.instances_id.tolist()
+
+
 def test_sharded_driver_world1(cuda):
     frames = list(synthetic_sequence(6, 3, 80, 160, 32, seed=4))
     pipe, _ = make_pipe(4)

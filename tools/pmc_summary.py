@@ -30,7 +30,7 @@ out = {}
 for name in sorted(set(fetch) | set(write), key=lambda n: -(fetch.get(n, [0, 0])[1] + write.get(n, [0, 0])[1])):
     fc, fv = fetch.get(name, [0, 0.0])
     wc, wv = write.get(name, [0, 0.0])
-    short = name.split('(')[0].replace('void ', '')
+    short = name.replace('(anonymous namespace)::', '').split('(')[0].replace('void ', '')
     out[short] = dict(fetch_calls=fc, write_calls=wc,
                       fetch_bytes_raw_per_launch=round(fv * 1024 / fc) if fc else None,
                       fetch_bytes_corrected_per_launch=round(2 * fv * 1024 / fc) if fc else None,
