@@ -105,11 +105,14 @@ int st_focus_pack(const float* img_nchw_dev, int N, int C, int H, int W,
  *   wgt_out      st_stem_packed_floats(Cout) floats, bias_out round_up(Cout,32) floats (host buffers)
  *   out_nhwc_dev [N][H/2][W/2][out_ld], channels written at [out_off, out_off + Cout)          */
 size_t st_stem_packed_floats(int Cout);
+/* used_planes: 3 = generic image; 1 = the caller guarantees that the three planes are identical (disp_postp is
+ * a 3-channel repeat of one map, loading_disparity.py:85-86): the per-tap weights of the three planes are summed
+ * (fp64, rounded once) and only plane 0 is read: K = 36 instead of 108. */
 int st_stem_pack_weights(const float* w, const float* conv_bias, /* may be NULL */
                          const float* bn_gamma, const float* bn_beta,
                          const float* bn_mean, const float* bn_var, /* NULL = no BN */
-                         double bn_eps, int Cout, float* wgt_out, float* bias_out);
-int st_stem_focus_conv(const float* img_nchw_dev, int N, int H, int W, const float* wgt_dev,
+                         double bn_eps, int Cout, int used_planes, float* wgt_out, float* bias_out);
+int st_stem_focus_conv(const float* img_nchw_dev, int N, int H, int W, int used_planes, const float* wgt_dev,
                        const float* bias_dev, int Cout, float* out_nhwc_dev, int out_ld, int out_off,
                        int act /* 1 = SiLU */, st_stream_t stream);
 
@@ -148,6 +151,10 @@ typedef struct StDetectorConfig {
   int height, width;    /* padded input size, multiples of 32 */
   double bn_eps;        /* 1e-3 */
   int with_right_branch; /* also build stem+stage1 features for the right image (stereo module) */
+  int disp_planes_identical; /* 1 = the caller guarantees disp_postp is a 3-channel repeat of ONE map (what the
+                              * reference loader yields, loading_disparity.py:85-86, and what
+                              * st_disp_upsample_pack writes): the disparity stem then reads plane 0 only with
+                              * plane-summed weights (K = 36 instead of 108).  0 = generic 3-plane input. */
 } StDetectorConfig;
 
 int st_detector_create(const StDetectorConfig* cfg, StDetector** out);

@@ -40,7 +40,7 @@ class StDetectorConfig(C.Structure):
     _fields_ = [
         ('struct_size', C.c_int), ('widen_factor', C.c_float), ('deepen_factor', C.c_float),
         ('num_classes', C.c_int), ('batch', C.c_int), ('height', C.c_int), ('width', C.c_int),
-        ('bn_eps', C.c_double), ('with_right_branch', C.c_int),
+        ('bn_eps', C.c_double), ('with_right_branch', C.c_int), ('disp_planes_identical', C.c_int),
     ]
 
 
@@ -65,8 +65,8 @@ _PROTOS = {
     'st_conv_pack_weights': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, C.c_double, _i, _i, _i, _i, _vp, _vp]),
     'st_focus_pack': (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
     'st_stem_packed_floats': (_sz, [_i]),
-    'st_stem_pack_weights': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, C.c_double, _i, _vp, _vp]),
-    'st_stem_focus_conv': (_i, [_vp, _i, _i, _i, _vp, _vp, _i, _vp, _i, _i, _i, _vp]),
+    'st_stem_pack_weights': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, C.c_double, _i, _i, _vp, _vp]),
+    'st_stem_focus_conv': (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _i, _vp, _i, _i, _i, _vp]),
     'st_pack_raw_inputs': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp]),
     'st_spp_pool': (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _i, _i, _vp]),
     'st_detector_create': (_i, [C.POINTER(StDetectorConfig), C.POINTER(_vp)]),

@@ -36,8 +36,9 @@ bool conv_variant_valid(int id, int cout);
 const char* conv_variant_name(int id);
 const char* conv_variant_signature(int id);
 int focus_pack_launch(const float* img, int N, int C, int H, int W, float* out, hipStream_t stream);
-int stem_focus_conv_launch(const float* in, int N, int H, int W, const float* wgt, const float* bias, int Cout,
-                           float* out, int out_ld, int out_off, int act, hipStream_t stream);
+int stem_focus_conv_launch(const float* in, int N, int H, int W, int used_planes, const float* wgt,
+                           const float* bias, int Cout, float* out, int out_ld, int out_off, int act,
+                           hipStream_t stream);
 int spp_pool_launch(const float* x, int x_ld, int x_off, int N, int H, int W, int C, float* out,
                     int out_ld, int out_off, hipStream_t stream);
 
@@ -76,6 +77,7 @@ struct PackedConv {
   int cin = 0, k = 1, cout = 0;
   size_t wgt_off = 0, bias_off = 0;  // float offsets inside the packed weight arena
   bool stem = false;                 // fused Focus+stem layout (st_stem_pack_weights), cin = 12, k = 3
+  int stem_planes = 3;               // image planes the fused stem reads (1: identical planes, summed weights)
 };
 
 constexpr int BUF_HEAD = -2;   // caller's head_out buffer
@@ -245,7 +247,7 @@ struct StDetector {
     o.type = Op::STEM;
     o.pc = pc; o.focus_input = input_idx; o.focus_batch_off = batch_off; o.out1 = out;
     o.phase = cur_phase;
-    o.macs = (double)cfg.batch * out.H * out.W * 108.0 * convs[pc].cout;
+    o.macs = (double)cfg.batch * out.H * out.W * 36.0 * convs[pc].stem_planes * convs[pc].cout;
     o.variant = 40;
     macs += o.macs;
     ops.push_back(o);
@@ -355,6 +357,7 @@ int StDetector::build() {
     stem_disp = new_tensor(N, H2, W2, c1);
     const int pcs = packed_convmodules({"backbone.disp_stem.conv"}, 12, {c1}, 3);
     convs[pcs].stem = true;
+    convs[pcs].stem_planes = cfg.disp_planes_identical ? 1 : 3;
     op_stem(pcs, 1, 0, stem_disp);
   } else {
     packed_disp = new_tensor(N, H2, W2, 12);
@@ -522,7 +525,7 @@ extern "C" int st_detector_finalize(StDetector* det) {
       const ConvSrc& s = pc.srcs[0];
       ST_CHECK(st_stem_pack_weights(get(s.conv_prefix + ".weight"), nullptr, get(s.bn_prefix + ".weight"),
                                     get(s.bn_prefix + ".bias"), get(s.bn_prefix + ".running_mean"),
-                                    get(s.bn_prefix + ".running_var"), det->cfg.bn_eps, pc.cout,
+                                    get(s.bn_prefix + ".running_var"), det->cfg.bn_eps, pc.cout, pc.stem_planes,
                                     host.data() + pc.wgt_off, host.data() + pc.bias_off));
       continue;
     }
@@ -587,8 +590,9 @@ int launch_op(StDetector* det, Op& o, int img0, const float* const inputs[3], fl
       ST_REQUIRE(src != nullptr, "detector: input %d not provided", o.focus_input);
       const PackedConv& pc = det->convs[o.pc];
       float* dst = resolve(det, o.out1, ws, head) + (size_t)o.focus_batch_off * o.out1.H * o.out1.W * o.out1.ld;
-      return stem_focus_conv_launch(src, det->cfg.batch, det->cfg.height, det->cfg.width, det->wgt_dev + pc.wgt_off,
-                                    det->wgt_dev + pc.bias_off, pc.cout, dst, o.out1.ld, o.out1.off, 1, stream);
+      return stem_focus_conv_launch(src, det->cfg.batch, det->cfg.height, det->cfg.width, pc.stem_planes,
+                                    det->wgt_dev + pc.wgt_off, det->wgt_dev + pc.bias_off, pc.cout, dst, o.out1.ld,
+                                    o.out1.off, 1, stream);
     }
     case Op::SPP: {
       float* x = resolve(det, o.in, ws, head, img0);
@@ -824,8 +828,8 @@ extern "C" int st_detector_op_desc(const StDetector* det, int i, char* buf, int 
   if (o.type == Op::FOCUS) {
     snprintf(buf, (size_t)cap, "focus_pack input=%d", o.focus_input);
   } else if (o.type == Op::STEM) {
-    snprintf(buf, (size_t)cap, "stem focus+conv6x6 s2 input=%d N=%d Hi=%d Wi=%d Cin=3 Cout=%d  %s", o.focus_input,
-             det->cfg.batch, det->cfg.height, det->cfg.width, det->convs[o.pc].cout,
+    snprintf(buf, (size_t)cap, "stem focus+conv6x6 s2 input=%d N=%d Hi=%d Wi=%d Cin=%d Cout=%d  %s", o.focus_input,
+             det->cfg.batch, det->cfg.height, det->cfg.width, det->convs[o.pc].stem_planes, det->convs[o.pc].cout,
              det->convs[o.pc].srcs[0].conv_prefix.c_str());
   } else if (o.type == Op::SPP) {
     snprintf(buf, (size_t)cap, "spp_pool N=%d H=%d W=%d C=%d", o.in.N, o.in.H, o.in.W, o.in.C);

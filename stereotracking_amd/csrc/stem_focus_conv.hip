@@ -40,11 +40,11 @@ constexpr int STEM_IH = 2 * STEM_TH + 4;                  // 20 input rows
 constexpr int STEM_IW = 2 * STEM_TW + 8;                  // 136 input cols: window starts 4 px left of the
                                                           // first needed col - 2, so rows are float4 aligned
 constexpr int STEM_ICH = STEM_IH * STEM_IW;               // floats per channel plane in LDS
-constexpr int STEM_KP = 54;                               // k pairs: 3 * 6 * 6 / 2
+constexpr int stem_kp(int cin) { return cin * 18; }       // k pairs: cin * 6 * 6 / 2  (54 for the 3-plane image)
 constexpr int STEM_ROW4 = STEM_IW / 4;                    // 34 float4 per staged row
-constexpr int STEM_TILE4 = 3 * STEM_IH * STEM_ROW4;       // 2040 float4 per window
-constexpr int STEM_NDMA = (STEM_TILE4 + 255) / 256;       // 8 wave-instructions of 1 KiB per wave
-constexpr int STEM_BUF = STEM_NDMA * 256 * 4;             // floats per window buffer (2048 float4, padded)
+constexpr int stem_tile4(int cin) { return cin * STEM_IH * STEM_ROW4; }          // 2040 float4 per 3-plane window
+constexpr int stem_ndma(int cin) { return (stem_tile4(cin) + 255) / 256; }        // 8 wave-instructions of 1 KiB
+constexpr int stem_buf(int cin) { return stem_ndma(cin) * 256 * 4; }              // floats per window buffer (padded)
 
 struct StemArgs {
   const float* in;     // [N][3][H][W] planar fp32
@@ -53,6 +53,7 @@ struct StemArgs {
   float* out;          // NHWC, pixel stride out_ld, channel offset out_off
   int N, H, W, Ho, Wo, Cout, CoutPad, out_ld, out_off, act;
   int tiles_x, tiles_y;
+  int planes;          // planes per image in memory (3); the kernel reads the first CIN of them
   unsigned out_bytes;  // bytes addressable through `out` (range check of the epilogue stores)
 };
 
@@ -61,6 +62,7 @@ __device__ __forceinline__ float stem_silu(float v) { return v * __builtin_amdgc
 // Global -> LDS of one input window with LDS-DMA (`buffer_load_dwordx4 ... lds`: no VGPR staging).  Every
 // wave-instruction fills 1 KiB of the flat [3][20][136] window; lanes whose float4 lies outside the image (or
 // past the window's 2040 float4) carry an out-of-range offset, which the buffer unit turns into zeros.
+template <int CIN>
 __device__ __forceinline__ void stem_dma(const StemArgs& p, int t, int tid, float* dst) {
   const int tx = t % p.tiles_x;
   const int t2 = t / p.tiles_x;
@@ -68,15 +70,15 @@ __device__ __forceinline__ void stem_dma(const StemArgs& p, int t, int tid, floa
   const int iy0 = 2 * ty * STEM_TH - 2, ix0 = 2 * tx * STEM_TW - 4;
 #if defined(__HIP_DEVICE_COMPILE__)  // device-only builtins; the host pass only needs the kernel stub
   const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<float*>(p.in + (size_t)n * 3 * p.H * p.W), 0, 3 * p.H * p.W * 4, 0x00020000);
+      const_cast<float*>(p.in + (size_t)n * p.planes * p.H * p.W), 0, CIN * p.H * p.W * 4, 0x00020000);
   const int wave = tid >> 6;
 #pragma unroll
-  for (int j = 0; j < STEM_NDMA; ++j) {
+  for (int j = 0; j < stem_ndma(CIN); ++j) {
     const int idx = tid + 256 * j;
     const int rowc = idx / STEM_ROW4, col4 = idx - rowc * STEM_ROW4;   // rowc = c * 20 + row
     const int c = rowc / STEM_IH, row = rowc - c * STEM_IH;
     const int gy = iy0 + row, gx = ix0 + 4 * col4;
-    const bool ok = idx < STEM_TILE4 && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
+    const bool ok = idx < stem_tile4(CIN) && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
     const unsigned off = ok ? (unsigned)(((c * p.H + gy) * p.W + gx) * 4) : 0x80000000u;
     __builtin_amdgcn_raw_ptr_buffer_load_lds(
         rsrc, (__attribute__((address_space(3))) void*)(dst + (j * 256 + wave * 64) * 4), 16, off, 0, 0, 0);
@@ -88,18 +90,19 @@ __device__ __forceinline__ void stem_dma(const StemArgs& p, int t, int tid, floa
 
 // Persistent workgroups (grid = resident slots) with two window buffers: the window of tile t+grid streams into
 // LDS while tile t runs its MFMAs, and the weights are staged once per workgroup instead of once per tile.
-template <int NB, bool VEC>
+template <int NB, bool VEC, int CIN>
 __global__ __launch_bounds__(256, NB == 1 ? 2 : 1) void stem_focus_conv_kernel(const StemArgs p) {
   extern __shared__ float4 stem_smem4[];
   float* smem = reinterpret_cast<float*>(stem_smem4);
-  float* wl = smem + 2 * STEM_BUF;   // [108][NB*32]
+  constexpr int STEM_KP = stem_kp(CIN), STEM_BUF = stem_buf(CIN);
+  float* wl = smem + 2 * STEM_BUF;   // [CIN*36][NB*32]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int half = lane >> 5, l31 = lane & 31;
   const int total = p.N * p.tiles_x * p.tiles_y;
   int t = blockIdx.x;
   if (t >= total) return;   // uniform per workgroup
 
-  stem_dma(p, t, tid, smem);
+  stem_dma<CIN>(p, t, tid, smem);
   for (int idx = tid; idx < 2 * STEM_KP * NB * 32; idx += 256) wl[idx] = p.wgt[idx];
   const float* wbase = wl + half * (NB * 32) + l31;   // B operand of lane = (co = l31, k = 2s + half)
   // operands are swapped (A = weights, B = pixels), so the accumulator is C[co][pixel]: lane = pixel l31 of the
@@ -177,7 +180,7 @@ __global__ __launch_bounds__(256, NB == 1 ? 2 : 1) void stem_focus_conv_kernel(c
   // all groups in the first 16 steps 152 us, separate epilogue phase after the barrier 149 us: VALU work does
   // not co-issue with the wave's own fp32 MFMAs, so bunching it only lengthens the bubbles.
   constexpr int GSTRIDE = STEM_KP / NGROUPS > 0 ? STEM_KP / NGROUPS : 1;   // k-steps between two store groups
-  static_assert(NGROUPS <= STEM_KP, "epilogue groups must fit the k loop");
+  constexpr int GPER = (NGROUPS + STEM_KP - 1) / STEM_KP;                  // groups per k-step when KP < NGROUPS
   auto koff = [](int s) {   // compile-time window offset of k-pair s: k order (c, ky6, kx6), kx6 fastest
     const int c = s / 18, rem = s % 18, ky6 = rem / 3, pp = rem % 3;
     return c * STEM_ICH + ky6 * STEM_IW + 2 * pp;
@@ -185,7 +188,7 @@ __global__ __launch_bounds__(256, NB == 1 ? 2 : 1) void stem_focus_conv_kernel(c
 
   while (true) {
     const int tn = t + gridDim.x;
-    if (tn < total) stem_dma(p, tn, tid, smem + (cur ^ 1) * STEM_BUF);   // lands during the MFMA phase
+    if (tn < total) stem_dma<CIN>(p, tn, tid, smem + (cur ^ 1) * STEM_BUF);   // lands during the MFMA phase
     const float* win = smem + cur * STEM_BUF;
 
     // ---- STEM_WB pixel blocks per wave: rows (WB/2)*wave + (i >> 1), x blocks i & 1.
@@ -219,7 +222,11 @@ __global__ __launch_bounds__(256, NB == 1 ? 2 : 1) void stem_focus_conv_kernel(c
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb)
           acc[i][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[cb][nb], a[cb][i], acc[i][nb], 0, 0, 0);
-      if (s % GSTRIDE == 0 && s / GSTRIDE < NGROUPS) store_group(s / GSTRIDE);
+      if (s % GSTRIDE == 0) {
+#pragma unroll
+        for (int u = 0; u < GPER; ++u)
+          if ((s / GSTRIDE) * GPER + u < NGROUPS) store_group((s / GSTRIDE) * GPER + u);
+      }
       __builtin_amdgcn_sched_barrier(0);
     }
     // next window landed (vmcnt(0)) and every wave is done reading this one
@@ -240,9 +247,12 @@ __global__ __launch_bounds__(256, NB == 1 ? 2 : 1) void stem_focus_conv_kernel(c
 
 }  // namespace
 
-int stem_focus_conv_launch(const float* in, int N, int H, int W, const float* wgt, const float* bias, int Cout,
-                           float* out, int out_ld, int out_off, int act, hipStream_t stream) {
+int stem_focus_conv_launch(const float* in, int N, int H, int W, int used_planes, const float* wgt,
+                           const float* bias, int Cout, float* out, int out_ld, int out_off, int act,
+                           hipStream_t stream) {
   ST_REQUIRE(in && wgt && bias && out, "stem_focus_conv: null pointer");
+  ST_REQUIRE(used_planes == 3 || used_planes == 1, "stem_focus_conv: used_planes must be 3 or 1 (got %d)",
+             used_planes);
   ST_REQUIRE(N > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 4 == 0,
              "stem_focus_conv: H must be even and W a multiple of 4 (got %dx%d)", H, W);
   ST_REQUIRE((long long)3 * H * W * 4 < (1ll << 31), "stem_focus_conv: image exceeds 2 GiB");
@@ -252,12 +262,13 @@ int stem_focus_conv_launch(const float* in, int N, int H, int W, const float* wg
   StemArgs a;
   a.in = in; a.wgt = wgt; a.bias = bias; a.out = out;
   a.N = N; a.H = H; a.W = W; a.Ho = H / 2; a.Wo = W / 2; a.Cout = Cout; a.CoutPad = round_up(Cout, 32);
-  a.out_ld = out_ld; a.out_off = out_off; a.act = act;
+  a.out_ld = out_ld; a.out_off = out_off; a.act = act; a.planes = 3;
   a.tiles_x = ceil_div(a.Wo, STEM_TW); a.tiles_y = ceil_div(a.Ho, STEM_TH);
   const long long tiles = (long long)N * a.tiles_x * a.tiles_y;
   ST_REQUIRE(tiles < (1ll << 30), "stem_focus_conv: too many tiles");
   const int nb = a.CoutPad / 32;
-  const size_t lds = (size_t)(2 * STEM_BUF + 2 * STEM_KP * nb * 32) * sizeof(float);   // 79.4 KB / 93.2 KB
+  const size_t lds = (size_t)(2 * stem_buf(used_planes) + 2 * stem_kp(used_planes) * nb * 32) * sizeof(float);
+  // 3 planes: 79.4 KB (Cout <= 32) / 93.2 KB; 1 plane: 28.8 KB / 33.4 KB
   // persistent workgroups: as many as fit a CU's 160 KB of LDS (2 for Cout <= 32), each walks t, t + grid, ...
   static int cus = 0;
   if (!cus) {
@@ -271,16 +282,19 @@ int stem_focus_conv_launch(const float* in, int N, int H, int W, const float* wg
   a.out_bytes = (unsigned)out_bytes;
   const bool vec = ((out_ld | out_off | Cout) & 3) == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0;
   using Kern = void (*)(const StemArgs);
-  static const Kern kerns[4] = {stem_focus_conv_kernel<1, false>, stem_focus_conv_kernel<1, true>,
-                                stem_focus_conv_kernel<2, false>, stem_focus_conv_kernel<2, true>};
-  const int ki = (nb - 1) * 2 + (vec ? 1 : 0);
-  static bool attr_set[4] = {false, false, false, false};
+  static const Kern kerns[8] = {stem_focus_conv_kernel<1, false, 3>, stem_focus_conv_kernel<1, true, 3>,
+                                stem_focus_conv_kernel<2, false, 3>, stem_focus_conv_kernel<2, true, 3>,
+                                stem_focus_conv_kernel<1, false, 1>, stem_focus_conv_kernel<1, true, 1>,
+                                stem_focus_conv_kernel<2, false, 1>, stem_focus_conv_kernel<2, true, 1>};
+  const int ki = (used_planes == 1 ? 4 : 0) + (nb - 1) * 2 + (vec ? 1 : 0);
+  static bool attr_set[8] = {false, false, false, false, false, false, false, false};
   if (!attr_set[ki]) {
     ST_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kerns[ki]),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_set[ki] = true;
   }
-  const int per_cu = (int)((160 * 1024) / lds);
+  // resident workgroups per CU: LDS, and 2 waves per SIMD (NB = 1) / 1 (NB = 2) by registers
+  const int per_cu = std::min((int)((160 * 1024) / lds), nb == 1 ? 2 : 1);
   const unsigned grid = (unsigned)std::min<long long>(tiles, (long long)cus * per_cu);
   hipLaunchKernelGGL(kerns[ki], dim3(grid), dim3(256), lds, stream, a);
   ST_CHECK_HIP(hipGetLastError());
@@ -290,21 +304,24 @@ int stem_focus_conv_launch(const float* in, int N, int H, int W, const float* wg
 }  // namespace st
 
 extern "C" size_t st_stem_packed_floats(int Cout) {
-  return Cout > 0 ? (size_t)2 * st::STEM_KP * st::round_up(Cout, 32) : 0;
+  return Cout > 0 ? (size_t)2 * st::stem_kp(3) * st::round_up(Cout, 32) : 0;
 }
 
 // w: the stem ConvModule's conv weight [Cout][12][3][3] (channels in Focus order), optional conv bias, optional
-// BatchNorm running statistics (folded in fp64 exactly like st_conv_pack_weights).
+// BatchNorm running statistics (folded in fp64 exactly like st_conv_pack_weights).  used_planes = 1 packs the
+// sum over the three image planes of every tap (36 x Cout): exact when the caller guarantees that the three
+// planes of the image are identical (the disparity input, a 3-channel repeat of one map).
 extern "C" int st_stem_pack_weights(const float* w, const float* conv_bias, const float* bn_gamma,
                                     const float* bn_beta, const float* bn_mean, const float* bn_var, double bn_eps,
-                                    int Cout, float* wgt_out, float* bias_out) {
-  if (!w || !wgt_out || !bias_out || Cout <= 0 || Cout > 64)
+                                    int Cout, int used_planes, float* wgt_out, float* bias_out) {
+  if (!w || !wgt_out || !bias_out || Cout <= 0 || Cout > 64 || (used_planes != 3 && used_planes != 1))
     return st::set_error(ST_ERR_INVALID, "st_stem_pack_weights: bad argument");
   const bool has_bn = bn_gamma != nullptr;
   if (has_bn && (!bn_beta || !bn_mean || !bn_var))
     return st::set_error(ST_ERR_INVALID, "st_stem_pack_weights: incomplete BN parameters");
   const int CoutPad = st::round_up(Cout, 32);
-  std::memset(wgt_out, 0, sizeof(float) * (size_t)2 * st::STEM_KP * CoutPad);
+  std::memset(wgt_out, 0, sizeof(float) * (size_t)2 * st::stem_kp(3) * CoutPad);
+  std::vector<double> accum((size_t)36 * (used_planes == 1 ? 1 : 3), 0.0);
   std::memset(bias_out, 0, sizeof(float) * (size_t)CoutPad);
   for (int co = 0; co < Cout; ++co) {
     double scale = 1.0, shift = conv_bias ? (double)conv_bias[co] : 0.0;
@@ -314,22 +331,23 @@ extern "C" int st_stem_pack_weights(const float* w, const float* conv_bias, cons
       shift = (double)bn_beta[co] + (shift - (double)bn_mean[co]) * inv;
     }
     bias_out[co] = (float)shift;
+    std::fill(accum.begin(), accum.end(), 0.0);
     for (int c = 0; c < 3; ++c)
       for (int ky6 = 0; ky6 < 6; ++ky6)
         for (int kx6 = 0; kx6 < 6; ++kx6) {
           const int ky = ky6 >> 1, dy = ky6 & 1, kx = kx6 >> 1, dx = kx6 & 1;
           const int cf = (dy + 2 * dx) * 3 + c;  // Focus channel: TL, BL, TR, BR groups of 3
           const double v = (double)w[(((size_t)co * 12 + cf) * 3 + ky) * 3 + kx] * scale;
-          const int k = (c * 6 + ky6) * 6 + kx6;
-          wgt_out[(size_t)k * CoutPad + co] = (float)v;
+          accum[(size_t)((used_planes == 1 ? 0 : c) * 6 + ky6) * 6 + kx6] += v;   // fp64 sum, rounded once
         }
+    for (size_t k = 0; k < accum.size(); ++k) wgt_out[k * CoutPad + co] = (float)accum[k];
   }
   return ST_OK;
 }
 
-extern "C" int st_stem_focus_conv(const float* img_dev, int N, int H, int W, const float* wgt_dev,
-                                  const float* bias_dev, int Cout, float* out_dev, int out_ld, int out_off, int act,
-                                  st_stream_t stream) {
-  return st::stem_focus_conv_launch(img_dev, N, H, W, wgt_dev, bias_dev, Cout, out_dev, out_ld, out_off, act,
-                                    static_cast<hipStream_t>(stream));
+extern "C" int st_stem_focus_conv(const float* img_dev, int N, int H, int W, int used_planes,
+                                  const float* wgt_dev, const float* bias_dev, int Cout, float* out_dev, int out_ld,
+                                  int out_off, int act, st_stream_t stream) {
+  return st::stem_focus_conv_launch(img_dev, N, H, W, used_planes, wgt_dev, bias_dev, Cout, out_dev, out_ld, out_off,
+                                    act, static_cast<hipStream_t>(stream));
 }

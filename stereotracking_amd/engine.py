@@ -30,13 +30,17 @@ class HipDetector:
     """
 
     def __init__(self, batch, height, width, widen_factor=0.5, deepen_factor=0.33, num_classes=1,
-                 bn_eps=1e-3, stereo=False):
+                 bn_eps=1e-3, stereo=False, disp_replicated=None):
+        """disp_replicated: the three planes of disp_postp are identical (a 3-channel repeat of one map), so the
+        disparity stem may read plane 0 with plane-summed weights.  Default: True for stereo contexts (the
+        disparity then comes from st_disp_upsample_pack, which writes exactly that), False otherwise."""
         self.lib = _lib.load()
         self.batch, self.height, self.width = int(batch), int(height), int(width)
         self.stereo = bool(stereo)
+        self.disp_replicated = self.stereo if disp_replicated is None else bool(disp_replicated)
         cfg = StDetectorConfig(C.sizeof(StDetectorConfig), float(widen_factor), float(deepen_factor),
                                int(num_classes), self.batch, self.height, self.width, float(bn_eps),
-                               int(self.stereo))
+                               int(self.stereo), int(self.disp_replicated))
         h = C.c_void_p()
         check(self.lib.st_detector_create(C.byref(cfg), C.byref(h)), 'st_detector_create')
         self.handle = h

@@ -207,28 +207,32 @@ def test_spp_pool_matches_torch_maxpool(N, H, W, Cc, cuda):
     assert torch.equal(out.cpu(), ref)
 
 
+@pytest.mark.parametrize('planes', [3, 1])
 @pytest.mark.parametrize('N,H,W,cout,act', [(2, 64, 96, 32, 1), (1, 50, 264, 24, 1), (1, 16, 136, 64, 0),
                                             (3, 34, 36, 8, 1), (40, 32, 128, 32, 1)])
-def test_fused_focus_stem_matches_torch(N, H, W, cout, act, cuda):
+def test_fused_focus_stem_matches_torch(N, H, W, cout, act, planes, cuda):
     """st_stem_focus_conv == Focus slicing (TL, BL, TR, BR) -> 3x3/s1/p1 conv -> BN (running stats) -> SiLU of
     the reference stem (csp_darknet_disparity_v1.py:104-111), including ragged tiles (H/2, W/2 not multiples of
     the 8 x 64 tile), Cout < 32 (padding lanes must not be stored), Cout = 64 (two MFMA column blocks), an
-    output slice of a wider buffer, and more tiles than persistent workgroups (N = 40: 640 tiles > 512 slots)."""
+    output slice of a wider buffer, and more tiles than persistent workgroups (N = 40: 640 tiles > 512 slots).
+    planes = 1: identical image planes, plane-summed weights, K = 36."""
     lib = _lib.load()
     torch.manual_seed(20 + cout)
     x = torch.rand(N, 3, H, W) * 255.0
+    if planes == 1:   # the disparity input: a 3-channel repeat of one map; planes 1, 2 are never read
+        x = x[:, :1].repeat(1, 3, 1, 1).contiguous()
     w = torch.randn(cout, 12, 3, 3) / 200.0
     gamma, beta = torch.rand(cout) + 0.5, torch.randn(cout) * 0.2
     mean, var = torch.randn(cout) * 0.5, torch.rand(cout) + 0.5
     eps = 1e-3
     wp = torch.empty(lib.st_stem_packed_floats(cout), dtype=torch.float32)
     bp = torch.empty((cout + 31) // 32 * 32, dtype=torch.float32)
-    check(lib.st_stem_pack_weights(ptr(w), None, ptr(gamma), ptr(beta), ptr(mean), ptr(var), eps, cout, ptr(wp),
-                                   ptr(bp)))
+    check(lib.st_stem_pack_weights(ptr(w), None, ptr(gamma), ptr(beta), ptr(mean), ptr(var), eps, cout, planes,
+                                   ptr(wp), ptr(bp)))
     xd, wd, bd = x.to(cuda), wp.to(cuda), bp.to(cuda)
     ld, off = cout + 8, 4
     out = torch.full((N, H // 2, W // 2, ld), -777.0, device=cuda)
-    check(lib.st_stem_focus_conv(ptr(xd), N, H, W, ptr(wd), ptr(bd), cout, ptr(out), ld, off, act, None))
+    check(lib.st_stem_focus_conv(ptr(xd), N, H, W, planes, ptr(wd), ptr(bd), cout, ptr(out), ld, off, act, None))
     torch.cuda.synchronize()
     xx = x.double()
     foc = torch.cat((xx[..., ::2, ::2], xx[..., 1::2, ::2], xx[..., ::2, 1::2], xx[..., 1::2, 1::2]), dim=1)
@@ -247,8 +251,9 @@ def test_fused_stem_rejects_bad_arguments(cuda):
     x = torch.zeros(1, 3, 32, 32, device=cuda)
     o = torch.zeros(1, 16, 16, 80, device=cuda)
     w = torch.zeros(lib.st_stem_packed_floats(32), device=cuda)
-    assert lib.st_stem_focus_conv(ptr(x), 1, 31, 32, ptr(w), ptr(w), 32, ptr(o), 32, 0, 1, None) != 0   # odd H
-    assert lib.st_stem_focus_conv(ptr(x), 1, 30, 30, ptr(w), ptr(w), 32, ptr(o), 32, 0, 1, None) != 0   # W % 4
-    assert lib.st_stem_focus_conv(ptr(x), 1, 30, 32, ptr(w), ptr(w), 80, ptr(o), 80, 0, 1, None) != 0   # Cout > 64
-    assert lib.st_stem_focus_conv(ptr(x), 1, 30, 32, ptr(w), ptr(w), 32, ptr(o), 32, 8, 1, None) != 0   # slice > ld
+    assert lib.st_stem_focus_conv(ptr(x), 1, 31, 32, 3, ptr(w), ptr(w), 32, ptr(o), 32, 0, 1, None) != 0   # odd H
+    assert lib.st_stem_focus_conv(ptr(x), 1, 30, 30, 3, ptr(w), ptr(w), 32, ptr(o), 32, 0, 1, None) != 0   # W % 4
+    assert lib.st_stem_focus_conv(ptr(x), 1, 30, 32, 3, ptr(w), ptr(w), 80, ptr(o), 80, 0, 1, None) != 0   # Cout > 64
+    assert lib.st_stem_focus_conv(ptr(x), 1, 30, 32, 3, ptr(w), ptr(w), 32, ptr(o), 32, 8, 1, None) != 0   # slice > ld
+    assert lib.st_stem_focus_conv(ptr(x), 1, 32, 32, 2, ptr(w), ptr(w), 32, ptr(o), 32, 0, 1, None) != 0   # planes
     assert b'stem_focus_conv' in lib.st_last_error()
