@@ -17,6 +17,7 @@
 // (max, sum e, sum d*e) of the 4 disparity groups are merged with wavefront shuffles
 // (__shfl_xor 16, 32), so the D x H x W volume is only written when the caller asks for it.
 #include <algorithm>
+#include <cstdint>
 
 #include "st_common.h"
 
@@ -131,6 +132,186 @@ __global__ __launch_bounds__(256) void costvolume_kernel(const float* __restrict
   if (dg == 0 && x < Wf && out_disp) out_disp[rowbase + x] = t / s;
 }
 
+// Register-tiled correlation: lane = 4 CONSECUTIVE pixels x DG disparities.  cost[x+p][d0+k] needs R[x+p-d0-k]:
+// for the lane's 4 x DG outputs that is one window of DG+3 consecutive R columns per channel, so a channel step
+// costs 1 + (DG+4)/4 ds_read_b128 for 4*DG FMAs (DG = 12: 5 reads per 48 FMAs; the one-pixel kernel above needs
+// 13 ds_read_b32 per 12 FMAs and is LDS-bandwidth bound).  Same c-ascending fmaf chain per output => the volume
+// stays bit-identical to the oracle.  Workgroup = 2 waves = 128 pixels of one feature row; channels are staged
+// in chunks of CVT_CC (transposed [c][x], float4-aligned rows with an odd float4 stride: conflict-free b128
+// reads AND conflict-free transposing writes with the lane = (16 pixels x 4 channel-quads) staging order).
+constexpr int CVT_TX = 128;   // pixels per workgroup
+constexpr int CVT_CC = 16;    // channels per staging chunk (two LDS buffers)
+static inline int cvt_row(int n) {  // >= n, multiple of 4, (row / 4) odd
+  int r = (n + 3) & ~3;
+  if (((r >> 2) & 1) == 0) r += 4;
+  return r;
+}
+
+template <int DG>
+__global__ __launch_bounds__(128) void costvolume_tiled_kernel(const float* __restrict__ featL,
+                                                               const float* __restrict__ featR, int Hf, int Wf,
+                                                               int C, int ld, int D, float temperature, int rowL,
+                                                               int rowR, float* __restrict__ out_cost,
+                                                               float* __restrict__ out_disp) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int bufsz = CVT_CC * (rowL + rowR);   // two buffers: [CVT_CC][rowL] + [CVT_CC][rowR] each
+  const int x0 = blockIdx.x * CVT_TX;
+  const int y = blockIdx.y, n = blockIdx.z;
+  const size_t rowbase = ((size_t)n * Hf + y) * Wf;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int dg = lane >> 4, pgi = lane & 15;
+  const int px0 = wave * 64 + 4 * pgi;   // first of this lane's 4 pixels (block-relative)
+  const int d0 = dg * DG;
+  constexpr int NW = DG + 4;             // floats of the R window: x' = x - d0 - DG + i, i = 0 .. DG+3
+  constexpr int RW = CVT_TX + 4 * DG;    // R columns of the block: column j <-> x' = x0 - 4*DG + j
+  constexpr int RW16 = (RW + 15) & ~15;
+  constexpr int CC4 = CVT_CC / 4;
+  constexpr int NL = CVT_TX * CC4 / 128, NR = (RW16 * CC4 + 127) / 128;   // float4 per thread per chunk
+
+  float acc[4][DG];
+#pragma unroll
+  for (int p = 0; p < 4; ++p)
+#pragma unroll
+    for (int k = 0; k < DG; ++k) acc[p][k] = 0.f;
+
+  // Staging of one channel chunk, transposed to [c][x].  Lane order: 16 consecutive lanes = 16 consecutive
+  // pixels of one channel quad (conflict-free transposing LDS writes with rows of 4 * odd floats).  The global
+  // loads of chunk i+1 are issued BEFORE the FMAs of chunk i and stored to the other LDS buffer after them:
+  // a load -> LDS-store loop serialises one HBM/L2 round trip per iteration, and that latency chain (not LDS
+  // bandwidth) is what bounded the one-pixel kernel above.
+  f32x4 stL[NL], stR[NR];
+  auto stage_load = [&](int cb) {
+    const int cc4 = min(CVT_CC, C - cb) >> 2;
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+      const int e = tid + 128 * i;
+      const int px = (e & 15) + 16 * (e / (16 * CC4)), c4 = (e >> 4) % CC4;
+      const int x = x0 + px;
+      stL[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (c4 < cc4 && x < Wf) stL[i] = *reinterpret_cast<const f32x4*>(featL + (rowbase + x) * ld + cb + 4 * c4);
+    }
+#pragma unroll
+    for (int i = 0; i < NR; ++i) {
+      const int e = tid + 128 * i;
+      const int j = (e & 15) + 16 * (e / (16 * CC4)), c4 = (e >> 4) % CC4;
+      const int x = x0 - 4 * DG + j;
+      stR[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (c4 < cc4 && j < RW && x >= 0 && x < Wf)
+        stR[i] = *reinterpret_cast<const f32x4*>(featR + (rowbase + x) * ld + cb + 4 * c4);
+    }
+  };
+  auto stage_store = [&](int buf) {
+    float* Ls = smem + buf * bufsz;
+    float* Rs = Ls + CVT_CC * rowL;
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+      const int e = tid + 128 * i;
+      const int px = (e & 15) + 16 * (e / (16 * CC4)), c4 = (e >> 4) % CC4;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) Ls[(4 * c4 + k) * rowL + px] = stL[i][k];
+    }
+#pragma unroll
+    for (int i = 0; i < NR; ++i) {
+      const int e = tid + 128 * i;
+      const int j = (e & 15) + 16 * (e / (16 * CC4)), c4 = (e >> 4) % CC4;
+      if (j < rowR) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) Rs[(4 * c4 + k) * rowR + j] = stR[i][k];
+      }
+    }
+  };
+
+  stage_load(0);
+  stage_store(0);
+  __syncthreads();
+  int buf = 0;
+  for (int cb = 0; cb < C; cb += CVT_CC, buf ^= 1) {
+    const int cc = min(CVT_CC, C - cb);
+    const bool more = cb + CVT_CC < C;
+    if (more) stage_load(cb + CVT_CC);   // in flight during the FMAs below
+    const float* lp = smem + buf * bufsz + px0;
+    const float* rp = smem + buf * bufsz + CVT_CC * rowL + px0 + 4 * DG - d0 - DG;   // window start (multiple of 4)
+    // ---- accumulate this chunk, operands of channel c+1 prefetched while channel c multiplies
+    f32x4 lv[2], rv[2][NW / 4];
+    lv[0] = *reinterpret_cast<const f32x4*>(lp);
+#pragma unroll
+    for (int q = 0; q < NW / 4; ++q) rv[0][q] = *reinterpret_cast<const f32x4*>(rp + 4 * q);
+    for (int c = 0; c < cc; c += 2) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int cn = c + h + 1;
+        if (cn < cc) {
+          lv[h ^ 1] = *reinterpret_cast<const f32x4*>(lp + cn * rowL);
+#pragma unroll
+          for (int q = 0; q < NW / 4; ++q) rv[h ^ 1][q] = *reinterpret_cast<const f32x4*>(rp + cn * rowR + 4 * q);
+        }
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+#pragma unroll
+          for (int k = 0; k < DG; ++k) {
+            const int i = DG + p - k;   // window index of x + p - d0 - k
+            acc[p][k] = fmaf(lv[h][p], rv[h][i >> 2][i & 3], acc[p][k]);
+          }
+      }
+    }
+    if (more) stage_store(buf ^ 1);
+    __syncthreads();
+  }
+
+  // ---- cost = acc / C (0 where the match falls left of the image), optional volume store, fused soft-argmin
+  const float fC = (float)C;
+  const bool pow2 = (C & (C - 1)) == 0;   // then x * (1/C) == x / C exactly (no subnormal results here)
+  const float rC = 1.0f / fC;
+  float m[4], s[4], t[4];
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    const int x = x0 + px0 + p;
+    m[p] = -__builtin_inff();
+#pragma unroll
+    for (int k = 0; k < DG; ++k) {
+      const int d = d0 + k;
+      float cst = pow2 ? acc[p][k] * rC : acc[p][k] / fC;
+      if (x - d < 0) cst = 0.f;
+      acc[p][k] = cst;
+      if (d < D) m[p] = fmaxf(m[p], temperature * cst);
+    }
+    if (out_cost && x < Wf) {
+      float* oc = out_cost + (rowbase + x) * (size_t)D + d0;
+      if ((D & 3) == 0 && d0 + DG <= D) {
+#pragma unroll
+        for (int q = 0; q < DG / 4; ++q) {
+          const f32x4 v = {acc[p][4 * q], acc[p][4 * q + 1], acc[p][4 * q + 2], acc[p][4 * q + 3]};
+          *reinterpret_cast<f32x4*>(oc + 4 * q) = v;
+        }
+      } else {
+#pragma unroll
+        for (int k = 0; k < DG; ++k)
+          if (d0 + k < D) oc[k] = acc[p][k];
+      }
+    }
+  }
+  if (!out_disp) return;   // uniform
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    m[p] = fmaxf(m[p], __shfl_xor(m[p], 16));
+    m[p] = fmaxf(m[p], __shfl_xor(m[p], 32));
+    s[p] = 0.f; t[p] = 0.f;
+#pragma unroll
+    for (int k = 0; k < DG; ++k) {
+      const int d = d0 + k;
+      if (d < D) {
+        const float e = cv_expf(temperature * acc[p][k] - m[p]);
+        s[p] += e;
+        t[p] = fmaf((float)d, e, t[p]);
+      }
+    }
+    s[p] += __shfl_xor(s[p], 16); t[p] += __shfl_xor(t[p], 16);
+    s[p] += __shfl_xor(s[p], 32); t[p] += __shfl_xor(t[p], 32);
+    const int x = x0 + px0 + p;
+    if (dg == 0 && x < Wf) out_disp[rowbase + x] = t[p] / s[p];
+  }
+}
+
 __global__ __launch_bounds__(256) void softargmin_kernel(const float* __restrict__ cost, long long npix, int D,
                                                          float temperature, float* __restrict__ out_disp) {
   for (long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x; p < npix;
@@ -240,10 +421,38 @@ extern "C" int st_costvolume_softargmin(const float* featL_dev, const float* fea
              "st_costvolume_softargmin: C and feat_ld must be positive multiples of 4");
   ST_REQUIRE(D > 0 && D <= 4 * CV_MAXDG, "st_costvolume_softargmin: D must be in [1, %d]", 4 * CV_MAXDG);
   ST_REQUIRE(Hf <= 65535 && N <= 65535, "st_costvolume_softargmin: grid too large");
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  // register-tiled kernel: DG (disparities per lane, 4 lanes share a pixel quad) a multiple of 4, up to 32
+  const int dgt = round_up((D + 3) / 4, 4);
+  if (dgt <= 32 && (out_cost_dev == nullptr || (reinterpret_cast<uintptr_t>(out_cost_dev) & 15) == 0)) {
+    const int rowLt = cvt_row(CVT_TX), rowRt = cvt_row(CVT_TX + 4 * dgt);
+    const size_t ldst = (size_t)2 * CVT_CC * (rowLt + rowRt) * sizeof(float);
+    const dim3 gridt((Wf + CVT_TX - 1) / CVT_TX, Hf, N), blockt(128);
+#define ST_CVT_LAUNCH(DGV)                                                                                    \
+  do {                                                                                                         \
+    auto kern = costvolume_tiled_kernel<DGV>;                                                                  \
+    ST_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                                      \
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldst));                  \
+    hipLaunchKernelGGL(kern, gridt, blockt, ldst, stream, featL_dev, featR_dev, Hf, Wf, C, feat_ld, D,         \
+                       temperature, rowLt, rowRt, out_cost_dev, out_disp_dev);                                 \
+  } while (0)
+    switch (dgt) {
+      case 4: ST_CVT_LAUNCH(4); break;
+      case 8: ST_CVT_LAUNCH(8); break;
+      case 12: ST_CVT_LAUNCH(12); break;
+      case 16: ST_CVT_LAUNCH(16); break;
+      case 20: ST_CVT_LAUNCH(20); break;
+      case 24: ST_CVT_LAUNCH(24); break;
+      case 28: ST_CVT_LAUNCH(28); break;
+      default: ST_CVT_LAUNCH(32); break;
+    }
+#undef ST_CVT_LAUNCH
+    ST_CHECK_HIP(hipGetLastError());
+    return ST_OK;
+  }
   const int rowL = row_len(CV_TX), rowR = row_len(CV_TX + D - 1);
   const size_t lds = (size_t)C * (rowL + rowR) * sizeof(float);
   ST_REQUIRE(lds <= 160 * 1024, "st_costvolume_softargmin: C=%d, D=%d needs %zu B of LDS (> 160 KiB)", C, D, lds);
-  hipStream_t stream = static_cast<hipStream_t>(stream_);
   const dim3 grid((Wf + CV_TX - 1) / CV_TX, Hf, N), block(256);
   const int DG = (D + 3) / 4;
 #define ST_CV_LAUNCH(DGV)                                                                                      \

@@ -1,0 +1,30 @@
+#!/usr/bin/env python
+"""Micro-benchmark of the cost-volume kernel on the bench geometry (8 x 184 x 320 x 64 ch features, 48 levels)."""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from stereotracking_amd import _lib  # noqa: E402
+from stereotracking_amd._lib import check, ptr  # noqa: E402
+
+lib = _lib.load()
+N, Hf, Wf, C, D = 8, 184, 320, 64, 48
+dev = torch.device('cuda:0')
+fl = torch.randn(N, Hf, Wf, C, device=dev)
+fr = torch.randn(N, Hf, Wf, C, device=dev)
+cost = torch.empty(N, Hf, Wf, D, device=dev)
+disp = torch.empty(N, Hf, Wf, device=dev)
+reps = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+for name, oc, od in (('volume only', cost, None), ('fused soft-argmin only', None, disp), ('both', cost, disp)):
+    for _ in range(3):
+        check(lib.st_costvolume_softargmin(ptr(fl), ptr(fr), N, Hf, Wf, C, C, D, 32.0, ptr(oc), ptr(od), None))
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        check(lib.st_costvolume_softargmin(ptr(fl), ptr(fr), N, Hf, Wf, C, C, D, 32.0, ptr(oc), ptr(od), None))
+    e1.record()
+    torch.cuda.synchronize()
+    print(f'costvolume ({name}): {e0.elapsed_time(e1) / reps * 1e3:.1f} us')
