@@ -103,6 +103,7 @@ def conv_roofline(pipe, img, right, steps):
     Hf, Wf = pipe.height // pipe.feat_stride, pipe.width // pipe.feat_stride
     agg_macs = sm.agg_macs(pipe.batch, Hf, Wf)   # per aggregation layer
     VARIANT_TILES = {v: lib.st_conv_variant_name(v).decode() for v in range(64)}
+    VARIANT_TILES[-1] = 'skipped'
     per_variant = {}
     for v in sorted(set(var[kind == 1].tolist()) | set(agg)):
         sel = (kind == 1) & (var == v)
@@ -265,6 +266,8 @@ def main():
     for _ in range(args.warmup):
         out = step()
     torch.cuda.synchronize()
+    if os.environ.get('ST_SKIP_AFTER_WARMUP'):   # timing-only ablation (tools): the buffers keep their valid warm-up contents
+        os.environ['ST_SKIP_OPS'] = os.environ['ST_SKIP_AFTER_WARMUP']
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()

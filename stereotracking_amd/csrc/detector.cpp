@@ -31,6 +31,7 @@
 namespace st {
 
 int conv2d_launch(const StConvDesc& d, hipStream_t stream, int force_variant, int* picked_variant);
+bool pw_conv_applicable(const StConvDesc& d);
 int conv_variant_count();
 bool conv_variant_valid(int id, int cout);
 const char* conv_variant_name(int id);
@@ -644,7 +645,12 @@ int run_ops(StDetector* det, int phase_lo, int phase_hi, const float* const inpu
       for (size_t k = oi; k < oe; ++k) {
         Op& o = det->ops[k];
         if (det->timing) ST_CHECK_HIP(hipEventRecord(det->events[ev_per_op * k + 2 * sbi], stream));
-        ST_CHECK(launch_op(det, o, sbi * g.sb, inputs, ws, head, stream));
+        // timing-only ablation (results are garbage): ST_SKIP_OPS="3,4,6" drops those launches to bound what a
+        // faster kernel for them could buy
+        const char* skip_env = getenv("ST_SKIP_OPS");   // read per launch: the bench flips it after the warm-up
+        const std::string skip(skip_env ? skip_env : "");
+        const bool skipped = !skip.empty() && ("," + skip + ",").find("," + std::to_string(k) + ",") != std::string::npos;
+        if (!skipped) ST_CHECK(launch_op(det, o, sbi * g.sb, inputs, ws, head, stream));
         if (det->timing) ST_CHECK_HIP(hipEventRecord(det->events[ev_per_op * k + 2 * sbi + 1], stream));
       }
     }
@@ -759,8 +765,22 @@ extern "C" int st_detector_autotune(StDetector* det, void* workspace_dev, size_t
     int best_v = -1;
     // candidates: every staged variant; the wave-specialised ones (>= 22) measured slower on every layer
     // shape of this network and are left out of the search
-    for (int v = 0; v < std::min(conv_variant_count(), 22) && rc == ST_OK; ++v) {
-      if (!conv_variant_valid(v, det->convs[saved[oi].pc].cout)) continue;
+    // + variant 41, the streaming 1x1 kernel (pointwise_conv.hip), where the layer shape allows it
+    const Op& so = saved[oi];
+    StConvDesc probe{};
+    probe.in_dev = static_cast<float*>(workspace_dev);   // alignment / size checks only
+    probe.N = so.in.N; probe.Hi = so.in.H; probe.Wi = so.in.W; probe.Cin = det->convs[so.pc].cin;
+    probe.in_ld = so.in.ld; probe.in_off = so.in.off; probe.Cout = det->convs[so.pc].cout;
+    probe.KH = probe.KW = det->convs[so.pc].k; probe.stride = so.stride; probe.pad = so.pad;
+    probe.out1_ld = so.out1.ld;
+    probe.out2_dev = so.out2.valid() ? static_cast<float*>(workspace_dev) : nullptr; probe.out2_ld = so.out2.ld;
+    probe.res_dev = so.res.valid() ? probe.in_dev : nullptr; probe.res_ld = so.res.ld;
+    probe.up_dev = so.up.valid() ? static_cast<float*>(workspace_dev) : nullptr;
+    const bool pw_ok = pw_conv_applicable(probe);
+    const int ncand = std::min(conv_variant_count(), 22);
+    for (int vi = 0; vi <= ncand && rc == ST_OK; ++vi) {
+      const int v = vi < ncand ? vi : 41;
+      if (v == 41 ? !pw_ok : !conv_variant_valid(v, det->convs[saved[oi].pc].cout)) continue;
       det->force_variant = v;
       rc = run_ops(det, 0, 0, inputs, static_cast<float*>(workspace_dev), head_out_dev, stream);  // warm
       if (rc != ST_OK) break;
@@ -792,9 +812,12 @@ extern "C" int st_detector_autotune(StDetector* det, void* workspace_dev, size_t
 }
 
 // id 40 = the fused Focus+stem kernel (stem_focus_conv.hip), reported with the conv ops
-extern "C" const char* st_conv_variant_name(int id) { return id == 40 ? "stem6x6s2" : conv_variant_name(id); }
+// id 41 = the streaming 1x1 kernel for narrow layers (pointwise_conv.hip)
+extern "C" const char* st_conv_variant_name(int id) {
+  return id == 40 ? "stem6x6s2" : id == 41 ? "pw128" : conv_variant_name(id);
+}
 extern "C" const char* st_conv_variant_signature(int id) {
-  return id == 40 ? "stem_focus_conv" : conv_variant_signature(id);
+  return id == 40 ? "stem_focus_conv" : id == 41 ? "pw_conv" : conv_variant_signature(id);
 }
 
 // Read / restore the per-op tile choice (one int per op, -1 = heuristic) so a tuning result can be
@@ -812,6 +835,7 @@ extern "C" int st_detector_set_tuning(StDetector* det, const int* variants, int 
   for (int i = 0; i < n; ++i) {
     const Op& o = det->ops[i];
     if (variants[i] < 0 || o.type != Op::CONV) continue;
+    if (variants[i] == 41) continue;   // streaming 1x1 kernel: its own applicability check runs at launch
     ST_REQUIRE(conv_variant_valid(variants[i], det->convs[o.pc].cout), "st_detector_set_tuning: variant %d invalid for op %d",
                variants[i], i);
   }

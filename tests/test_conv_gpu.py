@@ -257,3 +257,40 @@ def test_fused_stem_rejects_bad_arguments(cuda):
     assert lib.st_stem_focus_conv(ptr(x), 1, 30, 32, 3, ptr(w), ptr(w), 32, ptr(o), 32, 8, 1, None) != 0   # slice > ld
     assert lib.st_stem_focus_conv(ptr(x), 1, 32, 32, 2, ptr(w), ptr(w), 32, ptr(o), 32, 0, 1, None) != 0   # planes
     assert b'stem_focus_conv' in lib.st_last_error()
+
+
+@pytest.mark.parametrize('cin,cout,split,res,act,shape,in_ld,in_off', [
+    (64, 64, 32, False, 1, (2, 23, 41), None, 0),     # CSP main+short conv: split outputs, ragged last tile
+    (64, 64, None, True, 1, (1, 40, 67), None, 0),    # CSP final conv of the disparity branch: (a + res) * 0.5
+    (32, 32, None, False, 1, (3, 17, 33), 64, 32),    # bottleneck conv1 reading a channel slice of a wider buffer
+    (64, 24, None, False, 0, (1, 9, 130), None, 0),   # Cout < 32 (padded MFMA rows must not be stored), no act
+    (32, 64, 40, True, 1, (1, 31, 29), None, 0),      # split not on a 32 boundary (both outputs inside one block)
+    (64, 64, None, False, 1, (70, 32, 32), None, 0),  # 560 tiles > 512 persistent workgroups
+])
+def test_pointwise_streaming_kernel_matches_torch(cin, cout, split, res, act, shape, in_ld, in_off, cuda):
+    """Tile variant 41 (pointwise_conv.hip) == the generic conv semantics on 1x1 layers: bias, SiLU,
+    (v + res) * post_scale, split outputs, channel-offset input / output slices, ragged tiles."""
+    torch.manual_seed(cin + cout + shape[1])
+    N, H, W = shape
+    x = torch.randn(N, cin, H, W)
+    w = torch.randn(cout, cin, 1, 1) / (cin ** 0.5)
+    b = torch.randn(cout)
+    r = torch.randn(N, cout, H, W) if res else None
+    got, _ = run_conv(x, w, b, 1, 0, act, cuda, variant=41, res=r, post_scale=0.5 if res else 1.0, split=split,
+                      in_ld=in_ld, in_off=in_off)
+    assert_close(got, ref_conv(x, w, b, 1, 0, act, r, 0.5 if res else 1.0))
+    # and bit-for-bit deterministic against itself across launches (persistent tiles, no atomics)
+    again, _ = run_conv(x, w, b, 1, 0, act, cuda, variant=41, res=r, post_scale=0.5 if res else 1.0, split=split,
+                        in_ld=in_ld, in_off=in_off)
+    assert torch.equal(got, again)
+
+
+def test_pointwise_streaming_kernel_rejects_other_shapes(cuda):
+    lib = _lib.load()
+    x = torch.randn(1, 48, 8, 8)
+    w = torch.randn(32, 48, 1, 1)
+    with pytest.raises(Exception, match='not supported by the streaming kernel'):
+        run_conv(x, w, torch.zeros(32), 1, 0, 1, cuda, variant=41)      # Cin = 48
+    with pytest.raises(Exception, match='not supported by the streaming kernel'):
+        run_conv(torch.randn(1, 32, 8, 8), torch.randn(32, 32, 3, 3), torch.zeros(32), 1, 1, 1, cuda, variant=41)
+    assert b'streaming kernel' in lib.st_last_error()
