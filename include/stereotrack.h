@@ -82,6 +82,11 @@ int st_conv2d_nhwc(const StConvDesc* d, st_stream_t stream);
 /* Pack one Conv2d weight [Cout][Cin][KH][KW] (+ optional BN, folded in fp64)
  * into the kernel layout above.  Host function; out buffers are host memory
  * of st_conv_packed_floats(...) / roundup(Cout,32) floats. */
+/* Fused pair of 1x1 convolutions for the narrow high-resolution CSP layers: `b` (Cin = 32, Cout <= 32) consumes
+ * output channels [0, 32) of `a` (Cin 32 or 64, 32 < Cout <= 64, no residual) - the CSPLayer main_conv ->
+ * DarknetBottleneck conv1 pair (mmdet CSPLayer, built at csp_darknet_disparity_v1.py:113-153).  a's outputs are
+ * written as usual; b's in_dev / in_ld / in_off are ignored (its input never leaves the registers). */
+int st_conv1x1_chain(const StConvDesc* a, const StConvDesc* b, st_stream_t stream);
 size_t st_conv_packed_floats(int Cout, int Cin, int KH, int KW);
 int st_conv_pack_weights(const float* w, const float* conv_bias, /* may be NULL */
                          const float* bn_gamma, const float* bn_beta,

@@ -61,6 +61,7 @@ _PROTOS = {
     'st_last_error': (C.c_char_p, []),
     'st_conv2d_nhwc': (_i, [C.POINTER(StConvDesc), _vp]),
     'st_conv2d_nhwc_variant': (_i, [C.POINTER(StConvDesc), _vp, _i]),
+    'st_conv1x1_chain': (_i, [C.POINTER(StConvDesc), C.POINTER(StConvDesc), _vp]),
     'st_conv_packed_floats': (_sz, [_i, _i, _i, _i]),
     'st_conv_pack_weights': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, C.c_double, _i, _i, _i, _i, _vp, _vp]),
     'st_focus_pack': (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),

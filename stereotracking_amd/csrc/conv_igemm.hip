@@ -665,13 +665,13 @@ const char* conv_variant_signature(int id) {
 }
 
 bool pw_conv_applicable(const StConvDesc& d);          // pointwise_conv.hip (tile variant 41)
-int pw_conv_launch(const StConvDesc& d, hipStream_t stream);
+int pw_conv_launch(const StConvDesc& d, hipStream_t stream, const StConvDesc* chain);
 
 int conv2d_launch(const StConvDesc& d, hipStream_t stream, int force_variant, int* picked_variant) {
   ST_REQUIRE(d.in_dev && d.wgt_dev && d.bias_dev && d.out1_dev, "conv: null pointer");
   if (force_variant == 41) {   // streaming 1x1 kernel for narrow layers
     if (picked_variant) *picked_variant = 41;
-    return pw_conv_launch(d, stream);
+    return pw_conv_launch(d, stream, nullptr);
   }
   ST_REQUIRE(d.Cin % 4 == 0 && d.in_ld % 4 == 0 && d.in_off % 4 == 0,
              "conv: Cin/in_ld/in_off must be multiples of 4 (got %d/%d/%d)", d.Cin, d.in_ld,
@@ -793,6 +793,13 @@ int conv2d_launch(const StConvDesc& d, hipStream_t stream, int force_variant, in
 extern "C" int st_conv2d_nhwc(const StConvDesc* d, st_stream_t stream) {
   if (!d) return st::set_error(ST_ERR_INVALID, "st_conv2d_nhwc: null desc");
   return st::conv2d_launch(*d, static_cast<hipStream_t>(stream), -1, nullptr);
+}
+
+// Fused pair of 1x1 convs on the streaming kernel: `b` consumes output channels [0, 32) of `a` (the CSP
+// main_conv -> bottleneck conv1 pair) straight from registers; a's own outputs are still written.
+extern "C" int st_conv1x1_chain(const StConvDesc* a, const StConvDesc* b, st_stream_t stream) {
+  if (!a || !b) return st::set_error(ST_ERR_INVALID, "st_conv1x1_chain: null desc");
+  return st::pw_conv_launch(*a, static_cast<hipStream_t>(stream), b);
 }
 
 // test hook: force a tile variant (0..4); not part of the documented ABI surface

@@ -32,6 +32,8 @@ namespace st {
 
 int conv2d_launch(const StConvDesc& d, hipStream_t stream, int force_variant, int* picked_variant);
 bool pw_conv_applicable(const StConvDesc& d);
+bool pw_chain_applicable(const StConvDesc& d, const StConvDesc& c);
+int pw_conv_launch(const StConvDesc& d, hipStream_t stream, const StConvDesc* chain);
 int conv_variant_count();
 bool conv_variant_valid(int id, int cout);
 const char* conv_variant_name(int id);
@@ -116,6 +118,8 @@ struct Op {
   int variant = -1;    // conv tile variant picked at the last launch
   int tuned = -1;      // measured best variant (st_detector_autotune), -1 = heuristic
   int group = 0;       // sub-batch group (0 = whole batch in one launch)
+  bool chain_next = false;  // the NEXT op is a 1x1 conv on this op's out1 (CSP main_conv -> bottleneck conv1):
+                            // when both run on the streaming kernel (variant 41) they are launched as one
 };
 
 }  // namespace
@@ -273,6 +277,7 @@ struct StDetector {
     TRef mainb = new_tensor(x.N, x.H, x.W, mid);
     const int pc = packed_convmodules({p + ".main_conv", p + ".short_conv"}, x.C, {mid, mid}, 1);
     op_conv(pc, x, 1, mainb, mid, cat.slice(mid, mid));
+    if (nblocks > 0 && mid == 32) ops.back().chain_next = true;   // main_conv -> blocks.0.conv1 (reads mainb)
     TRef tmp = new_tensor(x.N, x.H, x.W, mid);
     for (int b = 0; b < nblocks; ++b) {
       const std::string bp = p + ".blocks." + std::to_string(b);
@@ -577,6 +582,23 @@ float* resolve(const StDetector* det, const TRef& t, float* ws, float* head, int
   return ws + det->buf_off[t.buf] + t.base + shift;
 }
 
+StConvDesc conv_desc(const StDetector* det, const Op& o, int img0, float* ws, float* head) {
+  const PackedConv& pc = det->convs[o.pc];
+  StConvDesc d{};
+  d.in_dev = resolve(det, o.in, ws, head, img0);
+  d.N = o.in.N; d.Hi = o.in.H; d.Wi = o.in.W; d.Cin = pc.cin; d.in_ld = o.in.ld; d.in_off = o.in.off;
+  d.wgt_dev = det->wgt_dev + pc.wgt_off;
+  d.bias_dev = det->wgt_dev + pc.bias_off;
+  d.Cout = pc.cout; d.KH = pc.k; d.KW = pc.k; d.stride = o.stride; d.pad = o.pad;
+  d.out1_dev = resolve(det, o.out1, ws, head, img0); d.out1_ld = o.out1.ld; d.out1_off = o.out1.off;
+  d.split = o.split;
+  d.out2_dev = resolve(det, o.out2, ws, head, img0); d.out2_ld = o.out2.ld; d.out2_off = o.out2.off;
+  d.up_dev = resolve(det, o.up, ws, head, img0); d.up_ld = o.up.ld; d.up_off = o.up.off;
+  d.res_dev = resolve(det, o.res, ws, head, img0); d.res_ld = o.res.ld; d.res_off = o.res.off;
+  d.post_scale = o.post_scale; d.act = o.act;
+  return d;
+}
+
 int launch_op(StDetector* det, Op& o, int img0, const float* const inputs[3], float* ws, float* head,
               hipStream_t stream) {
   switch (o.type) {
@@ -603,18 +625,8 @@ int launch_op(StDetector* det, Op& o, int img0, const float* const inputs[3], fl
     }
     case Op::CONV: {
       const PackedConv& pc = det->convs[o.pc];
-      StConvDesc d{};
-      d.in_dev = resolve(det, o.in, ws, head, img0);
-      d.N = o.in.N; d.Hi = o.in.H; d.Wi = o.in.W; d.Cin = pc.cin; d.in_ld = o.in.ld; d.in_off = o.in.off;
-      d.wgt_dev = det->wgt_dev + pc.wgt_off;
-      d.bias_dev = det->wgt_dev + pc.bias_off;
-      d.Cout = pc.cout; d.KH = pc.k; d.KW = pc.k; d.stride = o.stride; d.pad = o.pad;
-      d.out1_dev = resolve(det, o.out1, ws, head, img0); d.out1_ld = o.out1.ld; d.out1_off = o.out1.off;
-      d.split = o.split;
-      d.out2_dev = resolve(det, o.out2, ws, head, img0); d.out2_ld = o.out2.ld; d.out2_off = o.out2.off;
-      d.up_dev = resolve(det, o.up, ws, head, img0); d.up_ld = o.up.ld; d.up_off = o.up.off;
-      d.res_dev = resolve(det, o.res, ws, head, img0); d.res_ld = o.res.ld; d.res_off = o.res.off;
-      d.post_scale = o.post_scale; d.act = o.act;
+      (void)pc;
+      const StConvDesc d = conv_desc(det, o, img0, ws, head);
       return conv2d_launch(d, stream, det->force_variant >= 0 ? det->force_variant : o.tuned, &o.variant);
     }
   }
@@ -642,6 +654,7 @@ int run_ops(StDetector* det, int phase_lo, int phase_hi, const float* const inpu
       while (oe < nops && det->ops[oe].group == first.group && det->ops[oe].phase == first.phase) ++oe;
     const StDetector::Group g = det->groups[first.group];
     for (int sbi = 0; sbi < g.count; ++sbi) {
+      bool chain_done = false;
       for (size_t k = oi; k < oe; ++k) {
         Op& o = det->ops[k];
         if (det->timing) ST_CHECK_HIP(hipEventRecord(det->events[ev_per_op * k + 2 * sbi], stream));
@@ -650,7 +663,23 @@ int run_ops(StDetector* det, int phase_lo, int phase_hi, const float* const inpu
         const char* skip_env = getenv("ST_SKIP_OPS");   // read per launch: the bench flips it after the warm-up
         const std::string skip(skip_env ? skip_env : "");
         const bool skipped = !skip.empty() && ("," + skip + ",").find("," + std::to_string(k) + ",") != std::string::npos;
-        if (!skipped) ST_CHECK(launch_op(det, o, sbi * g.sb, inputs, ws, head, stream));
+        bool chained = false;
+        if (!skipped && chain_done) {   // this op was computed by the previous (chained) launch
+          chain_done = false;
+          o.variant = 41;
+          chained = true;
+        } else if (!skipped && o.type == Op::CONV && o.chain_next && k + 1 < oe && det->force_variant < 0 &&
+                   o.tuned == 41 && det->ops[k + 1].tuned == 41 && !getenv("ST_NO_CHAIN")) {
+          const StConvDesc da = conv_desc(det, o, sbi * g.sb, ws, head);
+          const StConvDesc db = conv_desc(det, det->ops[k + 1], sbi * g.sb, ws, head);
+          if (pw_chain_applicable(da, db)) {
+            ST_CHECK(pw_conv_launch(da, stream, &db));
+            o.variant = 41;
+            chain_done = true;
+            chained = true;
+          }
+        }
+        if (!skipped && !chained) ST_CHECK(launch_op(det, o, sbi * g.sb, inputs, ws, head, stream));
         if (det->timing) ST_CHECK_HIP(hipEventRecord(det->events[ev_per_op * k + 2 * sbi + 1], stream));
       }
     }

@@ -39,6 +39,12 @@ struct PwArgs {
   float post_scale;
   int act;
   unsigned in_bytes, out1_bytes, out2_bytes, res_bytes;
+  // chained second 1x1 conv on the first 32 output channels of this one (CHAIN kernels only)
+  const float* wgt2;
+  const float* bias2;
+  float* out3;
+  int Cout2, Kpad2, out3_ld, out3_off, act2;
+  unsigned out3_bytes;
 };
 
 __device__ __forceinline__ float pw_silu(float v) { return v * __builtin_amdgcn_rcpf(1.0f + __expf(-v)); }
@@ -49,7 +55,7 @@ __device__ __forceinline__ float pw_silu(float v) { return v * __builtin_amdgcn_
 // block loop is unrolled by 3), so every wave keeps 2 x Cin x 128 B of reads in flight and nothing in the loop
 // waits on a workgroup barrier: the first version streamed 128-pixel tiles through LDS by LDS-DMA and was held to
 // 3.7 TB/s by the vmcnt(0) + barrier per tile, which also waits for the previous tile's stores.
-template <int CIN, int NB, bool VEC, bool RES>
+template <int CIN, int NB, bool VEC, bool RES, bool CHAIN = false>
 __global__ __launch_bounds__(256, 2) void pw_conv_kernel(const PwArgs p) {
   constexpr int Q = CIN / 4;     // 16-byte quads per pixel
   constexpr int G = CIN / 8;     // k-groups of 8 channels (4 MFMA steps each)
@@ -69,6 +75,19 @@ __global__ __launch_bounds__(256, 2) void pw_conv_kernel(const PwArgs p) {
   }
   float* bl = wl + NB * 32 * CIN;   // bias [NB*32] in LDS (read per group in the epilogue: keeps 32 VGPRs free)
   if (tid < NB * 32) bl[tid] = p.bias[tid];
+  // CHAIN: a second 1x1 conv (32 -> Cout2 <= 32) on output channels [0, 32) of this one.  The accumulator layout
+  // of the swapped MFMA (lane = pixel, couts 8g + 4*half + {0..3}) IS the K-permuted B-operand layout, so the
+  // activated outputs feed the second product straight from registers: no LDS round trip, no extra HBM read.
+  float* wl2 = bl + NB * 32;        // [32][32], quads swizzled by the cout index (8 quads per row)
+  float* bl2 = wl2 + 32 * 32;
+  if (CHAIN) {
+    for (int e = tid; e < 32 * 8; e += 256) {
+      const int co = e >> 3, q = e & 7;
+      const f32x4 v = *reinterpret_cast<const f32x4*>(p.wgt2 + (size_t)co * p.Kpad2 + 4 * q);
+      *reinterpret_cast<f32x4*>(wl2 + (co * 8 + (q ^ (co & 7))) * 4) = v;
+    }
+    if (tid < 32) bl2[tid] = p.bias2[tid];
+  }
   const int wsw = l31 & (Q - 1);
   __syncthreads();   // weights visible; the only barrier of the kernel
 
@@ -80,6 +99,8 @@ __global__ __launch_bounds__(256, 2) void pw_conv_kernel(const PwArgs p) {
       __builtin_amdgcn_make_buffer_rsrc(p.out2 ? p.out2 : p.out1, 0, (int)(p.out2 ? p.out2_bytes : 0u), 0x00020000);
   const __amdgpu_buffer_rsrc_t rrsrc = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<float*>(p.res ? p.res : p.in), 0, (int)(p.res ? p.res_bytes : 0u), 0x00020000);
+  const __amdgpu_buffer_rsrc_t o3rsrc =
+      __builtin_amdgcn_make_buffer_rsrc(CHAIN ? p.out3 : p.out1, 0, (int)(CHAIN ? p.out3_bytes : 0u), 0x00020000);
 
   f32x4 xr[3][G];   // pixel operands of three blocks in flight
   auto load_x = [&](auto set_tag, int blk) {
@@ -140,6 +161,7 @@ __global__ __launch_bounds__(256, 2) void pw_conv_kernel(const PwArgs p) {
           acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[set][nb][s], xr[SET][g][s], acc[nb], 0, 0, 0);
     }
     // ---- epilogue: C[co][pixel], lane = pixel, couts nb*32 + 8*g + 4*half + {0..3}
+    f32x4 xm[CHAIN ? 4 : 1];   // activated outputs 0..31 of this pixel = B operand of the chained conv
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
@@ -154,6 +176,7 @@ __global__ __launch_bounds__(256, 2) void pw_conv_kernel(const PwArgs p) {
           if (RES) x = (x + rv[RES ? nb : 0][g][e]) * p.post_scale;
           v[e] = x;
         }
+        if (CHAIN && nb == 0) xm[CHAIN ? g : 0] = v;
         // branch-free split: the store into the "other" output carries an out-of-range offset and is dropped
         if (VEC) {   // every ld / off / split / Cout is a multiple of 4: one dwordx4 per group
           const bool ok = mv && co < p.Cout, first = co < p.split;
@@ -179,6 +202,40 @@ __global__ __launch_bounds__(256, 2) void pw_conv_kernel(const PwArgs p) {
           }
         }
       }
+    if (CHAIN) {
+      f32x16 acc2;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc2[r] = 0.f;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {   // k-group g = channels 8g + 4*half + step, exactly xm[g][step]
+        const f32x4 w2 = *reinterpret_cast<const f32x4*>(wl2 + (l31 * 8 + ((2 * g + half) ^ (l31 & 7))) * 4);
+#pragma unroll
+        for (int s2 = 0; s2 < 4; ++s2)
+          acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(w2[s2], xm[CHAIN ? g : 0][s2], acc2, 0, 0, 0);
+      }
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int co = 8 * g + 4 * half;
+        const f32x4 bq = *reinterpret_cast<const f32x4*>(bl2 + co);
+        f32x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float x = acc2[4 * g + e] + bq[e];
+          v[e] = p.act2 ? pw_silu(x) : x;
+        }
+        if (VEC) {
+          const unsigned off = (mv && co < p.Cout2) ? (unsigned)((m * p.out3_ld + p.out3_off + co) * 4) : 0x80000000u;
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), o3rsrc, off, 0, 0);
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const unsigned off =
+                (mv && co + e < p.Cout2) ? (unsigned)((m * p.out3_ld + p.out3_off + co + e) * 4) : 0x80000000u;
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v[e]), o3rsrc, off, 0, 0);
+          }
+        }
+      }
+    }
   };
   using S0 = std::integral_constant<int, 0>;
   using S1 = std::integral_constant<int, 1>;
@@ -213,7 +270,7 @@ __global__ __launch_bounds__(256, 2) void pw_conv_kernel(const PwArgs p) {
     }
   }
 #else
-  (void)wsw; (void)nwaves; (void)nblk; (void)t; (void)bl;
+  (void)wsw; (void)nwaves; (void)nblk; (void)t; (void)bl; (void)bl2;
 #endif
 }
 
@@ -234,8 +291,20 @@ bool pw_conv_applicable(const StConvDesc& d) {
   return true;
 }
 
-int pw_conv_launch(const StConvDesc& d, hipStream_t stream) {
+// `chain` (may be null): a second 1x1 conv whose input is exactly output channels [0, 32) of `d`'s out1 slice
+// (chain->in_dev / in_ld / in_off are ignored), Cin = 32, Cout <= 32, no split / residual / upsample.
+bool pw_chain_applicable(const StConvDesc& d, const StConvDesc& c) {
+  if (!pw_conv_applicable(d) || !pw_conv_applicable(c)) return false;
+  const int split = d.out2_dev ? d.split : d.Cout;
+  if (d.res_dev || split < 32 || d.Cout <= 32 || d.Cout > 64) return false;   // the fused kernel is the NB = 2 one
+  if (c.Cin != 32 || c.Cout > 32 || c.out2_dev || c.res_dev || c.up_dev) return false;
+  if (c.N != d.N || c.Hi != d.Hi || c.Wi != d.Wi) return false;
+  return true;
+}
+
+int pw_conv_launch(const StConvDesc& d, hipStream_t stream, const StConvDesc* chain) {
   ST_REQUIRE(pw_conv_applicable(d), "pointwise conv: shape not supported by the streaming kernel");
+  if (chain) ST_REQUIRE(pw_chain_applicable(d, *chain), "pointwise conv: pair cannot be chained");
   ST_REQUIRE(d.in_dev && d.wgt_dev && d.bias_dev && d.out1_dev, "pointwise conv: null pointer");
   const int split = d.out2_dev ? d.split : d.Cout;
   ST_REQUIRE(split >= 0 && split <= d.Cout && d.out1_off + split <= d.out1_ld, "pointwise conv: bad split / out1 slice");
@@ -260,7 +329,19 @@ int pw_conv_launch(const StConvDesc& d, hipStream_t stream) {
   if (d.out2_dev) vec = vec && ((d.out2_ld | d.out2_off) & 3) == 0 && al16(d.out2_dev);
   if (d.res_dev) vec = vec && ((d.res_ld | d.res_off) & 3) == 0 && al16(d.res_dev);
   const int nb = round_up(d.Cout, 32) / 32;
-  const size_t lds = (size_t)(nb * 32 * d.Cin + nb * 32) * sizeof(float);   // weights + bias
+  if (chain) {
+    a.wgt2 = chain->wgt_dev; a.bias2 = chain->bias_dev; a.out3 = chain->out1_dev;
+    a.Cout2 = chain->Cout; a.Kpad2 = 32; a.out3_ld = chain->out1_ld; a.out3_off = chain->out1_off; a.act2 = chain->act;
+    ST_REQUIRE(chain->wgt_dev && chain->bias_dev && chain->out1_dev, "pointwise conv: null chain pointer");
+    ST_REQUIRE(chain->out1_off + chain->Cout <= chain->out1_ld, "pointwise conv: chain output slice exceeds its ld");
+    a.out3_bytes = (unsigned)(M * chain->out1_ld * 4);
+    vec = vec && ((chain->out1_ld | chain->out1_off | chain->Cout) & 3) == 0 && al16(chain->out1_dev);
+  } else {
+    a.wgt2 = nullptr; a.bias2 = nullptr; a.out3 = nullptr;
+    a.Cout2 = 0; a.Kpad2 = 0; a.out3_ld = 0; a.out3_off = 0; a.act2 = 0; a.out3_bytes = 0;
+  }
+  // weights + bias (+ chained weights + bias)
+  const size_t lds = (size_t)(nb * 32 * d.Cin + nb * 32 + (chain ? 32 * 32 + 32 : 0)) * sizeof(float);
   static int cus = 0;
   if (!cus) {
     int dev = 0;
@@ -271,10 +352,13 @@ int pw_conv_launch(const StConvDesc& d, hipStream_t stream) {
   using Kern = void (*)(const PwArgs);
 #define PW_K(C, N) pw_conv_kernel<C, N, false, false>, pw_conv_kernel<C, N, true, false>, \
                    pw_conv_kernel<C, N, false, true>, pw_conv_kernel<C, N, true, true>
-  static const Kern kerns[16] = {PW_K(32, 1), PW_K(32, 2), PW_K(64, 1), PW_K(64, 2)};
+  static const Kern kerns[20] = {PW_K(32, 1), PW_K(32, 2), PW_K(64, 1), PW_K(64, 2),
+                                 pw_conv_kernel<32, 2, false, false, true>, pw_conv_kernel<32, 2, true, false, true>,
+                                 pw_conv_kernel<64, 2, false, false, true>, pw_conv_kernel<64, 2, true, false, true>};
 #undef PW_K
-  const int ki = (d.Cin == 64 ? 8 : 0) + (nb - 1) * 4 + (d.res_dev ? 2 : 0) + (vec ? 1 : 0);
-  static bool attr_set[16] = {};
+  const int ki = chain ? 16 + (d.Cin == 64 ? 2 : 0) + (vec ? 1 : 0)
+                       : (d.Cin == 64 ? 8 : 0) + (nb - 1) * 4 + (d.res_dev ? 2 : 0) + (vec ? 1 : 0);
+  static bool attr_set[20] = {};
   if (!attr_set[ki]) {
     ST_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kerns[ki]),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

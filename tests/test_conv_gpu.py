@@ -294,3 +294,52 @@ def test_pointwise_streaming_kernel_rejects_other_shapes(cuda):
     with pytest.raises(Exception, match='not supported by the streaming kernel'):
         run_conv(torch.randn(1, 32, 8, 8), torch.randn(32, 32, 3, 3), torch.zeros(32), 1, 1, 1, cuda, variant=41)
     assert b'streaming kernel' in lib.st_last_error()
+
+
+@pytest.mark.parametrize('cin,N,H,W', [(64, 2, 23, 41), (32, 1, 64, 96)])
+def test_chained_pointwise_pair_matches_torch(cin, N, H, W, cuda):
+    """st_conv1x1_chain: main+short 1x1 conv (split 32|32 into two buffers) with the bottleneck conv1 (32 -> 32)
+    chained on its first 32 outputs from registers == the two convolutions run one after the other."""
+    lib = _lib.load()
+    torch.manual_seed(cin + H)
+    x = torch.randn(N, cin, H, W)
+    wa, ba = torch.randn(64, cin, 1, 1) / cin ** 0.5, torch.randn(64)
+    wb, bb = torch.randn(32, 32, 1, 1) / 32 ** 0.5, torch.randn(32)
+    xin = x.permute(0, 2, 3, 1).contiguous().to(cuda)
+    (wpa, bpa), (wpb, bpb) = pack(wa, ba), pack(wb, bb)
+    wpa, bpa, wpb, bpb = wpa.to(cuda), bpa.to(cuda), wpb.to(cuda), bpb.to(cuda)
+    main = torch.full((N, H, W, 32), -777.0, device=cuda)
+    cat = torch.full((N, H, W, 64), -777.0, device=cuda)      # short goes to channels [32, 64)
+    tmp = torch.full((N, H, W, 36), -777.0, device=cuda)      # chained output at channel offset 4
+    a = StConvDesc()
+    a.in_dev = xin.data_ptr(); a.N, a.Hi, a.Wi, a.Cin, a.in_ld, a.in_off = N, H, W, cin, cin, 0
+    a.wgt_dev = wpa.data_ptr(); a.bias_dev = bpa.data_ptr()
+    a.Cout, a.KH, a.KW, a.stride, a.pad = 64, 1, 1, 1, 0
+    a.out1_dev = main.data_ptr(); a.out1_ld, a.out1_off, a.split = 32, 0, 32
+    a.out2_dev = cat.data_ptr(); a.out2_ld, a.out2_off = 64, 32
+    a.act = 1
+    b = StConvDesc()
+    b.in_dev = main.data_ptr(); b.N, b.Hi, b.Wi, b.Cin, b.in_ld, b.in_off = N, H, W, 32, 32, 0
+    b.wgt_dev = wpb.data_ptr(); b.bias_dev = bpb.data_ptr()
+    b.Cout, b.KH, b.KW, b.stride, b.pad = 32, 1, 1, 1, 0
+    b.out1_dev = tmp.data_ptr(); b.out1_ld, b.out1_off, b.split = 36, 4, 32
+    b.act = 1
+    check(lib.st_conv1x1_chain(C.byref(a), C.byref(b), _lib.current_stream()))
+    torch.cuda.synchronize()
+    ya = ref_conv(x, wa, ba, 1, 0, 1)
+    yb = F.silu(F.conv2d(ya[:, :32], wb.double(), bb.double()))
+    assert_close(main.cpu().permute(0, 3, 1, 2), ya[:, :32])
+    assert_close(cat.cpu()[..., 32:].permute(0, 3, 1, 2), ya[:, 32:])
+    assert torch.all(cat.cpu()[..., :32] == -777.0)
+    assert_close(tmp.cpu()[..., 4:].permute(0, 3, 1, 2), yb)
+    assert torch.all(tmp.cpu()[..., :4] == -777.0)
+    # the chained result is bit-identical to running conv1 separately on the stored main output (same kernel,
+    # same operand values, same summation order)
+    tmp2 = torch.full((N, H, W, 36), -777.0, device=cuda)
+    b.out1_dev = tmp2.data_ptr()
+    check(lib.st_conv2d_nhwc_variant(C.byref(b), _lib.current_stream(), 41))
+    torch.cuda.synchronize()
+    assert torch.equal(tmp, tmp2)
+    # pairs that cannot be chained are refused
+    b.Cin = 64
+    assert lib.st_conv1x1_chain(C.byref(a), C.byref(b), _lib.current_stream()) != 0
