@@ -63,6 +63,7 @@ def conv_roofline(pipe, img, right, steps):
     sm = pipe.stereo_module
     sm.timing = True
     agg = {}   # variant -> [launches, ms]
+    cv_ms = 0.0
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
     # an event pair with nothing in between already measures ~4.6 us on this stack (two barrier packets); that
     # overhead is measured live and removed from every per-launch duration, otherwise the HIP-event averages sit
@@ -90,6 +91,7 @@ def conv_roofline(pipe, img, right, steps):
         check(lib.st_detector_op_times(det.handle, nops, p(ms), p(kind), p(var), p(macs), p(phase)))
         ph0 = float(ms[phase == 0].sum())     # raw: what the bracketing events of the stereo module saw
         tot_ms += np.maximum(ms - null_ms, 0.0)
+        cv_ms += max(sm.pop_costvolume_time() - null_ms, 0.0)
         for v, t in sm.pop_times():   # aggregation convs: the same conv kernel, launched by the stereo module
             a = agg.setdefault(int(v), [0, 0.0])
             a[0] += 1
@@ -158,6 +160,15 @@ def conv_roofline(pipe, img, right, steps):
                 per_variant=per_variant,
                 other_kernels_ms_per_step={k: round(v / steps, 4) for k, v in other.items()},
                 focus_spp_ms_per_step=round(float(tot_ms[kind != 1].sum() / steps), 4))
+    # secondary roofline (SURVEY.md §8d "cost volume: HBM-bound scan", materialised form at 1/4 resolution):
+    # algorithmic bytes of one costvolume launch = both feature maps read once + the volume written once
+    Cf = pipe.det.tap('stage1_rgb').shape[-1]
+    cv_bytes = pipe.batch * Hf * Wf * 4.0 * (2 * Cf + (sm.levels if sm.agg_layers else 0)) + pipe.batch * Hf * Wf * 4.0
+    cv_us = cv_ms / steps * 1e3
+    roof['secondary_costvolume'] = dict(bound='hbm', kernel='st::costvolume_tiled_kernel', unit='GB/s', peak=8000.0,
+                                        bytes_per_launch=int(cv_bytes), avg_launch_us=round(cv_us, 2),
+                                        achieved=round(cv_bytes / (cv_us * 1e-6) / 1e9, 1) if cv_us > 0 else None,
+                                        frac=round(cv_bytes / (cv_us * 1e-6) / 8e12, 4) if cv_us > 0 else None)
     return roof
 
 
@@ -207,7 +218,14 @@ def cpu_baseline(sd, batch_cpu, max_disp, seconds, agg_layers):
         if time.perf_counter() - t0 >= seconds or n >= 64:
             break
     dt = time.perf_counter() - t0
-    return dict(value=round(n / dt, 4), unit='stereo frame-pairs/s', cores=torch.get_num_threads(), kind='port',
+    threads = torch.get_num_threads()
+    torch.set_num_threads(1)          # SURVEY.md §8d also asks for the 1-thread figure (one pair)
+    t1 = time.perf_counter()
+    one_pair()
+    dt1 = time.perf_counter() - t1
+    torch.set_num_threads(threads)
+    return dict(value=round(n / dt, 4), unit='stereo frame-pairs/s', cores=threads, kind='port',
+                value_1_thread=round(1.0 / dt1, 4),
                 sample=f'{n} x 1 synthetic 1280x720 pair (D={max_disp}, {agg_layers} aggregation convs, full YOLOX-s '
                        'two-branch), CPU oracle '
                        f'(PyTorch fp32 + C oracle), {dt:.1f} s', host_cpus=os.cpu_count())

@@ -10,6 +10,7 @@ first call.  Mirrors the dense part of OCSORT_Disparity.predict (reference
 mmtrack/models/mot/ocsort_disparity.py:50-83): detector.predict (:79) + bbox_postp_depth (:82-83).
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -42,6 +43,7 @@ class StereoDensePipeline:
         self.det = HipDetector(self.batch, self.height, self.width, widen_factor, deepen_factor, num_classes,
                                stereo=self.stereo)
         self._bufs = None
+        self._last_post = None
 
     # ---- parameters ------------------------------------------------------------------------------
     def param_table(self):
@@ -131,9 +133,13 @@ class StereoDensePipeline:
             if disp_postp is None:
                 raise ValueError('mono pipeline needs disp_postp')
             self.det.forward(img, disp_postp, b['head'])
-        boxes, scores, labels, prior, counts = self.det.decode_nms(
-            b['head'], self.score_thr, self.iou_thr, self.max_det, (self.ori_h, self.ori_w))
-        depth, scales, sboxes = self.box_depth(disp_postp, boxes, counts)
+        if os.environ.get('ST_ABLATE_POST') and self._last_post is not None:   # timing-only ablation (tools)
+            boxes, scores, labels, prior, counts, depth, scales, sboxes = self._last_post
+        else:
+            boxes, scores, labels, prior, counts = self.det.decode_nms(
+                b['head'], self.score_thr, self.iou_thr, self.max_det, (self.ori_h, self.ori_w))
+            depth, scales, sboxes = self.box_depth(disp_postp, boxes, counts)
+            self._last_post = (boxes, scores, labels, prior, counts, depth, scales, sboxes)
         return dict(boxes=boxes, scores=scores, labels=labels, prior_idx=prior, counts=counts, depth=depth,
                     scales=scales, scaled_boxes=sboxes, disp_postp=disp_postp, head=b['head'])
 

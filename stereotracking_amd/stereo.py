@@ -57,6 +57,7 @@ class StereoCostVolume(nn.Module):
         self.variant = -1      # conv tile variant of the aggregation layers (-1 = library default, or autotune())
         self.timing = False    # record events around every aggregation conv (bench.py roofline accounting)
         self._events = []
+        self._cv_events = []
 
     def forward(self, *args, **kwargs):
         raise RuntimeError('StereoCostVolume has no CPU forward: use compute() with a HipDetector context')
@@ -138,6 +139,15 @@ class StereoCostVolume(nn.Module):
         self._events = []
         return out
 
+    def pop_costvolume_time(self):
+        """ms of the cost-volume launches recorded since the last call (timing=True; syncs)."""
+        t = 0.0
+        for e0, e1 in self._cv_events:
+            e1.synchronize()
+            t += e0.elapsed_time(e1)
+        self._cv_events = []
+        return t
+
     # ---- compute ------------------------------------------------------------------------------------------
     def compute(self, engine, img, right, valid_hw, disp_lr=None, disp_postp=None, cost_out=None):
         """engine: a HipDetector built with stereo=True.  img/right: (N,3,H,W) fp32 CUDA.
@@ -159,10 +169,16 @@ class StereoCostVolume(nn.Module):
         if disp_postp is None:
             disp_postp = torch.empty(N, 3, H, W, dtype=torch.float32, device=dev)
         stream = current_stream()
+        if self.timing:
+            cv0, cv1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            cv0.record()
         if self.agg_layers == 0:
             check(self.lib.st_costvolume_softargmin(C.c_void_p(fl), C.c_void_p(fr), N, Hf, Wf, Cf, ld, D,
                                                     self.temperature, ptr(cost_out), ptr(disp_lr), stream),
                   'st_costvolume_softargmin')
+            if self.timing:
+                cv1.record()
+                self._cv_events.append((cv0, cv1))
         else:
             packed = self._pack(dev)
             va, vb = self._volumes(dev, N, Hf, Wf)
@@ -170,6 +186,9 @@ class StereoCostVolume(nn.Module):
             check(self.lib.st_costvolume_softargmin(C.c_void_p(fl), C.c_void_p(fr), N, Hf, Wf, Cf, ld, D,
                                                     self.temperature, ptr(va), None, stream),
                   'st_costvolume_softargmin')
+            if self.timing:
+                cv1.record()
+                self._cv_events.append((cv0, cv1))
             for l, (wp, bp) in enumerate(packed):
                 d = self._agg_desc(l, va, vb, wp, bp)
                 if self.timing:

@@ -8,6 +8,10 @@ ships no fixtures of its own, so these vectors pin the oracle, not the reference
   box_depth.npz        numpy restatement of extract_depth (reference ocsort_disparity.py:136-175) on a
                        structured disparity map, incl. the NaN / -1 / w>800-style branches
   costvolume.npz       C-oracle cost volume + soft-argmin + upsample on seeded features
+  tracker_sequence.npz 64-frame synthetic detection stream (SURVEY.md §8c fixture iv: 6 objects, dropped
+                       detections, depth-consistent scales) and the frame-by-frame output of the host
+                       OC-SORT-with-depth restatement (stereotracking_amd/trackers.py, line-by-line from reference
+                       ocsort_tracker_disparity.py:105-618): ids, boxes, depth of every returned track
 Run:  python tests/golden/make_golden.py   (deterministic; CI checks the files are reproduced)."""
 import os
 import sys
@@ -110,9 +114,51 @@ def costvolume():
     return dict(featL=fl, featR=fr, cost=cost, disp_lr=lr, disp_postp=up, temperature=16.0)
 
 
+def tracker_sequence():
+    from stereotracking_amd.motion import KalmanFilter
+    from stereotracking_amd.structures import InstanceData, TrackDataSample
+    from stereotracking_amd.trackers import OCSORTTracker_Disparity
+
+    class _Model:
+        motion = KalmanFilter()
+
+    rng = np.random.RandomState(51)
+    T, K = 64, 6
+    pos = rng.uniform([100, 80], [1100, 600], (K, 2))
+    vel = rng.uniform(-4, 4, (K, 2))
+    size = rng.uniform(12, 50, (K, 2))
+    depth = rng.uniform(5, 60, K)
+    score = rng.uniform(0.35, 0.95, K)
+    trk = OCSORTTracker_Disparity(obj_score_thr=0.3, init_track_thr=0.7, weight_iou_with_det_scores=False,
+                                  match_iou_thr=0.1, num_tentatives=3, vel_consist_weight=0.2, vel_delta_t=3,
+                                  num_frames_retain=30)
+    model = _Model()
+    det_rows, out_rows = [], []
+    for t in range(T):
+        p = pos + vel * t + rng.normal(0, 0.4, (K, 2))
+        keep = (rng.uniform(size=K) > 0.1) | (t == 0)
+        keep[3] &= not (20 <= t < 28)          # an occlusion of 8 frames: the track must be re-identified
+        b = np.concatenate([p - size / 2, p + size / 2], 1)[keep].astype(np.float32)
+        sc = (score[keep] + rng.normal(0, 0.02, keep.sum())).astype(np.float32)
+        dp = (depth[keep] + rng.normal(0, 0.2, keep.sum())).astype(np.float32)
+        scl = np.clip(dp * dp / 400.0, 1.0, 3.0).astype(np.float32)
+        for i in range(len(b)):
+            det_rows.append([t, *b[i], sc[i], dp[i], scl[i]])
+        s = TrackDataSample(dict(frame_id=t))
+        s.pred_det_instances = InstanceData(bboxes=torch.from_numpy(b), scores=torch.from_numpy(sc),
+                                            labels=torch.zeros(len(b), dtype=torch.long),
+                                            scales=torch.from_numpy(scl), depth=torch.from_numpy(dp))
+        r = trk.track(model, None, None, s)
+        for i in range(len(r.instances_id)):
+            out_rows.append([t, int(r.instances_id[i]), *r.bboxes[i].tolist(), float(r.scores[i]),
+                             float(r.depth[i])])
+    return dict(detections=np.asarray(det_rows, np.float32), tracks=np.asarray(out_rows, np.float64),
+                num_frames=T)
+
+
 if __name__ == '__main__':
     c_oracle.build()
     for name, fn in (('detector_tiny', detector_tiny), ('decode_nms', decode_nms), ('box_depth', box_depth),
-                     ('costvolume', costvolume)):
+                     ('costvolume', costvolume), ('tracker_sequence', tracker_sequence)):
         np.savez_compressed(os.path.join(HERE, name + '.npz'), **fn())
         print('wrote', name)

@@ -119,3 +119,44 @@ def test_full_size_pipeline_parity_and_batch_invariance(cuda):
         if int(o['counts'][0]) == k:   # a score within 1e-6 of the threshold may flip; otherwise identical picks
             same = (o['prior_idx'][0, :min(k, 300)] == out['prior_idx'][n, :min(k, 300)]).float().mean().item()
             assert same > 0.98
+
+
+def test_config0_tiny_pair_against_cpu_oracle(cuda):
+    """BASELINE.json configs[0]: ONE synthetic 1280x720 stereo pair, D=64, tiny CSPDarknet (widen 0.375, deepen
+    0.33) - the reference's own CPU-runnable case.  The whole HIP pipeline against the CPU
+    PyTorch / C oracle composition: disparity and head floats within 1e-3, kept prior indices / boxes / scores
+    bit-exact on the GPU's own head, per-box depth decisions equal."""
+    import numpy as np
+    from oracle import c_oracle, depth as odepth, stereo as ostereo
+    from stereotracking_amd.pipeline import StereoDensePipeline
+    H, W, D = 720, 1280, 64
+    pipe = StereoDensePipeline(1, (H, W), 0.375, 0.33, 1, stereo=True, max_disp=D, max_det=300, agg_layers=2)
+    sd = synthetic_state_dict(pipe.param_table(), seed=0, prior_prob=0.05, logit_std=1.5)
+    pipe.load_state_dict(sd, autotune=False)
+    batch = synthetic_batch([0], H, W, D)
+    out = pipe.run(batch['img'].to(cuda), batch['right'].to(cuda))
+    torch.cuda.synchronize()
+    ora = OracleDetector(0.33, 0.375, 1).eval()
+    ora.load_state_dict(sd, strict=False)
+    with torch.no_grad():
+        fl = ora.backbone.stage1_features(batch['img']).permute(0, 2, 3, 1).contiguous().numpy()
+        fr = ora.backbone.stage1_features(batch['right']).permute(0, 2, 3, 1).contiguous().numpy()
+        disp = torch.from_numpy(ostereo.disparity(fl, fr, fl.shape[-1], D // 4, pipe.temperature, sd, 2,
+                                                  valid_hw=(H, W))[2])
+        rows = head_to_rows(*ora(dict(img=batch['img'], disp_postp=out['disp_postp'].cpu())))
+    assert (out['disp_postp'].cpu() - disp).abs().max().item() <= 1e-3 * D
+    for got, ref in zip(pipe.det.head_levels(out['head']), rows):
+        assert rel_err(got[..., :6].cpu(), ref) <= 1e-3
+    ref = c_oracle.decode_nms(out['head'].cpu().numpy(), 1, pipe.det.levels, pipe.score_thr, pipe.iou_thr,
+                              pipe.max_det, (H, W))
+    k = min(int(ref[4][0]), pipe.max_det)
+    assert k > 0 and int(out['counts'][0]) == int(ref[4][0])
+    assert np.array_equal(out['prior_idx'][0, :k].cpu().numpy(), ref[3][0, :k])
+    assert np.array_equal(out['boxes'][0, :k].cpu().numpy(), ref[0][0, :k])
+    assert np.array_equal(out['scores'][0, :k].cpu().numpy(), ref[1][0, :k])
+    d_ref, s_ref, _ = odepth.bbox_postp_depth(torch.from_numpy(ref[0][0, :k]), out['disp_postp'].cpu())
+    d_ref = np.array([float(v) for v in d_ref], np.float64)
+    d_got = out['depth'][0, :k].cpu().double().numpy()
+    assert np.array_equal(np.isnan(d_got), np.isnan(d_ref)) and np.array_equal(d_got == -1, d_ref == -1)
+    ok = ~np.isnan(d_ref) & (d_ref != -1)
+    assert np.abs(d_got[ok] - d_ref[ok]).max() <= 1e-3 * max(1.0, np.abs(d_ref[ok]).max())
