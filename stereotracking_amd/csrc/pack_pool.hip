@@ -1,5 +1,6 @@
 // Small bandwidth-bound helpers of the detector: Focus space-to-depth packing and SPP pooling.
 #include <algorithm>
+#include <cstdlib>
 
 #include "st_common.h"
 
@@ -158,16 +159,25 @@ int spp_pool_launch(const float* x, int x_ld, int x_off, int N, int H, int W, in
   ST_REQUIRE(out_off + 4 * C <= out_ld && x_off + C <= x_ld, "spp_pool: slice exceeds ld");
   const int copy_x = !(x == out && x_ld == out_ld && x_off == out_off);
   // small maps (the stride-32 level of the path): whole-map LDS cascade, 8 channels per workgroup
-  const size_t lds = (size_t)2 * H * W * 8 * sizeof(float);
-  if (C % 8 == 0 && lds <= 150 * 1024 && N <= 65535) {
-    auto kern = spp_pool_lds_kernel<8>;
-    static bool attr_set = false;
-    if (!attr_set) {
+  // channels per workgroup: the cascade is 7 dependent LDS sweeps with barriers, i.e. latency-bound, so small
+  // problems want more, smaller workgroups.  Measured on 8 x 23x40x256: 8 channels (256 workgroups) 68 us,
+  // 4 channels 45 us, 2 channels 55 us (8-byte global accesses).
+  int cg = 8;
+  if (const char* e = getenv("ST_SPP_CG")) cg = atoi(e);
+  else if ((long long)(C / 8) * N < 1024) cg = 4;
+  if (cg != 2 && cg != 4) cg = 8;
+  const size_t lds = (size_t)2 * H * W * cg * sizeof(float);
+  if (C % cg == 0 && lds <= 150 * 1024 && N <= 65535) {
+    using Kern = void (*)(const float*, int, int, int, int, int, float*, int, int, int);
+    const Kern kern = cg == 8 ? spp_pool_lds_kernel<8> : cg == 4 ? spp_pool_lds_kernel<4> : spp_pool_lds_kernel<2>;
+    static bool attr_set[3] = {false, false, false};
+    const int ai = cg == 8 ? 0 : cg == 4 ? 1 : 2;
+    if (!attr_set[ai]) {
       ST_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        150 * 1024));
-      attr_set = true;
+      attr_set[ai] = true;
     }
-    hipLaunchKernelGGL(kern, dim3(C / 8, N), dim3(256), lds, stream, x, x_ld, x_off, H, W, C, out, out_ld, out_off,
+    hipLaunchKernelGGL(kern, dim3(C / cg, N), dim3(256), lds, stream, x, x_ld, x_off, H, W, C, out, out_ld, out_off,
                        copy_x);
     ST_CHECK_HIP(hipGetLastError());
     return ST_OK;
