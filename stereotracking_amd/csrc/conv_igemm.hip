@@ -666,12 +666,18 @@ const char* conv_variant_signature(int id) {
 
 bool pw_conv_applicable(const StConvDesc& d);          // pointwise_conv.hip (tile variant 41)
 int pw_conv_launch(const StConvDesc& d, hipStream_t stream, const StConvDesc* chain);
+bool dc_conv_applicable(const StConvDesc& d);          // direct_conv.hip (tile variant 42)
+int dc_conv_launch(const StConvDesc& d, hipStream_t stream);
 
 int conv2d_launch(const StConvDesc& d, hipStream_t stream, int force_variant, int* picked_variant) {
   ST_REQUIRE(d.in_dev && d.wgt_dev && d.bias_dev && d.out1_dev, "conv: null pointer");
   if (force_variant == 41) {   // streaming 1x1 kernel for narrow layers
     if (picked_variant) *picked_variant = 41;
     return pw_conv_launch(d, stream, nullptr);
+  }
+  if (force_variant == 42) {   // direct 3x3 kernel for narrow layers
+    if (picked_variant) *picked_variant = 42;
+    return dc_conv_launch(d, stream);
   }
   ST_REQUIRE(d.Cin % 4 == 0 && d.in_ld % 4 == 0 && d.in_off % 4 == 0,
              "conv: Cin/in_ld/in_off must be multiples of 4 (got %d/%d/%d)", d.Cin, d.in_ld,

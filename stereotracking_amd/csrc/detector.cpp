@@ -33,6 +33,7 @@ namespace st {
 int conv2d_launch(const StConvDesc& d, hipStream_t stream, int force_variant, int* picked_variant);
 bool pw_conv_applicable(const StConvDesc& d);
 bool pw_chain_applicable(const StConvDesc& d, const StConvDesc& c);
+bool dc_conv_applicable(const StConvDesc& d);
 int pw_conv_launch(const StConvDesc& d, hipStream_t stream, const StConvDesc* chain);
 int conv_variant_count();
 bool conv_variant_valid(int id, int cout);
@@ -805,11 +806,14 @@ extern "C" int st_detector_autotune(StDetector* det, void* workspace_dev, size_t
     probe.out2_dev = so.out2.valid() ? static_cast<float*>(workspace_dev) : nullptr; probe.out2_ld = so.out2.ld;
     probe.res_dev = so.res.valid() ? probe.in_dev : nullptr; probe.res_ld = so.res.ld;
     probe.up_dev = so.up.valid() ? static_cast<float*>(workspace_dev) : nullptr;
+    probe.out1_dev = static_cast<float*>(workspace_dev);
+    probe.out1_off = so.out1.off; probe.res_off = so.res.off;
     const bool pw_ok = pw_conv_applicable(probe);
+    const bool dc_ok = dc_conv_applicable(probe);   // + variant 42, the direct 3x3 kernel (direct_conv.hip)
     const int ncand = std::min(conv_variant_count(), 22);
-    for (int vi = 0; vi <= ncand && rc == ST_OK; ++vi) {
-      const int v = vi < ncand ? vi : 41;
-      if (v == 41 ? !pw_ok : !conv_variant_valid(v, det->convs[saved[oi].pc].cout)) continue;
+    for (int vi = 0; vi <= ncand + 1 && rc == ST_OK; ++vi) {
+      const int v = vi < ncand ? vi : vi == ncand ? 41 : 42;
+      if (v == 41 ? !pw_ok : v == 42 ? !dc_ok : !conv_variant_valid(v, det->convs[saved[oi].pc].cout)) continue;
       det->force_variant = v;
       rc = run_ops(det, 0, 0, inputs, static_cast<float*>(workspace_dev), head_out_dev, stream);  // warm
       if (rc != ST_OK) break;
@@ -843,10 +847,11 @@ extern "C" int st_detector_autotune(StDetector* det, void* workspace_dev, size_t
 // id 40 = the fused Focus+stem kernel (stem_focus_conv.hip), reported with the conv ops
 // id 41 = the streaming 1x1 kernel for narrow layers (pointwise_conv.hip)
 extern "C" const char* st_conv_variant_name(int id) {
-  return id == 40 ? "stem6x6s2" : id == 41 ? "pw128" : conv_variant_name(id);
+  return id == 40 ? "stem6x6s2" : id == 41 ? "pw128" : id == 42 ? "dc4x32" : conv_variant_name(id);
 }
 extern "C" const char* st_conv_variant_signature(int id) {
-  return id == 40 ? "stem_focus_conv" : id == 41 ? "pw_conv" : conv_variant_signature(id);
+  return id == 40 ? "stem_focus_conv" : id == 41 ? "pw_conv" : id == 42 ? "direct_conv3x3"
+                                                              : conv_variant_signature(id);
 }
 
 // Read / restore the per-op tile choice (one int per op, -1 = heuristic) so a tuning result can be
@@ -864,7 +869,7 @@ extern "C" int st_detector_set_tuning(StDetector* det, const int* variants, int 
   for (int i = 0; i < n; ++i) {
     const Op& o = det->ops[i];
     if (variants[i] < 0 || o.type != Op::CONV) continue;
-    if (variants[i] == 41) continue;   // streaming 1x1 kernel: its own applicability check runs at launch
+    if (variants[i] == 41 || variants[i] == 42) continue;   // own applicability checks run at launch
     ST_REQUIRE(conv_variant_valid(variants[i], det->convs[o.pc].cout), "st_detector_set_tuning: variant %d invalid for op %d",
                variants[i], i);
   }

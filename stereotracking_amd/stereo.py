@@ -101,7 +101,7 @@ class StereoCostVolume(nn.Module):
                          torch.zeros(N, Hf, Wf, D, dtype=torch.float32, device=dev))
         return self._vol
 
-    def autotune(self, dev, N, Hf, Wf, reps=5, candidates=range(22)):
+    def autotune(self, dev, N, Hf, Wf, reps=5, candidates=tuple(range(22)) + (42,)):
         """Pick the aggregation convs' tile variant by measurement (same policy as st_detector_autotune:
         min over `reps` individually timed launches).  Returns the chosen variant id."""
         if not self.agg_layers:

@@ -343,3 +343,32 @@ def test_chained_pointwise_pair_matches_torch(cin, N, H, W, cuda):
     # pairs that cannot be chained are refused
     b.Cin = 64
     assert lib.st_conv1x1_chain(C.byref(a), C.byref(b), _lib.current_stream()) != 0
+
+
+@pytest.mark.parametrize('cin,cout,res,act,shape,in_ld,in_off', [
+    (48, 48, False, 1, (2, 23, 41), None, 0),     # cost-volume aggregation conv: Cout = 48 exact, ragged tiles
+    (48, 48, False, 0, (1, 8, 64), None, 0),      # last aggregation layer: no activation, exact tiles
+    (32, 32, True, 1, (2, 19, 70), None, 0),      # CSP bottleneck conv2 + identity
+    (64, 64, True, 1, (1, 9, 33), 96, 32),        # input channel slice of a wider buffer, + residual
+    (32, 64, False, 1, (1, 5, 7), None, 0),       # image smaller than one tile
+    (64, 32, False, 1, (3, 12, 40), None, 0),
+])
+def test_direct_conv3x3_kernel_matches_torch(cin, cout, res, act, shape, in_ld, in_off, cuda):
+    """Tile variant 42 (direct_conv.hip, 16x16x4 MFMA, window in LDS, per-tap weights) == conv3x3/s1/p1 + bias +
+    SiLU (+ (v + res) * post_scale): zero padding from the DMA range check, ragged tiles, channel slices."""
+    torch.manual_seed(cin * 3 + cout + shape[2])
+    N, H, W = shape
+    x = torch.randn(N, cin, H, W)
+    w = torch.randn(cout, cin, 3, 3) / (9 * cin) ** 0.5
+    b = torch.randn(cout)
+    r = torch.randn(N, cout, H, W) if res else None
+    got, _ = run_conv(x, w, b, 1, 1, act, cuda, variant=42, res=r, post_scale=0.5 if res else 1.0, in_ld=in_ld,
+                      in_off=in_off)
+    assert_close(got, ref_conv(x, w, b, 1, 1, act, r, 0.5 if res else 1.0))
+
+
+def test_direct_conv3x3_kernel_rejects_other_shapes(cuda):
+    for cin, cout, k, s in ((40, 48, 3, 1), (48, 48, 1, 1), (48, 48, 3, 2), (32, 128, 3, 1)):
+        with pytest.raises(Exception, match='not supported by the direct 3x3 kernel'):
+            run_conv(torch.randn(1, cin, 8, 8), torch.randn(cout, cin, k, k), torch.zeros(cout), s, k // 2, 1, cuda,
+                     variant=42)
