@@ -119,7 +119,8 @@ def conv_roofline(pipe, img, right, steps):
     # instance a layer uses is an autotune outcome that varies from run to run, so the roofline entry aggregates
     # all instances: algorithmic flop of all its launches / their summed duration).  The fused stem kernel and the
     # per-instance table are listed next to it.
-    OTHER = ('stem6x6s2', 'pw128', 'skipped')   # separate kernels (stem_focus_conv.hip, pointwise_conv.hip)
+    # separate kernels (stem_focus_conv.hip, pointwise_conv.hip, direct_conv.hip), listed in per_variant only
+    OTHER = ('stem6x6s2', 'pw128', 'dc4x32', 'skipped')
     inst = {k: v for k, v in per_variant.items() if k not in OTHER}
     n_launch = sum(v['launches'] for v in inst.values())
     ms_inst = sum(v['ms_per_step'] for v in inst.values())
@@ -146,8 +147,8 @@ def conv_roofline(pipe, img, right, steps):
             traffic = int(tot_b / n_launch)
             traffic_src = 'profiles/r01_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE), launch-weighted'
     roof = dict(bound='mfma',
-                kernel='st::conv_igemm_kernel<...> (all tile instances; the fused stem kernel and the streaming 1x1 '
-                       'kernel are listed in per_variant as stem6x6s2 / pw128)',
+                kernel='st::conv_igemm_kernel<...> (all tile instances; the fused stem kernel, the streaming 1x1 '
+                       'kernel and the direct 3x3 kernel are listed in per_variant as stem6x6s2 / pw128 / dc4x32)',
                 achieved=round(tf_inst, 3), peak=PEAK_FP32_MFMA_TFLOPS, unit='TFLOP/s',
                 frac=round(tf_inst / PEAK_FP32_MFMA_TFLOPS, 4), traffic=traffic, traffic_source=traffic_src,
                 flop_per_launch=round(gf_inst * 1e9 / n_launch),
