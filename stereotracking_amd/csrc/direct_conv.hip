@@ -102,6 +102,22 @@ __global__ __launch_bounds__(256, 2) void direct_conv3x3_kernel(const DcArgs p) 
     }
   };
   wt_dma(0, 0);
+  // residual of this lane's outputs: issued now, consumed in the epilogue (its HBM latency rides under the MFMAs)
+  const int oy = y0 + wave;
+  f32x4 rv[RES ? CB : 1][2];
+  if (RES) {
+#pragma unroll
+    for (int pb = 0; pb < 2; ++pb) {
+      const int ox = x0 + pb * 16 + i16;
+      const bool ok = oy < p.H && ox < p.W;
+      const int m = (n * p.H + oy) * p.W + ox;
+#pragma unroll
+      for (int cb = 0; cb < CB; ++cb) {
+        const unsigned roff = ok ? (unsigned)((m * p.res_ld + p.res_off + cb * 16 + 4 * kq) * 4) : 0x80000000u;
+        rv[RES ? cb : 0][pb] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rrsrc, roff, 0, 0));
+      }
+    }
+  }
 
   f32x4 acc[CB][2];
 #pragma unroll
@@ -147,7 +163,6 @@ __global__ __launch_bounds__(256, 2) void direct_conv3x3_kernel(const DcArgs p) 
   }
 
   // ---- epilogue: D[co][pixel]: lane = pixel (pb*16 + i16), couts cb*16 + 4*kq + {0..3}
-  const int oy = y0 + wave;
 #pragma unroll
   for (int pb = 0; pb < 2; ++pb) {
     const int ox = x0 + pb * 16 + i16;
@@ -157,17 +172,12 @@ __global__ __launch_bounds__(256, 2) void direct_conv3x3_kernel(const DcArgs p) 
     for (int cb = 0; cb < CB; ++cb) {
       const int co = cb * 16 + 4 * kq;
       const f32x4 bq = *reinterpret_cast<const f32x4*>(p.bias + co);
-      f32x4 rv = {0.f, 0.f, 0.f, 0.f};
-      if (RES) {
-        const unsigned roff = ok ? (unsigned)((m * p.res_ld + p.res_off + co) * 4) : 0x80000000u;
-        rv = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rrsrc, roff, 0, 0));
-      }
       f32x4 v;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         float x = acc[cb][pb][e] + bq[e];
         if (p.act) x = dc_silu(x);
-        if (RES) x = (x + rv[e]) * p.post_scale;
+        if (RES) x = (x + rv[RES ? cb : 0][pb][e]) * p.post_scale;
         v[e] = x;
       }
       const unsigned off = ok ? (unsigned)((m * p.out_ld + p.out_off + co) * 4) : 0x80000000u;
