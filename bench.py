@@ -135,17 +135,18 @@ def conv_roofline(pipe, img, right, steps):
     tpath = os.path.join(ROOT, 'profiles', 'r01_hbm_traffic.json')
     if os.path.exists(tpath):
         tj = json.load(open(tpath))
-        tot_b, ok = 0.0, True
+        tot_b, cov = 0.0, 0
         for name, v in inst.items():
             vid = next(i for i, n in VARIANT_TILES.items() if n == name)
             row = tj.get('st::conv_igemm_kernel<%s>' % lib.st_conv_variant_signature(vid).decode())
             if not row or row.get('fetch_bytes_corrected_per_launch') is None:
-                ok = ok and v['gflop_per_step'] < 0.5    # tiny instances (1x1 prediction convs) may be absent
-                continue
+                continue   # this run's autotune picked an instance the committed PMC passes did not see
             tot_b += v['launches'] * (row['fetch_bytes_corrected_per_launch'] + (row.get('write_bytes_per_launch') or 0))
-        if ok and tot_b > 0:
-            traffic = int(tot_b / n_launch)
-            traffic_src = 'profiles/r01_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE), launch-weighted'
+            cov += v['launches']
+        if cov >= 0.5 * n_launch and tot_b > 0:
+            traffic = int(tot_b / cov)
+            traffic_src = ('profiles/r01_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE), launch-weighted '
+                           'over the %d of %d launches whose tile instance is in that profile' % (cov, n_launch))
     roof = dict(bound='mfma',
                 kernel='st::conv_igemm_kernel<...> (all tile instances; the fused stem kernel, the streaming 1x1 '
                        'kernel and the direct 3x3 kernel are listed in per_variant as stem6x6s2 / pw128 / dc4x32)',
