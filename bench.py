@@ -31,8 +31,8 @@ PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md, v_mfma_f32_32x32x2_f32 den
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=20)
-    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--steps', type=int, default=50)
+    ap.add_argument('--warmup', type=int, default=10)
     ap.add_argument('--batch', type=int, default=8, help='stereo pairs per GPU per step')
     ap.add_argument('--max-disp', type=int, default=192)
     ap.add_argument('--agg-layers', type=int, default=2, help='3x3 aggregation convs over the cost volume')
