@@ -25,7 +25,9 @@ def rel_err(got, ref):
     return ((got - ref).abs() / ref.abs().clamp(min=1.0)).max().item()
 
 
-@pytest.mark.parametrize('widen,N,H,W', [(0.375, 2, 96, 160), (0.5, 1, 192, 320), (0.5, 2, 64, 96)])
+@pytest.mark.parametrize('widen,N,H,W', [(0.375, 2, 96, 160), (0.5, 1, 192, 320), (0.5, 2, 64, 96),
+                                         (1.0, 1, 64, 96),     # stem 64 wide: two MFMA column blocks in the fused stem
+                                         (1.25, 1, 64, 64)])   # stem 80 wide: focus_pack + generic conv fallback
 def test_detector_head_parity(widen, N, H, W, cuda):
     det, ora = build_pair(widen, 0.33, N, H, W)
     batch = synthetic_batch(list(range(N)), H - 16, W, 64)
