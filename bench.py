@@ -36,6 +36,8 @@ def parse():
     ap.add_argument('--batch', type=int, default=8, help='stereo pairs per GPU per step')
     ap.add_argument('--max-disp', type=int, default=192)
     ap.add_argument('--agg-layers', type=int, default=2, help='3x3 aggregation convs over the cost volume')
+    ap.add_argument('--max-det', type=int, default=1000,
+                    help='rows of the fixed-size detection buffer per frame (a capacity: overflow is an error)')
     ap.add_argument('--inflight', type=int, default=3,
                     help='pipeline contexts fed round-robin, one HIP stream each (1 = strictly serial steps)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -267,19 +269,20 @@ def main():
     # `inflight` contexts (own workspace + HIP stream each): step i runs on context i % inflight, so the launch
     # tails and the latency-bound decode / NMS / depth kernels of one batch overlap the convs of the next
     runner = InflightPipelines(max(1, args.inflight), B, (720, 1280), 0.5, 0.33, 1, stereo=True,
-                               max_disp=args.max_disp, max_det=300, agg_layers=args.agg_layers)
+                               max_disp=args.max_disp, max_det=args.max_det, agg_layers=args.agg_layers)
     pipe = runner.pipes[0]
     sd = synthetic_state_dict(runner.param_table(), seed=0)
     runner.load_state_dict(sd, tuning_cache=os.environ.get('ST_TUNE_CACHE'))
     # every rank gets its own 8 pairs (weak scaling: frames shard across ranks)
     batch_cpu = synthetic_batch([rank * B + i for i in range(B)], 720, 1280, args.max_disp)
     img, right = batch_cpu['img'].to(dev), batch_cpu['right'].to(dev)
-    gathered = [torch.empty(world * B, pipe.max_det, 8, device=cdev) for _ in runner.pipes] if world > 1 else None
+    gathered = [torch.empty(world * B, pipe.max_det + 1, 8, device=cdev) for _ in runner.pipes] if world > 1 else None
 
     def post(out, ctx):   # runs under the context's stream
-        dets = pipe.pack_detections(out)
-        if world > 1:  # ONE collective per shard of frames: the fixed-size detection buffers (76.8 KB / rank)
+        dets = pipe.pack_detections(out)   # self-describing frame records: header row (true count) + max_det rows
+        if world > 1:  # ONE collective per shard of frames: the fixed-size records (8 x 32 KB / rank)
             dist.all_gather_into_tensor(gathered[ctx], dets if backend == 'nccl' else dets.cpu())
+        out['records'] = gathered[ctx] if world > 1 else dets
         return out
 
     def step():
@@ -307,6 +310,12 @@ def main():
         dt = float(t.item())
 
     counts = out['counts'].cpu().tolist()
+    rec_counts = out['records'][:, 0, 0].cpu().long().tolist()   # what the tracker side of the all-gather sees
+    if rec_counts[rank * B:(rank + 1) * B] != counts:
+        raise SystemExit(f'gathered frame records disagree with the local counts: {rec_counts} vs {counts}')
+    if max(rec_counts) > pipe.max_det:
+        raise SystemExit(f'detection buffer overflow: kept {rec_counts} > max_det={pipe.max_det} (raise --max-det); '
+                         'the reference applies no cap, a truncated run is not a valid measurement')
     line = {
         'metric': 'stereo frame-pairs/sec @1280x720 D=192', 'value': round(world * B * args.steps / dt, 3),
         'unit': 'stereo frame-pairs/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
@@ -318,7 +327,7 @@ def main():
                                'decode+NMS, per-box depth',
                    'global_batch': world * B, 'inflight_contexts': len(runner),
                    'parallelism': f'frames sharded x{world}, one all-gather of detections per step ({backend})',
-                   'detections_kept_rank0': counts},
+                   'detections_kept_rank0': counts, 'max_det': pipe.max_det, 'detections_overflow': False},
     }
     if rank == 0:
         roof = conv_roofline(pipe, img, right, max(3, min(args.steps, 10)))

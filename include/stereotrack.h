@@ -243,13 +243,18 @@ typedef struct StDecodeDesc {
   float scale_x, scale_y; /* scale_factor (w,h); boxes /= scale before NMS */
   float pad_left, pad_top;/* pad_param subtracted before scaling (0 if none) */
   float ori_w, ori_h;     /* clamp range after NMS */
+  int nms_mask_rows;      /* candidates (in score order) whose pairwise IoU bits are precomputed chip-wide;
+                           * 0 = default 4096.  Sizes the workspace (rows^2 / 8 bytes per image); later
+                           * candidates are resolved on the fly by one wave - results do not depend on it */
 } StDecodeDesc;
 
 size_t st_decode_nms_workspace_bytes(const StDecodeDesc* d);
 /* outputs per image n: out_boxes[n][max_det][4] (xyxy), out_scores[n][max_det],
  * out_labels[n][max_det] (int64), out_prior_idx[n][max_det] (flat prior index,
  * the bit-exact identity of a kept box), out_count[n] = number kept (may exceed
- * max_det: then only the first max_det are stored). */
+ * max_det: then only the first max_det are stored - the reference applies NO cap under
+ * yolox_style=True, so callers must treat out_count[n] > max_det as an overflow and re-run with a
+ * larger buffer or raise; rows past min(count, max_det) are left untouched). */
 int st_decode_nms(const StDecodeDesc* d, const float* head_out_dev, void* workspace_dev,
                   size_t workspace_bytes, st_stream_t stream, float* out_boxes_dev,
                   float* out_scores_dev, int64_t* out_labels_dev, int32_t* out_prior_idx_dev,
@@ -290,6 +295,19 @@ int st_box_depth(const float* disp_dev, size_t img_pitch, int N, int H, int W,
                  const float* boxes_dev, const int32_t* counts_dev, int max_det, float baseline,
                  float focal, void* workspace_dev, size_t workspace_bytes, st_stream_t stream,
                  float* out_depth_dev, float* out_scale_dev, float* out_scaled_boxes_dev);
+/* rows k >= min(counts[n], max_det) of the three outputs are written as 0 (never stale). */
+
+/* ------------------------------------------------------------------------
+ * 7. Linear assignment of the CPU association step (HOST function, no GPU):
+ *    replaces `lap.lapjv(dists, extend_cost=True, cost_limit=1 - match_iou_thr)`,
+ *    reference mmtrack/models/trackers/ocsort_tracker_disparity.py:260-261, :312-313.
+ *    cost: row-major float64 [n_rows][n_cols] (tracks x detections).
+ *    x_out[n_rows] = column matched to row i or -1; y_out[n_cols] = row matched to
+ *    column j or -1.  Dense Jonker-Volgenant on lap's (n_rows+n_cols)^2 extension, so
+ *    that non-unique optima resolve as they do there.  NaN costs are unmatchable.
+ * ---------------------------------------------------------------------- */
+int st_lapjv_extended(const double* cost, int n_rows, int n_cols, double cost_limit,
+                      int32_t* x_out, int32_t* y_out);
 
 #ifdef __cplusplus
 }

@@ -51,7 +51,7 @@ class StDecodeDesc(C.Structure):
         ('level_offset', C.c_size_t * 4),
         ('score_thr', C.c_float), ('iou_thr', C.c_float), ('max_det', C.c_int),
         ('scale_x', C.c_float), ('scale_y', C.c_float), ('pad_left', C.c_float), ('pad_top', C.c_float),
-        ('ori_w', C.c_float), ('ori_h', C.c_float),
+        ('ori_w', C.c_float), ('ori_h', C.c_float), ('nms_mask_rows', C.c_int),
     ]
 
 
@@ -95,6 +95,7 @@ _PROTOS = {
     'st_detector_tap': (_i, [_vp, C.c_char_p, _vp, C.POINTER(_vp), C.POINTER(_i), C.POINTER(_i),
                              C.POINTER(_i), C.POINTER(_i), C.POINTER(_i)]),
     'st_decode_nms_workspace_bytes': (_sz, [C.POINTER(StDecodeDesc)]),
+    'st_lapjv_extended': (_i, [_vp, _i, _i, C.c_double, _vp, _vp]),
     'st_decode_nms': (_i, [C.POINTER(StDecodeDesc), _vp, _vp, _sz, _vp, _vp, _vp, _vp, _vp, _vp]),
     'st_costvolume_softargmin': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _f, _vp, _vp, _vp]),
     'st_softargmin': (_i, [_vp, _i, _i, _i, _i, _f, _vp, _vp]),

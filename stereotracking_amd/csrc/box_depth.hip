@@ -193,7 +193,16 @@ __global__ __launch_bounds__(512) void box_depth_kernel(const float* __restrict_
   __shared__ int s_cnt[4][512];
   const int n = blockIdx.y, k = blockIdx.x;
   const int cnt_n = min(counts[n], max_det);
-  if (k >= cnt_n) return;  // block-uniform
+  if (k >= cnt_n) {  // block-uniform: rows past the count are defined (zero), never stale
+    if (threadIdx.x == 0) {
+      const size_t o = (size_t)n * max_det + k;
+      out_depth[o] = 0.f;
+      out_scale[o] = 0.f;
+      const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+      *reinterpret_cast<f32x4*>(out_sboxes + o * 4) = z;
+    }
+    return;
+  }
   const float* disp = disp_all + (size_t)n * img_pitch;
   const f32x4 bx = *reinterpret_cast<const f32x4*>(boxes + ((size_t)n * max_det + k) * 4);
   const int x1 = (int)bx[0], y1 = (int)bx[1], x2 = (int)bx[2], y2 = (int)bx[3];

@@ -56,7 +56,9 @@ struct DecodeArgs {
   int lvl_start[5];  // first flat prior index of each level
   int P;             // priors per image
   int cap;           // max candidates entering NMS (nms_pre)
-  int Tcap;          // ceil(cap/64)
+  int mcap;          // rows / columns of the precomputed IoU bit mask (multiple of 64); candidates past it
+                     // are resolved on the fly by the reduce kernel (identical results, slower)
+  int Tm;            // mcap / 64: mask words per row
   int batch;
   float score_thr, iou_thr;
   int max_det;
@@ -68,7 +70,7 @@ struct DecodeArgs {
   f32x4* s_box;      // [N][cap]
   float* s_score;    // [N][cap]
   int* s_idx;        // [N][cap]
-  u64* mask;         // [N][cap][Tcap]
+  u64* mask;         // [N][mcap][Tm]
 };
 
 __global__ __launch_bounds__(256) void decode_filter_kernel(DecodeArgs a) {
@@ -152,11 +154,11 @@ __device__ __forceinline__ bool iou_gt(const f32x4& bi, float ai, const f32x4& b
 
 __global__ __launch_bounds__(256) void nms_mask_kernel(DecodeArgs a) {
   const int n = blockIdx.y;
-  const int K = min(a.count[n], a.cap);
+  const int K = min(min(a.count[n], a.cap), a.mcap);   // the mask covers the first mcap candidates
   const int T = (K + 63) >> 6;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const f32x4* boxes = a.s_box + (size_t)n * a.cap;
-  u64* mask = a.mask + (size_t)n * a.cap * a.Tcap;
+  u64* mask = a.mask + (size_t)n * a.mcap * a.Tm;
   const long long items = (long long)T * T;
   for (long long it = (long long)blockIdx.x * 4 + wave; it < items; it += (long long)gridDim.x * 4) {
     const int ti = (int)(it / T), tj = (int)(it - (long long)ti * T);
@@ -175,7 +177,7 @@ __global__ __launch_bounds__(256) void nms_mask_kernel(DecodeArgs a) {
       const bool later = (ti != tj) || (jj > lane);
       if (later && iou_gt(bi, ai, b, a.iou_thr)) bits |= 1ull << jj;
     }
-    if (i < K) mask[(size_t)i * a.Tcap + tj] = bits;
+    if (i < K) mask[(size_t)i * a.Tm + tj] = bits;
   }
 }
 
@@ -187,18 +189,32 @@ __global__ __launch_bounds__(64) void nms_reduce_kernel(DecodeArgs a, float* out
   const int lane = threadIdx.x;
   const int K = min(a.count[n], a.cap);
   const int T = (K + 63) >> 6;
+  const int Tm = min(T, a.Tm);   // chunks [0, Tm) have their IoU bits in the mask, chunks [Tm, T) do not
   const f32x4* boxes = a.s_box + (size_t)n * a.cap;
   const float* scores = a.s_score + (size_t)n * a.cap;
   const int* idx = a.s_idx + (size_t)n * a.cap;
-  const u64* mask = a.mask + (size_t)n * a.cap * a.Tcap;
+  const u64* mask = a.mask + (size_t)n * a.mcap * a.Tm;
+  const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
   for (int w = lane; w < T; w += 64) removed[w] = 0ull;
   __syncthreads();
   int outcount = 0;
   for (int c = 0; c < T; ++c) {
     u64 rem = removed[c];
     const int i = c * 64 + lane;
-    const u64 d = i < K ? mask[(size_t)i * a.Tcap + c] : 0ull;
     const int nb = min(64, K - c * 64);
+    const f32x4 bi = i < K ? boxes[i] : zero;
+    const float ai = (bi[2] - bi[0]) * (bi[3] - bi[1]);
+    u64 d = 0ull;
+    if (c < Tm) {
+      d = i < K ? mask[(size_t)i * a.Tm + c] : 0ull;
+    } else {   // diagonal tile on the fly (same bits nms_mask_kernel would have written)
+      for (int jj = 0; jj < nb; ++jj) {
+        f32x4 b;
+        b[0] = __shfl(bi[0], jj); b[1] = __shfl(bi[1], jj);
+        b[2] = __shfl(bi[2], jj); b[3] = __shfl(bi[3], jj);
+        if (jj > lane && i < K && iou_gt(bi, ai, b, a.iou_thr)) d |= 1ull << jj;
+      }
+    }
     u64 keep = 0ull;
     for (int b = 0; b < nb; ++b) {  // wave-uniform serial resolve of the diagonal tile
       const u64 db = __shfl(d, b);
@@ -209,22 +225,38 @@ __global__ __launch_bounds__(64) void nms_reduce_kernel(DecodeArgs a, float* out
     }
     // OR the rows of the boxes kept in this chunk into the later words: lane = kept row, streaming its own
     // mask row (independent loads, deep memory-level parallelism) and ds_or-ing into the LDS bitmap
-    if ((keep >> lane) & 1ull) {
-      const u64* row = mask + (size_t)i * a.Tcap;
-      for (int w = c + 1; w < T; ++w) {
+    if (c < Tm && ((keep >> lane) & 1ull)) {
+      const u64* row = mask + (size_t)i * a.Tm;
+      for (int w = c + 1; w < Tm; ++w) {
         const u64 m = row[w];
         if (m) atomicOr(reinterpret_cast<unsigned long long*>(&removed[w]), (unsigned long long)m);
       }
     }
+    // column chunks the mask does not cover: lane = column, the kept rows of this chunk are broadcast one by one
+    for (int w = max(c + 1, Tm); w < T; ++w) {   // wave-uniform
+      const int j = w * 64 + lane;
+      const f32x4 bj = j < K ? boxes[j] : zero;
+      bool sup = false;
+      u64 kk = keep;
+      while (kk) {
+        const int b = __builtin_ctzll(kk);
+        kk &= kk - 1ull;
+        f32x4 r;
+        r[0] = __shfl(bi[0], b); r[1] = __shfl(bi[1], b); r[2] = __shfl(bi[2], b); r[3] = __shfl(bi[3], b);
+        const float ar = __shfl(ai, b);
+        sup = sup || iou_gt(r, ar, bj, a.iou_thr);
+      }
+      const u64 bits = __ballot(sup && j < K);
+      if (lane == 0 && bits) removed[w] |= bits;
+    }
     if ((keep >> lane) & 1ull) {
       const int pos = outcount + __builtin_popcountll(keep & ((1ull << lane) - 1ull));
       if (pos < a.max_det) {
-        const f32x4 b = boxes[i];
         f32x4 o;
-        o[0] = fminf(fmaxf(b[0], 0.0f), a.ori_w);
-        o[1] = fminf(fmaxf(b[1], 0.0f), a.ori_h);
-        o[2] = fminf(fmaxf(b[2], 0.0f), a.ori_w);
-        o[3] = fminf(fmaxf(b[3], 0.0f), a.ori_h);
+        o[0] = fminf(fmaxf(bi[0], 0.0f), a.ori_w);
+        o[1] = fminf(fmaxf(bi[1], 0.0f), a.ori_h);
+        o[2] = fminf(fmaxf(bi[2], 0.0f), a.ori_w);
+        o[3] = fminf(fmaxf(bi[3], 0.0f), a.ori_h);
         const size_t oo = (size_t)n * a.max_det + pos;
         *reinterpret_cast<f32x4*>(out_boxes + oo * 4) = o;
         out_scores[oo] = scores[i];
@@ -240,7 +272,7 @@ __global__ __launch_bounds__(64) void nms_reduce_kernel(DecodeArgs a, float* out
 
 struct DecodeLayout {
   size_t count, cand_key, cand_box, s_box, s_score, s_idx, mask, total;
-  int P, cap, Tcap;
+  int P, cap, mcap, Tm;
 };
 
 static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
@@ -258,8 +290,12 @@ static int decode_layout(const StDecodeDesc& d, DecodeLayout& L) {
   ST_REQUIRE(P < (1 << 30), "st_decode_nms: too many priors");
   L.P = (int)P;
   L.cap = L.P;  // nms_pre default (100000) >= priors: every candidate enters NMS
-  L.Tcap = (L.cap + 63) / 64;
-  ST_REQUIRE(L.Tcap <= 512, "st_decode_nms: more than 32768 candidates per image not supported");
+  ST_REQUIRE((L.cap + 63) / 64 <= 512, "st_decode_nms: more than 32768 candidates per image not supported");
+  // IoU bit mask for the first `mcap` candidates in score order (a few hundred to a few thousand pass the score
+  // threshold in practice); later candidates are resolved on the fly: the workspace no longer grows with P^2
+  ST_REQUIRE(d.nms_mask_rows >= 0, "st_decode_nms: nms_mask_rows must be >= 0");
+  L.mcap = std::min((L.cap + 63) / 64 * 64, ((d.nms_mask_rows > 0 ? d.nms_mask_rows : 4096) + 63) / 64 * 64);
+  L.Tm = L.mcap / 64;
   size_t o = 0;
   L.count = o; o = align256(o + sizeof(int) * d.batch);
   L.cand_key = o; o = align256(o + sizeof(u64) * (size_t)d.batch * L.P);
@@ -267,7 +303,7 @@ static int decode_layout(const StDecodeDesc& d, DecodeLayout& L) {
   L.s_box = o; o = align256(o + sizeof(f32x4) * (size_t)d.batch * L.cap);
   L.s_score = o; o = align256(o + sizeof(float) * (size_t)d.batch * L.cap);
   L.s_idx = o; o = align256(o + sizeof(int) * (size_t)d.batch * L.cap);
-  L.mask = o; o = align256(o + sizeof(u64) * (size_t)d.batch * L.cap * L.Tcap);
+  L.mask = o; o = align256(o + sizeof(u64) * (size_t)d.batch * L.mcap * L.Tm);
   L.total = o;
   return ST_OK;
 }
@@ -306,7 +342,7 @@ extern "C" int st_decode_nms(const StDecodeDesc* d, const float* head_out_dev, v
     start += d->level_h[l] * d->level_w[l];
   }
   a.lvl_start[d->num_levels] = start;
-  a.P = L.P; a.cap = L.cap; a.Tcap = L.Tcap; a.batch = d->batch;
+  a.P = L.P; a.cap = L.cap; a.mcap = L.mcap; a.Tm = L.Tm; a.batch = d->batch;
   a.score_thr = d->score_thr; a.iou_thr = d->iou_thr; a.max_det = d->max_det;
   a.scale_x = d->scale_x; a.scale_y = d->scale_y; a.pad_left = d->pad_left; a.pad_top = d->pad_top;
   a.ori_w = d->ori_w; a.ori_h = d->ori_h;

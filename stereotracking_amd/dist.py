@@ -39,9 +39,9 @@ def shard_frames(num_frames, rank=None, world_size=None):
 
 
 def gather_detections(local, counts=None):
-    """local: (F_local, M, 8) fixed-size detection buffer of this rank's frames
-    (x1,y1,x2,y2,score,label,depth,scale; rows past `counts` are padding).
-    Returns (world*F_local, M, 8) [and gathered counts] on every rank, in rank = frame order.
+    """local: (F_local, M + 1, 8) frame records of this rank's frames (pack_detections: header row with the
+    true count + M rows x1,y1,x2,y2,score,label,depth,scale) - or any fixed-size buffer.
+    Returns (world*F_local, ...) [and gathered `counts` when given] on every rank, in rank = frame order.
     One collective per shard, never per frame: the payload is KBs, the cost is launch latency."""
     rank, w = world()
     if w == 1:
@@ -55,8 +55,22 @@ def gather_detections(local, counts=None):
     return out, cout
 
 
-def unpack_frame(buf, count):
-    """(M, 8) row block -> dict of tensors for the tracker (first `count` rows)."""
-    k = int(count)
-    b = buf[:k]
+class DetectionOverflow(RuntimeError):
+    """A frame kept more boxes than the fixed-size detection buffer holds.  The reference applies no cap
+    (yolox_style=True), so dropping the surplus would change the tracker's input: fail loudly instead."""
+
+
+def unpack_frame(record, frame=None):
+    """One frame record (M + 1, 8) (StereoDensePipeline.pack_detections) -> dict of tensors for the tracker.
+    Raises DetectionOverflow when the frame kept more boxes than the buffer has rows."""
+    k, cap = int(record[0, 0]), int(record[0, 1])
+    if k > cap:
+        raise DetectionOverflow(f'frame {frame}: {k} detections kept but the detection buffer has {cap} rows; '
+                                f'build the pipeline with a larger max_det')
+    b = record[1:1 + k]
     return dict(bboxes=b[:, :4], scores=b[:, 4], labels=b[:, 5].long(), depth=b[:, 6], scales=b[:, 7])
+
+
+def record_counts(records):
+    """(F, M + 1, 8) records -> (counts (F,) int64, capacity M)."""
+    return records[:, 0, 0].long(), records.shape[1] - 1

@@ -173,7 +173,8 @@ class HipDetector:
         return cls, reg, obj
 
     # ---- decode + NMS ------------------------------------------------------------------------
-    def decode_desc(self, score_thr, iou_thr, max_det, ori_shape, scale_factor=(1.0, 1.0), pad_param=None):
+    def decode_desc(self, score_thr, iou_thr, max_det, ori_shape, scale_factor=(1.0, 1.0), pad_param=None,
+                    nms_mask_rows=0):
         d = StDecodeDesc()
         d.struct_size = C.sizeof(StDecodeDesc)
         d.batch = self.batch
@@ -186,15 +187,18 @@ class HipDetector:
         d.pad_left = float(pad_param[2]) if pad_param is not None else 0.0
         d.pad_top = float(pad_param[0]) if pad_param is not None else 0.0
         d.ori_h, d.ori_w = float(ori_shape[0]), float(ori_shape[1])
+        d.nms_mask_rows = int(nms_mask_rows)
         return d
 
-    def decode_nms(self, head_out, score_thr=0.01, iou_thr=0.5, max_det=300, ori_shape=None,
-                   scale_factor=(1.0, 1.0), pad_param=None):
+    def decode_nms(self, head_out, score_thr=0.01, iou_thr=0.5, max_det=1000, ori_shape=None,
+                   scale_factor=(1.0, 1.0), pad_param=None, nms_mask_rows=0):
         """-> boxes (N,max_det,4), scores (N,max_det), labels (N,max_det) int64,
-        prior_idx (N,max_det) int32, counts (N,) int32 — all on device, no host sync."""
+        prior_idx (N,max_det) int32, counts (N,) int32 — all on device, no host sync.  counts[n] is the
+        TRUE number kept; counts[n] > max_det means the buffer overflowed (the reference applies no cap
+        under yolox_style=True) and the caller must raise or re-run with a larger max_det."""
         _require_cuda(head_out, 'head_out')
         ori_shape = ori_shape or (self.height, self.width)
-        d = self.decode_desc(score_thr, iou_thr, max_det, ori_shape, scale_factor, pad_param)
+        d = self.decode_desc(score_thr, iou_thr, max_det, ori_shape, scale_factor, pad_param, nms_mask_rows)
         nbytes = self.lib.st_decode_nms_workspace_bytes(C.byref(d))
         if nbytes == 0:
             check(-1, 'st_decode_nms_workspace_bytes')

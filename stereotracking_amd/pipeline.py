@@ -10,7 +10,6 @@ first call.  Mirrors the dense part of OCSORT_Disparity.predict (reference
 mmtrack/models/mot/ocsort_disparity.py:50-83): detector.predict (:79) + bbox_postp_depth (:82-83).
 """
 import ctypes as C
-import os
 
 import torch
 
@@ -25,7 +24,11 @@ class StereoDensePipeline:
 
     def __init__(self, batch, ori_shape=(720, 1280), widen_factor=0.5, deepen_factor=0.33, num_classes=1,
                  stereo=True, max_disp=192, feat_stride=4, temperature=32.0, score_thr=0.01, iou_thr=0.5,
-                 max_det=300, baseline=0.25, focal_length=640, pad_size_divisor=32, agg_layers=0):
+                 max_det=1000, baseline=0.25, focal_length=640, pad_size_divisor=32, agg_layers=0):
+        """max_det: rows of the fixed-size detection buffer per frame.  The reference applies NO cap on the
+        kept boxes (yolox_style=True => max_per_img = len(results)), so this is a
+        capacity, not a threshold: `run()` reports `overflow` whenever a frame kept more boxes than fit, and
+        every consumer in this package (sequence drivers, MOT shell, bench.py) raises on it."""
         self.lib = _lib.load()
         self.batch = int(batch)
         self.ori_h, self.ori_w = int(ori_shape[0]), int(ori_shape[1])
@@ -43,7 +46,6 @@ class StereoDensePipeline:
         self.det = HipDetector(self.batch, self.height, self.width, widen_factor, deepen_factor, num_classes,
                                stereo=self.stereo)
         self._bufs = None
-        self._last_post = None
 
     # ---- parameters ------------------------------------------------------------------------------
     def param_table(self):
@@ -94,9 +96,9 @@ class StereoDensePipeline:
             b['head'] = torch.empty(self.det.head_floats, **f32)
             b['disp_lr'] = torch.empty(N, H // self.feat_stride, W // self.feat_stride, **f32)
             b['disp_postp'] = torch.empty(N, 3, H, W, **f32)
-            b['depth'] = torch.empty(N, M, **f32)
-            b['scales'] = torch.empty(N, M, **f32)
-            b['scaled_boxes'] = torch.empty(N, M, 4, **f32)
+            b['depth'] = torch.zeros(N, M, **f32)       # rows past the count are written as 0 by st_box_depth
+            b['scales'] = torch.zeros(N, M, **f32)
+            b['scaled_boxes'] = torch.zeros(N, M, 4, **f32)
             self._bufs = b
         return self._bufs
 
@@ -121,7 +123,8 @@ class StereoDensePipeline:
     def run(self, img, right=None, disp_postp=None):
         """img (N,3,H,W) fp32 CUDA; stereo: right (N,3,H,W); mono: disp_postp (N,3,H,W).
         Returns a dict of device tensors (no host sync): boxes (N,M,4) unscaled xyxy, scores, labels,
-        prior_idx, counts, depth, scales, scaled_boxes, disp_postp, head."""
+        prior_idx, counts (TRUE number kept per frame), overflow (N,) bool = counts > M, depth, scales,
+        scaled_boxes, disp_postp, head.  Rows past min(counts, M) are zero (prior_idx -1)."""
         _require_cuda(img, 'img')
         b = self._buffers(img.device)
         if self.stereo:
@@ -133,21 +136,30 @@ class StereoDensePipeline:
             if disp_postp is None:
                 raise ValueError('mono pipeline needs disp_postp')
             self.det.forward(img, disp_postp, b['head'])
-        if os.environ.get('ST_ABLATE_POST') and self._last_post is not None:   # timing-only ablation (tools)
-            boxes, scores, labels, prior, counts, depth, scales, sboxes = self._last_post
-        else:
-            boxes, scores, labels, prior, counts = self.det.decode_nms(
-                b['head'], self.score_thr, self.iou_thr, self.max_det, (self.ori_h, self.ori_w))
-            depth, scales, sboxes = self.box_depth(disp_postp, boxes, counts)
-            self._last_post = (boxes, scores, labels, prior, counts, depth, scales, sboxes)
-        return dict(boxes=boxes, scores=scores, labels=labels, prior_idx=prior, counts=counts, depth=depth,
-                    scales=scales, scaled_boxes=sboxes, disp_postp=disp_postp, head=b['head'])
+        boxes, scores, labels, prior, counts = self.det.decode_nms(
+            b['head'], self.score_thr, self.iou_thr, self.max_det, (self.ori_h, self.ori_w))
+        depth, scales, sboxes = self.box_depth(disp_postp, boxes, counts)
+        return dict(boxes=boxes, scores=scores, labels=labels, prior_idx=prior, counts=counts,
+                    overflow=counts > self.max_det, depth=depth, scales=scales, scaled_boxes=sboxes,
+                    disp_postp=disp_postp, head=b['head'])
 
     @staticmethod
-    def pack_detections(out):
-        """Fixed-size buffer for the all-gather: (N, M, 8) = x1,y1,x2,y2,score,label,depth,scale."""
-        return torch.cat([out['boxes'], out['scores'][..., None], out['labels'][..., None].float(),
+    def pack_detections(out, scaled=False, n_real=None):
+        """Fixed-size, self-describing frame records for the all-gather: (N, M + 1, 8) fp32.
+        Row 0 = header [count kept (true, may exceed M = overflow), M, valid frame flag, 0...]; rows 1..M =
+        x1,y1,x2,y2,score,label,depth,scale (`scaled`: the depth-scaled boxes the tracker consumes).  A fresh
+        tensor: safe to keep after the context's buffers are reused.  Frames >= n_real are batch padding."""
+        boxes = out['scaled_boxes'] if scaled else out['boxes']
+        rows = torch.cat([boxes, out['scores'][..., None], out['labels'][..., None].float(),
                           out['depth'][..., None], out['scales'][..., None]], dim=-1)
+        N, M = rows.shape[0], rows.shape[1]
+        head = rows.new_zeros(N, 1, 8)
+        head[:, 0, 0] = out['counts'].float()
+        head[:, 0, 1] = float(M)
+        head[:, 0, 2] = 1.0
+        if n_real is not None and n_real < N:
+            head[n_real:] = 0.0
+        return torch.cat([head, rows], dim=1)
 
 
 class InflightPipelines:

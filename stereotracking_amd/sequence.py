@@ -64,21 +64,19 @@ def frames_to_batch(frames, device, use_right=True):
     return out
 
 
-def detect_shard(pipe, frames, device):
+def detect_shard(pipe, frames, device, check_overflow=True):
     """Dense path over this rank's frames, `pipe.batch` frames per launch plan.  `pipe` is a StereoDensePipeline
     (strictly serial batches) or an InflightPipelines runner (consecutive batches overlap on its streams).
-    -> (F_pad, max_det, 8) detection buffer with SCALED boxes (what the tracker consumes), counts."""
+    -> (F_pad, max_det + 1, 8) frame records (header row + SCALED boxes, what the tracker consumes), counts
+    (true counts; 0 for batch padding).  Raises DetectionOverflow if a frame kept more than max_det boxes
+    (check_overflow=False defers that to unpack_frame, after a collective, so every rank raises together)."""
     runner = pipe if hasattr(pipe, 'submit') else None
     one = runner.pipes[0] if runner is not None else pipe
     B = one.batch
-    bufs, counts = [], []
+    bufs = []
 
     def pack(out, n_real):
-        det = torch.cat([out['scaled_boxes'], out['scores'][..., None], out['labels'][..., None].float(),
-                         out['depth'][..., None], out['scales'][..., None]], dim=-1)   # fresh tensor
-        c = torch.minimum(out['counts'], torch.full_like(out['counts'], one.max_det))  # fresh tensor
-        c[n_real:] = 0
-        return det, c
+        return one.pack_detections(out, scaled=True, n_real=n_real)   # fresh tensor
 
     for i in range(0, len(frames), B):
         chunk = list(frames[i:i + B])
@@ -86,25 +84,30 @@ def detect_shard(pipe, frames, device):
         chunk = chunk + [chunk[-1]] * (B - n_real)  # pad the last batch with a repeated frame
         batch = frames_to_batch(chunk, device, use_right=one.stereo)
         if runner is not None:   # packed under the context's stream, before that context is reused
-            (det, c), _ = runner.submit(batch['img'], right=batch.get('right'), disp_postp=batch.get('disp_postp'),
-                                        post=lambda out, ctx, n=n_real: pack(out, n))
+            det, _ = runner.submit(batch['img'], right=batch.get('right'), disp_postp=batch.get('disp_postp'),
+                                   post=lambda out, ctx, n=n_real: pack(out, n))
         else:
-            det, c = pack(pipe.run(batch['img'], right=batch.get('right'), disp_postp=batch.get('disp_postp')),
-                          n_real)
+            det = pack(pipe.run(batch['img'], right=batch.get('right'), disp_postp=batch.get('disp_postp')), n_real)
         bufs.append(det)
-        counts.append(c)
     if runner is not None:
         runner.synchronize()
-    return torch.cat(bufs), torch.cat(counts)
+    records = torch.cat(bufs)
+    counts, cap = sdist.record_counts(records)
+    if check_overflow and bool((counts > cap).any()):   # one host sync per shard, after all batches were enqueued
+        bad = torch.nonzero(counts > cap).flatten().tolist()
+        raise sdist.DetectionOverflow(f'frames {bad} kept {counts[bad].tolist()} boxes, detection buffer has {cap} '
+                                      f'rows: build the pipeline with a larger max_det')
+    return records, counts.to(torch.int32)
 
 
 def track_gathered(dets, counts, num_frames, tracker, model):
-    """CPU association over gathered detections in frame order -> list of InstanceData per frame
-    (boxes unscaled back, as OCSORT_Disparity.predict does at ocsort_disparity.py:95-97)."""
-    dets, counts = dets.cpu(), counts.cpu()
+    """CPU association over gathered frame records in frame order -> list of InstanceData per frame
+    (boxes unscaled back, as OCSORT_Disparity.predict does at ocsort_disparity.py:95-97).  `counts` is
+    ignored (the records carry their own; kept in the signature for callers that still pass it)."""
+    dets = dets.cpu()
     results = []
     for t in range(num_frames):
-        f = sdist.unpack_frame(dets[t], counts[t])
+        f = sdist.unpack_frame(dets[t], frame=t)
         sample = TrackDataSample(dict(frame_id=t))
         sample.pred_det_instances = InstanceData(**f)
         trk = tracker.track(model, None, None, sample)
@@ -122,16 +125,14 @@ def run_sharded_sequence(pipe, frames, tracker, model, device):
     per_rank = (chunk + B - 1) // B * B   # equal padded length on every rank
     mine = frames[start:stop]
     if mine:
-        dets, counts = detect_shard(pipe, mine, device)
+        dets, _ = detect_shard(pipe, mine, device, check_overflow=False)   # raised after the gather, on every rank
     else:
-        dets = torch.zeros(0, pipe.max_det, 8, device=device)
-        counts = torch.zeros(0, dtype=torch.int32, device=device)
+        dets = torch.zeros(0, pipe.max_det + 1, 8, device=device)
     pad = per_rank - dets.shape[0]
     if pad:
-        dets = torch.cat([dets, dets.new_zeros(pad, pipe.max_det, 8)])
-        counts = torch.cat([counts, counts.new_zeros(pad)])
-    all_dets, all_counts = sdist.gather_detections(dets, counts)
+        dets = torch.cat([dets, dets.new_zeros(pad, pipe.max_det + 1, 8)])
+    all_dets = sdist.gather_detections(dets)   # ONE collective: the records carry their own counts
     _, world = sdist.world()
     # drop the per-rank padding: rank r holds frames [r*chunk, r*chunk + chunk) in its first `chunk` slots
     idx = torch.cat([torch.arange(r * per_rank, r * per_rank + chunk) for r in range(world)])[:T]
-    return track_gathered(all_dets[idx.to(all_dets.device)], all_counts[idx.to(all_counts.device)], T, tracker, model)
+    return track_gathered(all_dets[idx.to(all_dets.device)], None, T, tracker, model)

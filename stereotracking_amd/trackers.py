@@ -10,16 +10,18 @@ Behavioural spec (file:line in /root/reference):
     ocr_assign_ids (last-observation IoU, lapjv)                      :273-317
     online_smooth (virtual KF updates over the lost gap)              :319-343
   pop_invalid_tracks                       kalman_tracker_base.py:78-88
-  lap.lapjv(cost, extend_cost=True, cost_limit=c) is un-vendored: its published behaviour is restated in
-  `lapjv_extended` (pad to (n+m)^2 with c/2 off-blocks and a zero corner, solve, map padded matches to -1).
+  lap.lapjv(cost, extend_cost=True, cost_limit=c) is un-vendored: `lapjv_extended` calls the library's host
+  solver st_lapjv_extended (csrc/lapjv.cpp: the same dense Jonker-Volgenant procedure on the (n+m)^2 extension
+  with c/2 off-blocks and a zero corner), so that ties between equally good assignments resolve as in `lap`.
   mmdet.bbox_overlaps is un-vendored: restated in `bbox_overlaps` (eps = 1e-6 on the union).
 """
+import ctypes as C
 import math
 
 import numpy as np
 import torch
-from scipy.optimize import linear_sum_assignment
 
+from . import _lib
 from .registry import MODELS
 from .structures import InstanceData
 
@@ -51,24 +53,17 @@ def bbox_overlaps(b1, b2, eps=1e-6):
 
 def lapjv_extended(cost, cost_limit):
     """lap.lapjv(cost, extend_cost=True, cost_limit=cost_limit) -> (x, y): x[i] = column matched to row i or
-    -1, y[j] = row matched to column j or -1."""
-    cost = np.asarray(cost, dtype=np.float64)
-    # NaN costs (a NaN box out of extract_depth's empty-segment branch, ocsort_disparity.py:163-165) are
-    # undefined behaviour inside lap's C solver; here they are made unmatchable instead
-    cost = np.where(np.isfinite(cost), cost, 1e6)
+    -1, y[j] = row matched to column j or -1 (int32).  NaN costs (a NaN box out of extract_depth's empty-segment
+    branch, ocsort_disparity.py:163-165) are undefined behaviour inside lap's solver; the library makes them
+    unmatchable instead."""
+    cost = np.ascontiguousarray(cost, dtype=np.float64)
     n_rows, n_cols = cost.shape
-    n = n_rows + n_cols
-    ext = np.full((n, n), cost_limit / 2.0, dtype=np.float64)
-    ext[n_rows:, n_cols:] = 0.0
-    ext[:n_rows, :n_cols] = cost
-    r, c = linear_sum_assignment(ext)
-    x = np.full(n, -1, dtype=np.int64)
-    y = np.full(n, -1, dtype=np.int64)
-    x[r] = c
-    y[c] = r
-    x[x >= n_cols] = -1
-    y[y >= n_rows] = -1
-    return x[:n_rows].astype(np.int32), y[:n_cols].astype(np.int32)
+    x = np.empty(n_rows, dtype=np.int32)
+    y = np.empty(n_cols, dtype=np.int32)
+    _lib.check(_lib.load().st_lapjv_extended(cost.ctypes.data_as(C.c_void_p), n_rows, n_cols, float(cost_limit),
+                                             x.ctypes.data_as(C.c_void_p), y.ctypes.data_as(C.c_void_p)),
+               'st_lapjv_extended')
+    return x, y
 
 
 class _Track:

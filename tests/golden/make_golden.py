@@ -9,10 +9,14 @@ ships no fixtures of its own, so these vectors pin the oracle, not the reference
                        structured disparity map, incl. the NaN / -1 / w>800-style branches
   costvolume.npz       C-oracle cost volume + soft-argmin + upsample on seeded features
   tracker_sequence.npz 64-frame synthetic detection stream (SURVEY.md §8c fixture iv: 6 objects, dropped
-                       detections, depth-consistent scales) and the frame-by-frame output of the host
-                       OC-SORT-with-depth restatement (stereotracking_amd/trackers.py, line-by-line from reference
-                       ocsort_tracker_disparity.py:105-618): ids, boxes, depth of every returned track
-Run:  python tests/golden/make_golden.py   (deterministic; CI checks the files are reproduced)."""
+                       detections, an 8-frame occlusion, depth-consistent scales) and the frame-by-frame output of
+                       the ORACLE tracker (oracle/tracker.py: statement-by-statement restatement of reference
+                       ocsort_tracker_disparity.py:20-618, kalman_tracker_base.py:19-88, base_tracker.py:10-141,
+                       kalman_filter.py:38-189) with the SHIPPED tracker config: ids, boxes, scores, depth, scales
+  lapjv_ties.npz       <= 7x7 assignment problems with NON-UNIQUE optima: all optimal assignments enumerated by
+                       brute force, the one oracle/lapjv.py (restatement of lap.lapjv) picks is pinned
+Nothing here is produced by product code (stereotracking_amd/ supplies only the seeded synthetic INPUTS).
+Run:  python tests/golden/make_golden.py [name ...]   (deterministic; CI checks the files are reproduced)."""
 import os
 import sys
 
@@ -114,51 +118,124 @@ def costvolume():
     return dict(featL=fl, featR=fr, cost=cost, disp_lr=lr, disp_postp=up, temperature=16.0)
 
 
-def tracker_sequence():
-    from stereotracking_amd.motion import KalmanFilter
-    from stereotracking_amd.structures import InstanceData, TrackDataSample
-    from stereotracking_amd.trackers import OCSORTTracker_Disparity
-
-    class _Model:
-        motion = KalmanFilter()
-
-    rng = np.random.RandomState(51)
-    T, K = 64, 6
+def detection_stream(seed=51, T=64, K=6, occlusion=(3, 20, 28), duplicates=False):
+    """Seeded synthetic detection stream (SURVEY.md §8c fixture iv): K objects with constant velocity + noise,
+    10 % dropped detections, one object occluded for 8 frames, depth-consistent scales; boxes are the SCALED boxes
+    the tracker consumes.  `duplicates`: every 7th frame repeats a detection exactly (equal IoU => the assignment
+    optimum is not unique and the solver's tie behaviour decides the ids).  -> rows [t, x1,y1,x2,y2, score, depth, scale]."""
+    rng = np.random.RandomState(seed)
     pos = rng.uniform([100, 80], [1100, 600], (K, 2))
     vel = rng.uniform(-4, 4, (K, 2))
     size = rng.uniform(12, 50, (K, 2))
     depth = rng.uniform(5, 60, K)
     score = rng.uniform(0.35, 0.95, K)
-    trk = OCSORTTracker_Disparity(obj_score_thr=0.3, init_track_thr=0.7, weight_iou_with_det_scores=False,
-                                  match_iou_thr=0.1, num_tentatives=3, vel_consist_weight=0.2, vel_delta_t=3,
-                                  num_frames_retain=30)
-    model = _Model()
-    det_rows, out_rows = [], []
+    rows = []
     for t in range(T):
         p = pos + vel * t + rng.normal(0, 0.4, (K, 2))
         keep = (rng.uniform(size=K) > 0.1) | (t == 0)
-        keep[3] &= not (20 <= t < 28)          # an occlusion of 8 frames: the track must be re-identified
+        k_occ, t0, t1 = occlusion
+        keep[k_occ] &= not (t0 <= t < t1)          # an occlusion: the track must be re-identified
         b = np.concatenate([p - size / 2, p + size / 2], 1)[keep].astype(np.float32)
         sc = (score[keep] + rng.normal(0, 0.02, keep.sum())).astype(np.float32)
         dp = (depth[keep] + rng.normal(0, 0.2, keep.sum())).astype(np.float32)
         scl = np.clip(dp * dp / 400.0, 1.0, 3.0).astype(np.float32)
+        if duplicates and t % 7 == 3 and len(b):
+            j = t % len(b)
+            b, sc, dp, scl = (np.concatenate([a, a[j:j + 1]]) for a in (b, sc, dp, scl))
         for i in range(len(b)):
-            det_rows.append([t, *b[i], sc[i], dp[i], scl[i]])
-        s = TrackDataSample(dict(frame_id=t))
-        s.pred_det_instances = InstanceData(bboxes=torch.from_numpy(b), scores=torch.from_numpy(sc),
-                                            labels=torch.zeros(len(b), dtype=torch.long),
-                                            scales=torch.from_numpy(scl), depth=torch.from_numpy(dp))
-        r = trk.track(model, None, None, s)
+            rows.append([t, *b[i], sc[i], dp[i], scl[i]])
+    return np.asarray(rows, np.float32)
+
+
+SHIPPED_TRACKER = dict(obj_score_thr=0.3, init_track_thr=0.7, weight_iou_with_det_scores=False, match_iou_thr=0.1,
+                       num_tentatives=3, vel_consist_weight=0.2, vel_delta_t=3, num_frames_retain=30)
+"""configs/stereo_tracking/ocsort/yolox_s_mmyolo_mot_airdrone_disp.py:49-58 (the shipped values)."""
+
+
+def run_oracle_tracker(det, num_frames, **cfg):
+    """The ORACLE tracker (oracle/tracker.py, the restatement of the reference classes) over a detection stream.
+    -> rows [t, id, x1,y1,x2,y2, score, depth, scale]."""
+    from oracle import tracker as otr
+
+    class _Model:
+        motion = otr.KalmanFilter()
+
+    trk = otr.OCSORTTracker_Disparity(**cfg)
+    out = []
+    for t in range(num_frames):
+        d = det[det[:, 0] == t]
+        inst = otr.Instances(bboxes=torch.from_numpy(d[:, 1:5].copy()), scores=torch.from_numpy(d[:, 5].copy()),
+                             labels=torch.zeros(len(d), dtype=torch.long), scales=torch.from_numpy(d[:, 7].copy()),
+                             depth=torch.from_numpy(d[:, 6].copy()))
+        r = trk.track(_Model(), None, None, otr.Sample(t, inst))
         for i in range(len(r.instances_id)):
-            out_rows.append([t, int(r.instances_id[i]), *r.bboxes[i].tolist(), float(r.scores[i]),
-                             float(r.depth[i])])
-    return dict(detections=np.asarray(det_rows, np.float32), tracks=np.asarray(out_rows, np.float64),
-                num_frames=T)
+            out.append([t, int(r.instances_id[i]), *r.bboxes[i].tolist(), float(r.scores[i]), float(r.depth[i]),
+                        float(r.scales[i])])
+    return np.asarray(out, np.float64).reshape(-1, 9)
+
+
+def tracker_sequence():
+    """Fixture (iv): generated by the ORACLE tracker with the shipped tracker config; the product tracker must
+    reproduce it frame by frame (tests/test_cpu_tracker_oracle.py)."""
+    T = 64
+    det = detection_stream(51, T)
+    return dict(detections=det, tracks=run_oracle_tracker(det, T, **SHIPPED_TRACKER), num_frames=T)
+
+
+def lapjv_ties():
+    """<= 7x7 cost matrices whose optimum is NOT unique, with ALL optimal assignments enumerated by brute force and
+    the one the oracle's lapjv restatement returns pinned.  Stored padded to 7x7 (NaN outside rows x cols)."""
+    import itertools
+    from oracle.lapjv import lapjv
+    rng = np.random.RandomState(61)
+    mats, shapes, limits, chosen, n_opt = [], [], [], [], []
+
+    def all_optimal(cost, lim):
+        r, c = cost.shape
+        best, sols = None, []
+        for k in range(min(r, c) + 1):
+            for rows in itertools.combinations(range(r), k):
+                for cols in itertools.permutations(range(c), k):
+                    tot = sum(cost[i, j] for i, j in zip(rows, cols)) + (r - k) * lim / 2 + (c - k) * lim / 2
+                    x = -np.ones(r, np.int32)
+                    for i, j in zip(rows, cols):
+                        x[i] = j
+                    if best is None or tot < best - 1e-12:
+                        best, sols = tot, [x]
+                    elif abs(tot - best) <= 1e-12:
+                        sols.append(x)
+        return best, sols
+
+    cases = []
+    for t in range(400):
+        r, c = rng.randint(2, 6), rng.randint(2, 6)
+        grid = rng.choice([2, 4, 8])
+        cases.append((np.round(rng.rand(r, c) * grid) / grid, float(rng.choice([0.5, 0.75, 0.9]))))
+    for r, c in ((7, 7), (6, 7), (7, 5)):          # the largest sizes: duplicate rows / columns (equal-IoU boxes)
+        base = np.round(rng.rand(r, c) * 8) / 8
+        base[1] = base[0]
+        base[:, 2] = base[:, 1]
+        cases.append((base, 0.9))
+    for cost, lim in cases:
+        best, sols = all_optimal(cost, lim)
+        if len(sols) < 2:
+            continue
+        opt, x, y = lapjv(cost, True, lim)
+        assert any(np.array_equal(x, s) for s in sols), 'oracle lapjv returned a non-optimal assignment'
+        pad = np.full((7, 7), np.nan)
+        pad[:cost.shape[0], :cost.shape[1]] = cost
+        xp = np.full(7, -2, np.int32)
+        xp[:len(x)] = x
+        mats.append(pad); shapes.append(cost.shape); limits.append(lim); chosen.append(xp); n_opt.append(len(sols))
+    return dict(cost=np.asarray(mats), shape=np.asarray(shapes, np.int32), cost_limit=np.asarray(limits),
+                x=np.asarray(chosen), num_optimal=np.asarray(n_opt, np.int32))
 
 
 if __name__ == '__main__':
     c_oracle.build()
     for name, fn in (('detector_tiny', detector_tiny), ('decode_nms', decode_nms), ('box_depth', box_depth),
-                     ('costvolume', costvolume), ('tracker_sequence', tracker_sequence)):
+                     ('costvolume', costvolume), ('tracker_sequence', tracker_sequence), ('lapjv_ties', lapjv_ties)):
+        if len(sys.argv) > 1 and name not in sys.argv[1:]:
+            continue
         np.savez_compressed(os.path.join(HERE, name + '.npz'), **fn())
         print('wrote', name)

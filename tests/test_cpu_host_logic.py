@@ -295,36 +295,3 @@ def test_stereo_config_builds_cost_volume_module_with_aggregation():
         st(torch.zeros(1, 48, 4, 4))
     with pytest.raises(ValueError):
         MODELS.build(dict(type='StereoCostVolume', max_disp=40, agg_layers=1))   # 10 levels: not a multiple of 4
-
-
-def test_tracker_golden_sequence():
-    """tests/golden/tracker_sequence.npz (SURVEY.md §8c fixture iv): a 64-frame synthetic detection stream with
-    dropped detections, an 8-frame occlusion and depth-consistent scales; the frame-by-frame tracker output
-    (ids, boxes, depth of every returned track) must be reproduced exactly."""
-    from stereotracking_amd.structures import InstanceData, TrackDataSample
-    from stereotracking_amd.trackers import OCSORTTracker_Disparity
-    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'tracker_sequence.npz'))
-    det, ref = g['detections'], g['tracks']
-    trk = OCSORTTracker_Disparity(obj_score_thr=0.3, init_track_thr=0.7, weight_iou_with_det_scores=False,
-                                  match_iou_thr=0.1, num_tentatives=3, vel_consist_weight=0.2, vel_delta_t=3,
-                                  num_frames_retain=30)
-    model = _Model()
-    n_rows = 0
-    for t in range(int(g['num_frames'])):
-        d = det[det[:, 0] == t]
-        s = TrackDataSample(dict(frame_id=t))
-        s.pred_det_instances = InstanceData(
-            bboxes=torch.from_numpy(d[:, 1:5].copy()), scores=torch.from_numpy(d[:, 5].copy()),
-            labels=torch.zeros(len(d), dtype=torch.long), scales=torch.from_numpy(d[:, 7].copy()),
-            depth=torch.from_numpy(d[:, 6].copy()))
-        r = trk.track(model, None, None, s)
-        e = ref[ref[:, 0] == t]
-        assert r.instances_id.tolist() == e[:, 1].astype(int).tolist(), f'frame {t}'
-        assert np.allclose(r.bboxes.double().numpy(), e[:, 2:6], rtol=0, atol=1e-4), f'frame {t}'
-        assert np.allclose(r.depth.double().numpy(), e[:, 7], rtol=0, atol=1e-5)
-        n_rows += len(e)
-    assert n_rows == len(ref) and len(set(ref[:, 1].astype(int))) >= 6
-    # identities are stable through the dropped detections and the 8-frame occlusion (frames 20-27): the six
-    # ids alive right after the occlusion are exactly the six ids of the last frame
-    ids = lambda t: set(ref[ref[:, 0] == t][:, 1].astype(int).tolist())
-    assert len(ids(28)) == 6 and ids(28) == ids(63)

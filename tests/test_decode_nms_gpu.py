@@ -10,11 +10,13 @@ from stereotracking_amd.engine import HipDetector
 pytestmark = pytest.mark.gpu
 
 
-def run_both(det, head_np, cuda, score_thr=0.01, iou_thr=0.5, max_det=None, ori_shape=None, scale=(1.0, 1.0), pad=None):
+def run_both(det, head_np, cuda, score_thr=0.01, iou_thr=0.5, max_det=None, ori_shape=None, scale=(1.0, 1.0), pad=None,
+             nms_mask_rows=0):
     max_det = max_det or det.num_priors
     ori_shape = ori_shape or (det.height, det.width)
     ref = c_oracle.decode_nms(head_np, det.batch, det.levels, score_thr, iou_thr, max_det, ori_shape, scale, pad)
-    got = det.decode_nms(torch.from_numpy(head_np).to(cuda), score_thr, iou_thr, max_det, ori_shape, scale, pad)
+    got = det.decode_nms(torch.from_numpy(head_np).to(cuda), score_thr, iou_thr, max_det, ori_shape, scale, pad,
+                         nms_mask_rows=nms_mask_rows)
     torch.cuda.synchronize()
     got = [g.cpu().numpy() for g in got]
     return got, ref
@@ -130,3 +132,24 @@ def test_full_size_priors(cuda):
     head = random_head(det, np.random.RandomState(10), logit_mean=-3.0, logit_std=1.5)
     got, ref = run_both(det, head, cuda, max_det=2000, ori_shape=(720, 1280))
     assert_bit_exact(got, ref, 2000)
+
+
+@pytest.mark.parametrize('mask_rows', [64, 128, 1024])
+def test_candidates_beyond_the_iou_mask_are_resolved_on_the_fly(det_small, cuda, mask_rows):
+    """The precomputed IoU bit mask covers only the first `nms_mask_rows` candidates (workspace no longer grows
+    with priors^2); everything past it goes through the reduce kernel's on-the-fly path.  Results must not depend
+    on where that boundary falls: bit-exact against the oracle with hundreds of candidates on both sides."""
+    head = random_head(det_small, np.random.RandomState(21), logit_mean=-1.0)
+    got, ref = run_both(det_small, head, cuda, score_thr=0.001, nms_mask_rows=mask_rows)
+    assert ref[4].min() > 100
+    assert_bit_exact(got, ref, det_small.num_priors)
+    d = det_small.decode_desc(0.001, 0.5, 100, (160, 256), nms_mask_rows=64)
+    small = det_small.lib.st_decode_nms_workspace_bytes(d)
+    d.nms_mask_rows = 1 << 20   # clamped to the prior count (840 -> 896 rows)
+    assert small < det_small.lib.st_decode_nms_workspace_bytes(d)
+
+
+def test_full_size_default_workspace_is_bounded(cuda):
+    det = HipDetector(8, 736, 1280, 0.5, 0.33, 1)
+    d = det.decode_desc(0.01, 0.5, 1000, (720, 1280))
+    assert det.lib.st_decode_nms_workspace_bytes(d) < 32 << 20      # was 373 MB with a priors^2 mask

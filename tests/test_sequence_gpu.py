@@ -18,7 +18,7 @@ class _Model:
 
 
 def make_pipe(batch, sd=None):
-    pipe = StereoDensePipeline(batch, (80, 160), 0.375, 0.33, 1, stereo=True, max_disp=32, max_det=64)
+    pipe = StereoDensePipeline(batch, (80, 160), 0.375, 0.33, 1, stereo=True, max_disp=32, max_det=256)
     sd = sd or synthetic_state_dict(pipe.param_table(), seed=9, prior_prob=0.2, logit_std=2.5)
     pipe.load_state_dict(sd, autotune=False)
     return pipe, sd
@@ -41,8 +41,11 @@ def test_batched_sequence_equals_frame_by_frame(cuda):
     assert int(c1.sum()) > 0
     for t in range(10):
         k = int(c1[t])
-        # same kernels, same per-output summation order whatever the batch / tile choice: bit-identical
-        assert torch.equal(d4[t, :k], d1[t, :k])
+        assert int(d4[t, 0, 0]) == k and int(d4[t, 0, 1]) == 256 and int(d4[t, 0, 2]) == 1   # record header
+        # same kernels, same per-output summation order whatever the batch: bit-identical rows 1..k
+        assert torch.equal(d4[t, 1:1 + k], d1[t, 1:1 + k])
+        assert not d4[t, 1 + k:].any()                                  # rows past the count are zero
+    assert not d4[10:, 0].any()                                         # batch padding: header all zero
     r4 = track_gathered(d4, c4, 10, make_tracker(), _Model())
     r1 = track_gathered(d1, c1, 10, make_tracker(), _Model())
     assert sum(len(r) for r in r1) > 0
@@ -56,7 +59,7 @@ def test_sequence_through_inflight_contexts_equals_serial(cuda):
     from stereotracking_amd.pipeline import InflightPipelines
     frames = list(synthetic_sequence(14, 4, 80, 160, 32, seed=6))   # 4 + 4 + 4 + 2 over 3 contexts
     pipe, sd = make_pipe(4)
-    runner = InflightPipelines(3, 4, (80, 160), 0.375, 0.33, 1, stereo=True, max_disp=32, max_det=64)
+    runner = InflightPipelines(3, 4, (80, 160), 0.375, 0.33, 1, stereo=True, max_disp=32, max_det=256)
     runner.load_state_dict(sd, autotune=False)
     d0, c0 = detect_shard(pipe, frames, cuda)
     d1, c1 = detect_shard(runner, frames, cuda)
@@ -87,7 +90,7 @@ def test_inflight_contexts_match_serial_results(cuda):
     from stereotracking_amd.pipeline import InflightPipelines
     H, W, D, B = 80, 160, 32, 2
     args = (B, (H, W), 0.375, 0.33, 1)
-    kw = dict(stereo=True, max_disp=D, max_det=64, agg_layers=1)
+    kw = dict(stereo=True, max_disp=D, max_det=256, agg_layers=1)
     runner = InflightPipelines(3, *args, **kw)
     serial = StereoDensePipeline(*args, **kw)
     sd = synthetic_state_dict(runner.param_table(), seed=2, prior_prob=0.2, logit_std=2.5)
@@ -105,7 +108,28 @@ def test_inflight_contexts_match_serial_results(cuda):
     for (out, _), (img, right) in zip(got, dev_in):
         ref = serial.run(img, right)
         torch.cuda.synchronize()
-        for k in ('counts', 'prior_idx', 'boxes', 'scores', 'depth', 'scaled_boxes', 'disp_postp', 'head'):
+        for k in ('counts', 'prior_idx', 'boxes', 'scores', 'depth', 'scaled_boxes', 'disp_postp'):
             assert torch.equal(out[k].nan_to_num(-7.0), ref[k].nan_to_num(-7.0)), k
+        for a, b in zip(serial.det.head_levels(out['head']), serial.det.head_levels(ref['head'])):
+            assert torch.equal(a[..., :6], b[..., :6])      # slots 6, 7 of a head row are never written
         kept += int(ref['counts'].sum())
     assert kept > 0
+
+
+def test_detection_buffer_overflow_is_loud(cuda):
+    """The reference applies no cap on kept boxes (yolox_style=True); the fixed-size buffer is a capacity.  A frame
+    that keeps more boxes than fit must raise, never drop boxes silently (every benched frame did)."""
+    from stereotracking_amd.dist import DetectionOverflow
+    frames = list(synthetic_sequence(3, 4, 80, 160, 32, seed=2))
+    pipe = StereoDensePipeline(4, (80, 160), 0.375, 0.33, 1, stereo=True, max_disp=32, max_det=16)
+    sd = synthetic_state_dict(pipe.param_table(), seed=9, prior_prob=0.2, logit_std=2.5)
+    pipe.load_state_dict(sd, autotune=False)
+    with pytest.raises(DetectionOverflow, match='max_det'):
+        detect_shard(pipe, frames, cuda)
+    rec, counts = detect_shard(pipe, frames, cuda, check_overflow=False)
+    assert int(counts.max()) > 16                      # the TRUE count is reported
+    with pytest.raises(DetectionOverflow):
+        track_gathered(rec, None, 3, make_tracker(), _Model())
+    batch = synthetic_batch([0, 1, 2, 3], 80, 160, 32)
+    out = pipe.run(batch['img'].to(cuda), batch['right'].to(cuda))
+    assert bool(out['overflow'].any()) and torch.equal(out['overflow'], out['counts'] > 16)
