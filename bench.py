@@ -291,8 +291,6 @@ def main():
     for _ in range(args.warmup):
         out = step()
     torch.cuda.synchronize()
-    if os.environ.get('ST_SKIP_AFTER_WARMUP'):   # timing-only ablation (tools): the buffers keep their valid warm-up contents
-        os.environ['ST_SKIP_OPS'] = os.environ['ST_SKIP_AFTER_WARMUP']
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()

@@ -78,6 +78,13 @@ typedef struct StConvDesc {
 } StConvDesc;
 
 int st_conv2d_nhwc(const StConvDesc* d, st_stream_t stream);
+/* The same convolution with the kernel instance chosen by the caller instead of the library's heuristic:
+ * variant 0..21 = tile instances of the implicit-GEMM kernel (st_conv_variant_name), 41 = streaming 1x1 kernel,
+ * 42 = direct 3x3 kernel, -1 = heuristic.  Returns ST_ERR_INVALID when the instance cannot run this layer (tile
+ * does not divide the padded Cout, ...), so callers can autotune per layer by timing the valid ones — which is
+ * what st_detector_autotune does internally and StereoCostVolume.autotune does for the aggregation convs.
+ * Results are the same convolution for every valid variant (fp32 rounding differs with the summation order). */
+int st_conv2d_nhwc_variant(const StConvDesc* d, st_stream_t stream, int variant);
 
 /* Pack one Conv2d weight [Cout][Cin][KH][KW] (+ optional BN, folded in fp64)
  * into the kernel layout above.  Host function; out buffers are host memory

@@ -112,11 +112,12 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
+    path = os.environ.get('ST_LIBRARY') or LIB_PATH   # ST_LIBRARY: tools/ load the -DST_ABLATION build
+    if not os.path.exists(path):
         raise RuntimeError(
-            f'{LIB_PATH} not found: build it with `python -c "import __graft_entry__ as g; g.build()"` '
+            f'{path} not found: build it with `python -c "import __graft_entry__ as g; g.build()"` '
             f'(or `make -C stereotracking_amd/csrc`).  stereotracking_amd has no CPU fallback.')
-    lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+    lib = C.CDLL(path, mode=C.RTLD_GLOBAL)
     for name, (res, args) in _PROTOS.items():
         fn = getattr(lib, name)  # AttributeError = the library does not export a declared symbol
         fn.restype = res

@@ -325,7 +325,10 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(ConvKArgs p) {
     load_chunk(0);
     store_chunk(0);
   }
-  __syncthreads();  // (drains the DMA: hipcc emits vmcnt(0) in front of the barrier)
+  // LDS-DMA data is only ordered behind the ISSUING wave's vmcnt; other waves read it after the barrier, so every
+  // wave drains its own DMA explicitly before joining it (not left to the compiler's waitcnt insertion)
+  if (DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
 
   // Main loop.  A K-chunk is 16 MFMA "slots" (4 fragment groups x 4 k-steps) per accumulator tile.  The
   // staging of chunk k+1 is threaded through the MFMA stream of chunk k, one 16-B item per slot: global
@@ -417,6 +420,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(ConvKArgs p) {
         for (int b_ = 0; b_ < BP; ++b_) asm volatile("" ::"v"(breg[b_]));
       }
     }
+    if (DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMA of chunk kc + 1 has landed
     if (ABL < 2) __syncthreads();
   };
   for (int kc = 0; kc + 1 < nchunks; ++kc) do_chunk(kc, std::true_type{});
@@ -425,6 +429,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(ConvKArgs p) {
   conv_epilogue<TM, TN>(p, acc, m0, n0, wm, wn, l31, lh, BM, BN);
 }
 
+#ifdef ST_ABLATION   // measured-negative experiment: tools-only build, not in the product library
 // ---- wave-specialised variant ---------------------------------------------------------------------------
 // WM*WN MFMA waves + ONE loader wave per block.  The ablations (tools/conv_ablation.py) show that what the
 // staged kernel loses against its no-load build is the ISSUE cost of the staging instructions inside the
@@ -597,6 +602,8 @@ static int launch_ws(const ConvKArgs& a, int m_tiles, hipStream_t stream) {
   return ST_OK;
 }
 
+#endif  // ST_ABLATION
+
 template <int TM, int TN, int WM, int WN, int NBUF = 2, int ABL = 0, int ILV = 1, int DMA = 0>
 static int launch_variant(const ConvKArgs& a, int m_tiles, hipStream_t stream) {
   constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
@@ -632,7 +639,11 @@ static const ConvVariant kVariants[] = {{128, 128, 256}, {128, 64, 128}, {128, 3
                                         {256, 128, 512}, {256, 128, 512}, {256, 128, 512},
                                         {128, 128, 320}, {64, 64, 320},   {64, 128, 320}, {128, 32, 320},
                                         {128, 64, 320},  {128, 128, 384}, {64, 128, 384}, {128, 128, 512}};
-constexpr int kNumVariants = 30;
+#ifdef ST_ABLATION
+constexpr int kNumVariants = 30;   // + the wave-specialised experiments 22..29
+#else
+constexpr int kNumVariants = 22;
+#endif
 
 int conv_variant_count() { return kNumVariants; }
 bool conv_variant_valid(int id, int cout) {
@@ -744,7 +755,8 @@ int conv2d_launch(const StConvDesc& d, hipStream_t stream, int force_variant, in
   if (picked_variant) *picked_variant = pick;
   a.n_tiles = cout_pad / v.bn;
   const int m_tiles = ceil_div(a.M, v.bm);
-  if (force_variant >= 100) {  // timing-only ablations (tools/conv_ablation.py)
+#ifdef ST_ABLATION
+  if (force_variant >= 100) {  // timing-only ablations (tools/conv_ablation.py): WRONG results by construction
     const int abl = force_variant / 100;
     if (pick == 0 && abl == 1) return launch_variant<2, 2, 2, 2, 2, 1>(a, m_tiles, stream);
     if (pick == 0 && abl == 2) return launch_variant<2, 2, 2, 2, 2, 2>(a, m_tiles, stream);
@@ -760,6 +772,9 @@ int conv2d_launch(const StConvDesc& d, hipStream_t stream, int force_variant, in
     if (pick == 3 && abl == 3) return launch_variant<1, 1, 2, 2, 2, 0, 0>(a, m_tiles, stream);
     return set_error(ST_ERR_INVALID, "conv: no ablation build for variant %d", force_variant);
   }
+#else
+  ST_REQUIRE(force_variant < 100, "conv: ablation builds exist only in the ST_ABLATION (tools) library");
+#endif
   switch (pick) {
     case 0: return launch_variant<2, 2, 2, 2>(a, m_tiles, stream);
     case 1: return launch_variant<2, 2, 2, 1>(a, m_tiles, stream);
@@ -783,6 +798,7 @@ int conv2d_launch(const StConvDesc& d, hipStream_t stream, int force_variant, in
     case 19: return launch_variant<2, 2, 4, 2, 2, 0, 1, 1>(a, m_tiles, stream);
     case 20: return launch_variant<2, 2, 4, 2, 2, 0, 0, 1>(a, m_tiles, stream);
     case 21: return launch_variant<2, 2, 4, 2, 2, 0, 1, 0>(a, m_tiles, stream);
+#ifdef ST_ABLATION
     case 22: return launch_ws<2, 2, 2, 2>(a, m_tiles, stream);
     case 23: return launch_ws<1, 1, 2, 2>(a, m_tiles, stream);
     case 24: return launch_ws<1, 2, 2, 2>(a, m_tiles, stream);
@@ -790,7 +806,9 @@ int conv2d_launch(const StConvDesc& d, hipStream_t stream, int force_variant, in
     case 26: return launch_ws<1, 2, 4, 1>(a, m_tiles, stream);
     case 27: return launch_ws<2, 2, 2, 2, 2>(a, m_tiles, stream);
     case 28: return launch_ws<1, 2, 2, 2, 2>(a, m_tiles, stream);
-    default: return launch_ws<2, 2, 2, 2, 4>(a, m_tiles, stream);
+    case 29: return launch_ws<2, 2, 2, 2, 4>(a, m_tiles, stream);
+#endif
+    default: return set_error(ST_ERR_INVALID, "conv: unknown tile variant %d", pick);
   }
 }
 
@@ -808,7 +826,9 @@ extern "C" int st_conv1x1_chain(const StConvDesc* a, const StConvDesc* b, st_str
   return st::pw_conv_launch(*a, static_cast<hipStream_t>(stream), b);
 }
 
-// test hook: force a tile variant (0..4); not part of the documented ABI surface
+// The same convolution with the tile variant chosen by the caller (include/stereotrack.h: ids 0..21 = tile
+// instances of conv_igemm_kernel, 41 = streaming 1x1 kernel, 42 = direct 3x3 kernel, -1 = library heuristic);
+// how callers that autotune per layer (StereoCostVolume.autotune) apply their choice.
 extern "C" int st_conv2d_nhwc_variant(const StConvDesc* d, st_stream_t stream, int variant) {
   if (!d) return st::set_error(ST_ERR_INVALID, "st_conv2d_nhwc_variant: null desc");
   return st::conv2d_launch(*d, static_cast<hipStream_t>(stream), variant, nullptr);

@@ -431,8 +431,8 @@ extern "C" int st_costvolume_softargmin(const float* featL_dev, const float* fea
 #define ST_CVT_LAUNCH(DGV)                                                                                    \
   do {                                                                                                         \
     auto kern = costvolume_tiled_kernel<DGV>;                                                                  \
-    ST_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                                      \
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldst));                  \
+    static int lds_set = 0;                                                                                    \
+    ST_ENSURE_DYNAMIC_LDS(kern, ldst, lds_set);                                                                \
     hipLaunchKernelGGL(kern, gridt, blockt, ldst, stream, featL_dev, featR_dev, Hf, Wf, C, feat_ld, D,         \
                        temperature, rowLt, rowRt, out_cost_dev, out_disp_dev);                                 \
   } while (0)
@@ -458,8 +458,8 @@ extern "C" int st_costvolume_softargmin(const float* featL_dev, const float* fea
 #define ST_CV_LAUNCH(DGV)                                                                                      \
   do {                                                                                                         \
     auto kern = costvolume_kernel<DGV>;                                                                        \
-    ST_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                                      \
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                   \
+    static int lds_set = 0;                                                                                    \
+    ST_ENSURE_DYNAMIC_LDS(kern, lds, lds_set);                                                                 \
     hipLaunchKernelGGL(kern, grid, block, lds, stream, featL_dev, featR_dev, Hf, Wf, C, feat_ld, D,            \
                        temperature, rowL, rowR, out_cost_dev, out_disp_dev);                                   \
   } while (0)

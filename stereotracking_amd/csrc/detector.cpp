@@ -152,6 +152,10 @@ struct StDetector {
   bool timing = false;
   std::vector<hipEvent_t> events;  // 2 per op
   int force_variant = -1;          // autotune only
+  bool allow_chain = true;         // fuse CSP main_conv -> bottleneck conv1 when both run on the streaming kernel
+#ifdef ST_ABLATION
+  std::vector<char> skip;          // tools-only: ops whose launches are dropped (st_detector_set_skip)
+#endif
   // Sub-batch groups: the high-resolution front of the network is run SB images at a time through
   // SB-sized intermediate buffers that are REUSED by every sub-batch, so the intermediates of one
   // sub-batch (~100 MB per image at 736x1280) stay in the 256 MiB Infinity Cache instead of
@@ -319,9 +323,11 @@ int StDetector::build() {
   cur_phase = 0;
   const int NB = stereo ? 2 * N : N;
   // Focus + stem ConvModule as ONE kernel reading the planar image (stem_focus_conv.hip) whenever the stem is
-  // at most 64 channels wide (widen_factor <= 1); otherwise focus_pack + the generic conv.  ST_NO_FUSED_STEM=1
-  // forces the two-kernel path (A/B measurements).
-  const bool fused_stem = c1 <= 64 && !getenv("ST_NO_FUSED_STEM");
+  // at most 64 channels wide (widen_factor <= 1); otherwise focus_pack + the generic conv.
+  bool fused_stem = c1 <= 64;
+#ifdef ST_ABLATION   // tools-only build: ST_NO_FUSED_STEM=1 forces the two-kernel path (A/B measurements)
+  if (getenv("ST_NO_FUSED_STEM")) fused_stem = false;
+#endif
   TRef packed_rgb, stem_rgb;
   if (fused_stem) {
     stem_rgb = new_tensor(NB, H2, W2, c1);
@@ -340,9 +346,11 @@ int StDetector::build() {
   }
   // images per sub-batch of the high-resolution front.  Measured on MI355X (bench.py, N=8): off 1135,
   // SB=4 1110, SB=2 1066, SB=1 974 pairs/s - the smaller launches cost more than the Infinity-Cache
-  // residency buys, so the default is OFF (ST_SUBBATCH=k re-enables it for experiments).
+  // residency buys, so the default is OFF (the tools-only ST_ABLATION build reads ST_SUBBATCH=k).
   int sbatch = 0;
+#ifdef ST_ABLATION
   if (const char* e = getenv("ST_SUBBATCH")) sbatch = atoi(e);
+#endif
   if (sbatch <= 0 || N % sbatch != 0) sbatch = N;  // one group covering the whole batch
   TRef s1 = new_tensor(NB, H4, W4, c2);  // stage1 features of every (left | right) image: kept for the stereo module
   begin_group(sbatch, NB);
@@ -659,18 +667,18 @@ int run_ops(StDetector* det, int phase_lo, int phase_hi, const float* const inpu
       for (size_t k = oi; k < oe; ++k) {
         Op& o = det->ops[k];
         if (det->timing) ST_CHECK_HIP(hipEventRecord(det->events[ev_per_op * k + 2 * sbi], stream));
-        // timing-only ablation (results are garbage): ST_SKIP_OPS="3,4,6" drops those launches to bound what a
-        // faster kernel for them could buy
-        const char* skip_env = getenv("ST_SKIP_OPS");   // read per launch: the bench flips it after the warm-up
-        const std::string skip(skip_env ? skip_env : "");
-        const bool skipped = !skip.empty() && ("," + skip + ",").find("," + std::to_string(k) + ",") != std::string::npos;
+#ifdef ST_ABLATION   // tools-only build, timing only (results are garbage): st_detector_set_skip drops launches to
+        const bool skipped = k < det->skip.size() && det->skip[k];   // bound what a faster kernel could buy
+#else
+        constexpr bool skipped = false;
+#endif
         bool chained = false;
         if (!skipped && chain_done) {   // this op was computed by the previous (chained) launch
           chain_done = false;
           o.variant = 41;
           chained = true;
         } else if (!skipped && o.type == Op::CONV && o.chain_next && k + 1 < oe && det->force_variant < 0 &&
-                   o.tuned == 41 && det->ops[k + 1].tuned == 41 && !getenv("ST_NO_CHAIN")) {
+                   o.tuned == 41 && det->ops[k + 1].tuned == 41 && det->allow_chain) {
           const StConvDesc da = conv_desc(det, o, sbi * g.sb, ws, head);
           const StConvDesc db = conv_desc(det, det->ops[k + 1], sbi * g.sb, ws, head);
           if (pw_chain_applicable(da, db)) {
@@ -740,6 +748,19 @@ extern "C" int st_detector_set_timing(StDetector* det, int enable) {
 }
 
 extern "C" int st_detector_num_ops(const StDetector* det) { return det ? (int)det->ops.size() : 0; }
+
+#ifdef ST_ABLATION
+// Tools-only build (make ABLATION=1): drop the launches of the listed ops (timing experiments; results are
+// garbage) and/or forbid the chained 1x1 pair.  Not part of the product library.
+extern "C" int st_detector_set_skip(StDetector* det, const int* ops, int n, int allow_chain) {
+  if (!det) return set_error(ST_ERR_INVALID, "st_detector_set_skip: null detector");
+  det->skip.assign(det->ops.size(), 0);
+  for (int i = 0; i < n; ++i)
+    if (ops[i] >= 0 && ops[i] < (int)det->ops.size()) det->skip[ops[i]] = 1;
+  det->allow_chain = allow_chain != 0;
+  return ST_OK;
+}
+#endif
 
 // kind: 0 focus-pack, 1 conv, 2 spp; variant = conv tile variant (0..4) or -1; macs = conv MACs
 extern "C" int st_detector_op_times(StDetector* det, int cap, float* ms, int* kind, int* variant, double* macs,

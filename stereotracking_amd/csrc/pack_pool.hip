@@ -163,9 +163,11 @@ int spp_pool_launch(const float* x, int x_ld, int x_off, int N, int H, int W, in
   // problems want more, smaller workgroups.  Measured on 8 x 23x40x256: 8 channels (256 workgroups) 68 us,
   // 4 channels 45 us, 2 channels 55 us (8-byte global accesses).
   int cg = 8;
+  if ((long long)(C / 8) * N < 1024) cg = 4;
+#ifdef ST_ABLATION
   if (const char* e = getenv("ST_SPP_CG")) cg = atoi(e);
-  else if ((long long)(C / 8) * N < 1024) cg = 4;
   if (cg != 2 && cg != 4) cg = 8;
+#endif
   const size_t lds = (size_t)2 * H * W * cg * sizeof(float);
   if (C % cg == 0 && lds <= 150 * 1024 && N <= 65535) {
     using Kern = void (*)(const float*, int, int, int, int, int, float*, int, int, int);

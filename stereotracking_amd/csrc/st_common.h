@@ -31,6 +31,17 @@ inline int round_up(int a, int b) { return ceil_div(a, b) * b; }
     if (!(cond)) return st::set_error(ST_ERR_INVALID, __VA_ARGS__);  \
   } while (0)
 
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is a driver call: raise the limit of a kernel only when a
+// launch needs more dynamic LDS than any earlier launch of it did (`cached` = a static int next to the call site).
+#define ST_ENSURE_DYNAMIC_LDS(kern, bytes, cached)                                                           \
+  do {                                                                                                       \
+    if ((int)(bytes) > (cached)) {                                                                           \
+      ST_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                                  \
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)(bytes)));          \
+      (cached) = (int)(bytes);                                                                               \
+    }                                                                                                        \
+  } while (0)
+
 #define ST_CHECK(expr)        \
   do {                        \
     int rc_ = (expr);         \

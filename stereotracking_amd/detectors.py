@@ -210,9 +210,12 @@ class YOLODetector_Disparity_V1(nn.Module):
         ori = metas[0].get('ori_shape', (eng.height, eng.width))[:2]
         sf = metas[0].get('scale_factor', (1.0, 1.0)) if rescale else (1.0, 1.0)
         pad = metas[0].get('pad_param', None) if rescale else None
+        def _pad(v):   # compare by VALUE: every data sample carries its own (equal) pad_param array
+            return None if v is None else tuple(float(x) for x in v)
         for m in metas[1:]:
             if (tuple(m.get('ori_shape', ori)[:2]) != tuple(ori) or
-                    tuple(m.get('scale_factor', sf)) != tuple(sf) or m.get('pad_param', None) is not pad and rescale):
+                    tuple(m.get('scale_factor', sf)) != tuple(sf) or
+                    (rescale and _pad(m.get('pad_param', None)) != _pad(pad))):
                 raise NotImplementedError('one HIP decode launch needs uniform ori_shape/scale_factor/pad_param')
         cfg = self.test_cfg
         nms = cfg.get('nms', dict(type='nms', iou_threshold=0.65))

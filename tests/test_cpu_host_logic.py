@@ -66,6 +66,31 @@ def test_models_build_from_reference_shaped_config():
         model.detector.predict(dict(img=z, disp_postp=z), [])
 
 
+REF_CFG_DIR = '/root/reference/configs/stereo_tracking/ocsort'
+
+
+@pytest.mark.skipif(not os.path.isdir(REF_CFG_DIR), reason='reference tree not present (GPU box)')
+@pytest.mark.parametrize('name', ['yolox_s_mmyolo_mot_airdrone_disp.py'])
+def test_reference_config_files_parse_verbatim_and_build(name):
+    """Drop-in check of the plugin surface: the REFERENCE's own config file, read from where it lies
+    (with its own `_base_` chain), parses with this repo's loader and `MODELS.build(cfg.model)` yields the HIP-backed
+    OCSORT_Disparity with the shipped thresholds - no edits to the config."""
+    from stereotracking_amd import mot  # noqa: F401
+    from stereotracking_amd.config import Config
+    from stereotracking_amd.registry import MODELS
+    cfg = Config.fromfile(os.path.join(REF_CFG_DIR, name))
+    ours = Config.fromfile(CFG)
+    assert cfg.model.detector.test_cfg == ours.model.detector.test_cfg       # same merged thresholds
+    assert dict(cfg.model.tracker) == dict(ours.model.tracker)
+    assert dict(cfg.model.detector.backbone) == dict(ours.model.detector.backbone)
+    model = MODELS.build(cfg.model)
+    assert type(model).__name__ == 'OCSORT_Disparity' and type(model.detector).__name__ == 'YOLODetector_Disparity_V1'
+    assert model.detector.widen_factor == 0.5 and model.detector.deepen_factor == 0.33
+    assert model.tracker.match_iou_thr == 0.1 and model.tracker.num_frames_retain == 30
+    assert type(model.data_preprocessor).__name__ == 'TrackDataPreprocessor_Disparity_V1'
+    assert model.data_preprocessor.pad_size_divisor == 32
+
+
 def test_structures_and_preprocessor():
     from stereotracking_amd.mot import TrackDataPreprocessor_Disparity_V1, stack_batch
     from stereotracking_amd.structures import InstanceData, TrackDataSample

@@ -1,9 +1,13 @@
 #!/usr/bin/env python
 """Timing-only ablations of the conv kernel on one layer shape (results are wrong by construction):
-   full kernel vs. no-global-loads vs. no-loads-no-barrier.  usage: conv_ablation.py"""
+   full kernel vs. no-global-loads vs. no-loads-no-barrier.  Needs the TOOLS-ONLY library:
+   make -C stereotracking_amd/csrc ABLATION=1 ; usage: conv_ablation.py"""
 import ctypes as C
 import os
 import sys
+
+_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+os.environ.setdefault('ST_LIBRARY', os.path.join(_ROOT, 'stereotracking_amd', 'lib', 'libstereotrack_hip_ablation.so'))
 
 import torch
 
