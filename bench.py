@@ -41,6 +41,13 @@ def parse():
     ap.add_argument('--inflight', type=int, default=3,
                     help='pipeline contexts fed round-robin, one HIP stream each (1 = strictly serial steps)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-test-step', action='store_true',
+                    help='skip the second leg through Config.fromfile -> MODELS.build -> model.test_step')
+    ap.add_argument('--frames-per-call', type=int, default=64,
+                    help='frames of ONE video handed to each model.test_step call of the second leg (BASELINE configs[2] '
+                         'is a 64-frame sequence); they run --batch at a time on the model\'s in-flight contexts')
+    ap.add_argument('--sustain-seconds', type=float, default=2.0,
+                    help='after the K timed steps, keep stepping for this long and report it as `sustained`')
     ap.add_argument('--cpu-seconds', type=float, default=15.0, help='budget of the CPU oracle leg')
     return ap.parse_args()
 
@@ -67,9 +74,10 @@ def conv_roofline(pipe, img, right, steps):
     agg = {}   # variant -> [launches, ms]
     cv_ms = 0.0
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
-    # an event pair with nothing in between already measures ~4.6 us on this stack (two barrier packets); that
-    # overhead is measured live and removed from every per-launch duration, otherwise the HIP-event averages sit
-    # ~6 % above rocprofv3's kernel durations (profiles/r01_kernel_stats_inflight1.csv)
+    # an event pair with nothing in between already measures ~4.6 us on this stack (two barrier packets).  It is
+    # measured and REPORTED (event_pair_overhead_us) but NOT subtracted: the per-launch durations below are raw
+    # HIP-event times, ~5 % longer than rocprofv3's kernel durations of the same launches (profiles/r02_kernel_stats_
+    # inflight1.csv), so `frac` is a lower bound that the committed rocprof summary can only improve on
     pairs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(101)]
     for a_, b_ in pairs:
         a_.record()
@@ -92,12 +100,12 @@ def conv_roofline(pipe, img, right, steps):
         p = lambda a: a.ctypes.data_as(C.c_void_p)
         check(lib.st_detector_op_times(det.handle, nops, p(ms), p(kind), p(var), p(macs), p(phase)))
         ph0 = float(ms[phase == 0].sum())     # raw: what the bracketing events of the stereo module saw
-        tot_ms += np.maximum(ms - null_ms, 0.0)
-        cv_ms += max(sm.pop_costvolume_time() - null_ms, 0.0)
+        tot_ms += ms
+        cv_ms += sm.pop_costvolume_time()
         for v, t in sm.pop_times():   # aggregation convs: the same conv kernel, launched by the stereo module
             a = agg.setdefault(int(v), [0, 0.0])
             a[0] += 1
-            a[1] += max(t - null_ms, 0.0)
+            a[1] += t
             ph0 += t
         other['costvolume+softargmin+upsample'] += ev[0].elapsed_time(ev[1]) - ph0
         other['decode_nms'] += ev[2].elapsed_time(ev[3])
@@ -134,7 +142,7 @@ def conv_roofline(pipe, img, right, steps):
     # HBM bytes per launch from the committed rocprofv3 PMC passes (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE,
     # separate passes; tools/pmc_summary.py): launch-weighted mean over the instances of this run
     traffic, traffic_src = None, None
-    tpath = os.path.join(ROOT, 'profiles', 'r01_hbm_traffic.json')
+    tpath = os.path.join(ROOT, 'profiles', 'r02_hbm_traffic.json')
     if os.path.exists(tpath):
         tj = json.load(open(tpath))
         tot_b, cov = 0.0, 0
@@ -147,7 +155,8 @@ def conv_roofline(pipe, img, right, steps):
             cov += v['launches']
         if cov >= 0.5 * n_launch and tot_b > 0:
             traffic = int(tot_b / cov)
-            traffic_src = ('profiles/r01_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE), launch-weighted '
+            traffic_src = ('profiles/r02_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, NOT '
+                           'measured inside this run), launch-weighted '
                            'over the %d of %d launches whose tile instance is in that profile' % (cov, n_launch))
     roof = dict(bound='mfma',
                 kernel='st::conv_igemm_kernel<...> (all tile instances; the fused stem kernel, the streaming 1x1 '
@@ -156,7 +165,7 @@ def conv_roofline(pipe, img, right, steps):
                 frac=round(tf_inst / PEAK_FP32_MFMA_TFLOPS, 4), traffic=traffic, traffic_source=traffic_src,
                 flop_per_launch=round(gf_inst * 1e9 / n_launch),
                 avg_launch_us=round(ms_inst * 1e3 / n_launch, 2),
-                launches_per_step=n_launch, event_pair_overhead_us=round(null_ms * 1e3, 2),
+                launches_per_step=n_launch, event_pair_overhead_us=round(null_ms * 1e3, 2), event_overhead_subtracted=False,
                 largest_instance=dict(tile=dom, **inst[dom],
                                       symbol='st::conv_igemm_kernel<%s>' % lib.st_conv_variant_signature(
                                           next(i for i, n in VARIANT_TILES.items() if n == dom)).decode()),
@@ -237,6 +246,91 @@ def cpu_baseline(sd, batch_cpu, max_disp, seconds, agg_layers):
                        f'(PyTorch fp32 + C oracle), {dt:.1f} s', host_cpus=os.cpu_count())
 
 
+def test_step_leg(args, sd, batch_cpu, dev, pairs_target):
+    """The SAME workload through the reference's plugin surface (SURVEY.md §8b "Callers"): Config.fromfile of the
+    stereo config -> MODELS.build -> model.test_step(data), data = what a dataset pipeline yields (lists of (1,3,h,w)
+    frames of ONE video + TrackDataSamples), inputs resident in HBM.  One call carries --frames-per-call frames (64 =
+    the sequence length of BASELINE configs[2]); inside the call they run `batch` at a time on the model's in-flight
+    contexts while the CPU association step (shipped thresholds) consumes the finished chunks in frame order."""
+    from stereotracking_amd import mot  # noqa: F401  (registers the classes)
+    from stereotracking_amd.config import Config
+    from stereotracking_amd.registry import MODELS
+    from stereotracking_amd.structures import TrackDataSample
+    cfg = Config.fromfile(os.path.join(ROOT, 'configs', 'stereo_tracking', 'ocsort',
+                                       'stereo_yolox_s_mot_airdrone_costvolume.py'))
+    cfg.model.stereo['max_disp'] = args.max_disp
+    cfg.model.stereo['agg_layers'] = args.agg_layers
+    B, F = args.batch, max(args.batch, args.frames_per_call)
+    model = MODELS.build(dict(cfg.model, dense_batch=B, inflight=max(1, args.inflight), max_det=args.max_det,
+                              tuning_cache=os.environ.get('ST_TUNE_CACHE')))
+    model.detector.load_state_dict({k: v for k, v in sd.items() if not k.startswith('stereo.')}, strict=False)
+    model.stereo.load_state_dict({k[len('stereo.'):]: v for k, v in sd.items() if k.startswith('stereo.')})
+    left = [batch_cpu['img'][i % B:i % B + 1, :, :720].to(torch.uint8).to(dev) for i in range(F)]
+    right = [batch_cpu['right'][i % B:i % B + 1, :, :720].to(torch.uint8).to(dev) for i in range(F)]
+    frame = [0]
+
+    def call():
+        samples = [TrackDataSample(dict(frame_id=frame[0] + i, ori_shape=(720, 1280), img_shape=(720, 1280),
+                                        scale_factor=(1.0, 1.0))) for i in range(F)]
+        frame[0] += F
+        return model.test_step(dict(inputs=dict(img=list(left), right=list(right)), data_samples=samples))
+
+    for _ in range(2):
+        outs = call()
+    torch.cuda.synchronize()
+    model.timings.update(frames=0, tracker_s=0.0, host_s=0.0)
+    calls = max(2, -(-pairs_target // F))
+    t0 = time.perf_counter()
+    for _ in range(calls):
+        outs = call()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    tm = model.timings
+    return dict(value=round(calls * F / dt, 3), unit='stereo frame-pairs/s', calls=calls, frames_per_call=F,
+                ms_per_call=round(dt / calls * 1e3, 3),
+                path='Config.fromfile(stereo_yolox_s_mot_airdrone_costvolume.py) -> MODELS.build -> model.test_step',
+                tracker_ms_per_frame=round(tm['tracker_s'] / max(tm['frames'], 1) * 1e3, 4),
+                tracks_last_frame=int(len(outs[-1].pred_track_instances)),
+                detections_last_frame=int(len(outs[-1].pred_det_instances)),
+                note='includes the preprocessor (uint8 -> fp32, pad, stack), the dense path on the model\'s in-flight '
+                     'contexts, one D2H of the detection records per 8-frame chunk, the CPU OC-SORT association with the '
+                     'shipped thresholds and one batched depth launch for the tracks per chunk')
+
+
+def tracker_cost(seconds=1.0):
+    """Host cost of the association step alone on a realistic load (6 objects, dropped
+    detections, an occlusion): ms per frame of OCSORTTracker_Disparity with the shipped thresholds.  Decides whether
+    SURVEY §8 f-4 (batched GPU association) is needed: the dense path delivers a frame every ~0.75 ms."""
+    from stereotracking_amd.motion import KalmanFilter
+    from stereotracking_amd.structures import InstanceData, TrackDataSample
+    from stereotracking_amd.synthetic import synthetic_detection_stream
+    from stereotracking_amd.trackers import OCSORTTracker_Disparity
+
+    class _Model:
+        motion = KalmanFilter()
+
+    T = 64
+    det = synthetic_detection_stream(51, T)
+    frames = []
+    for t in range(T):
+        d = det[det[:, 0] == t]
+        frames.append(dict(bboxes=torch.from_numpy(d[:, 1:5].copy()), scores=torch.from_numpy(d[:, 5].copy()),
+                           labels=torch.zeros(len(d), dtype=torch.long), scales=torch.from_numpy(d[:, 7].copy()),
+                           depth=torch.from_numpy(d[:, 6].copy())))
+    trk = OCSORTTracker_Disparity(obj_score_thr=0.3, init_track_thr=0.7, weight_iou_with_det_scores=False,
+                                  match_iou_thr=0.1, num_tentatives=3, vel_consist_weight=0.2, vel_delta_t=3,
+                                  num_frames_retain=30)
+    n, t0 = 0, time.perf_counter()
+    while time.perf_counter() - t0 < seconds:
+        for t in range(T):
+            s = TrackDataSample(dict(frame_id=t))
+            s.pred_det_instances = InstanceData(**frames[t])
+            trk.track(_Model(), None, None, s)
+        n += T
+    return dict(ms_per_frame=round((time.perf_counter() - t0) / n * 1e3, 4), objects=6, frames=n,
+                workload='64-frame synthetic detection stream (6 objects, 10 % dropped detections, 8-frame occlusion)')
+
+
 def main():
     args = parse()
     rank = int(os.environ.get('RANK', 0))
@@ -307,6 +401,17 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
+    sustained = None
+    if args.sustain_seconds > 0:     # a longer region for the eye of a GPU-busy sampler; `value` stays the K-step figure
+        n_s, t1 = 0, time.perf_counter()
+        while time.perf_counter() - t1 < args.sustain_seconds:
+            for _ in range(args.steps):
+                out = step()
+            n_s += args.steps
+            torch.cuda.synchronize()
+        dts = time.perf_counter() - t1
+        sustained = dict(seconds=round(dts, 3), steps=n_s, value=round(world * B * n_s / dts, 3))
+
     counts = out['counts'].cpu().tolist()
     rec_counts = out['records'][:, 0, 0].cpu().long().tolist()   # what the tracker side of the all-gather sees
     if rec_counts[rank * B:(rank + 1) * B] != counts:
@@ -326,6 +431,7 @@ def main():
                    'global_batch': world * B, 'inflight_contexts': len(runner),
                    'parallelism': f'frames sharded x{world}, one all-gather of detections per step ({backend})',
                    'detections_kept_rank0': counts, 'max_det': pipe.max_det, 'detections_overflow': False},
+        'sustained': sustained,
     }
     if rank == 0:
         roof = conv_roofline(pipe, img, right, max(3, min(args.steps, 10)))
@@ -336,6 +442,11 @@ def main():
                             'timed region overlaps kernels of consecutive batches, which inflates per-launch durations '
                             '(compare profiles/*_inflight1 for the serialized rocprof summary)')
         line['roofline'] = roof
+        if world == 1 and not args.no_test_step:
+            del runner   # its three workspaces are not needed any more
+            line['test_step'] = test_step_leg(args, sd, batch_cpu, dev, B * args.steps)
+            line['test_step']['vs_pipeline'] = round(line['test_step']['value'] / line['value'], 4)
+        line['tracker_cpu'] = tracker_cost()
         if world == 1 and not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline(sd, batch_cpu, args.max_disp, args.cpu_seconds, args.agg_layers)
         print(json.dumps(line), flush=True)

@@ -316,6 +316,38 @@ int st_box_depth(const float* disp_dev, size_t img_pitch, int N, int H, int W,
 int st_lapjv_extended(const double* cost, int n_rows, int n_cols, double cost_limit,
                       int32_t* x_out, int32_t* y_out);
 
+/* ------------------------------------------------------------------------
+ * 8. The whole association step of one frame as a HOST routine (no GPU): the
+ *    consumer of the detection records.  Reference
+ *    OCSORTTracker_Disparity.track, mmtrack/models/trackers/ocsort_tracker_disparity.py:345-618
+ *    (+ kalman_tracker_base.py:49-88, base_tracker.py:54-141, motion/kalman_filter.py:60-189);
+ *    constructor kwargs = configs/stereo_tracking/ocsort/yolox_s_mmyolo_mot_airdrone_disp.py:49-58.
+ *    dets[n][8] = x1,y1,x2,y2 (depth-SCALED box), score, label, depth, scale - one row of a frame
+ *    record; out_rows / out_ids = pred_track_instances in the reference's output order
+ *    (matched detections stage by stage, then the newly started tracks).
+ * ---------------------------------------------------------------------- */
+typedef struct StTracker StTracker;
+typedef struct StTrackerConfig {
+  int struct_size;
+  float obj_score_thr, init_track_thr;
+  int weight_iou_with_det_scores;
+  float match_iou_thr;
+  int num_tentatives;
+  float vel_consist_weight;
+  int vel_delta_t;
+  int num_frames_retain;
+} StTrackerConfig;
+int st_tracker_create(const StTrackerConfig* cfg, StTracker** out);
+int st_tracker_destroy(StTracker* t);
+int st_tracker_reset(StTracker* t);
+int st_tracker_track(StTracker* t, int frame_id, const float* dets, int n, float* out_rows,
+                     int64_t* out_ids, int cap, int* out_n);
+/* state inspection (tests, checkpointing): live tracks in creation order */
+int st_tracker_num_tracks(const StTracker* t);
+long long st_tracker_next_id(const StTracker* t);
+int st_tracker_get_track(const StTracker* t, int index, int64_t* id, double* mean8, double* cov64,
+                         int* tentative, int* tracked, int* last_frame);
+
 #ifdef __cplusplus
 }
 #endif

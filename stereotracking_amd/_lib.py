@@ -44,6 +44,14 @@ class StDetectorConfig(C.Structure):
     ]
 
 
+class StTrackerConfig(C.Structure):
+    _fields_ = [
+        ('struct_size', C.c_int), ('obj_score_thr', C.c_float), ('init_track_thr', C.c_float),
+        ('weight_iou_with_det_scores', C.c_int), ('match_iou_thr', C.c_float), ('num_tentatives', C.c_int),
+        ('vel_consist_weight', C.c_float), ('vel_delta_t', C.c_int), ('num_frames_retain', C.c_int),
+    ]
+
+
 class StDecodeDesc(C.Structure):
     _fields_ = [
         ('struct_size', C.c_int), ('batch', C.c_int), ('num_levels', C.c_int),
@@ -96,6 +104,13 @@ _PROTOS = {
                              C.POINTER(_i), C.POINTER(_i), C.POINTER(_i)]),
     'st_decode_nms_workspace_bytes': (_sz, [C.POINTER(StDecodeDesc)]),
     'st_lapjv_extended': (_i, [_vp, _i, _i, C.c_double, _vp, _vp]),
+    'st_tracker_create': (_i, [C.POINTER(StTrackerConfig), C.POINTER(_vp)]),
+    'st_tracker_destroy': (_i, [_vp]),
+    'st_tracker_reset': (_i, [_vp]),
+    'st_tracker_track': (_i, [_vp, _i, _vp, _i, _vp, _vp, _i, C.POINTER(_i)]),
+    'st_tracker_num_tracks': (_i, [_vp]),
+    'st_tracker_next_id': (C.c_longlong, [_vp]),
+    'st_tracker_get_track': (_i, [_vp, _i, _vp, _vp, _vp, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i)]),
     'st_decode_nms': (_i, [C.POINTER(StDecodeDesc), _vp, _vp, _sz, _vp, _vp, _vp, _vp, _vp, _vp]),
     'st_costvolume_softargmin': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _f, _vp, _vp, _vp]),
     'st_softargmin': (_i, [_vp, _i, _i, _i, _i, _f, _vp, _vp]),

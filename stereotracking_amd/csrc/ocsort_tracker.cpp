@@ -1,0 +1,430 @@
+// Depth-guided OC-SORT association step as a host-side native routine (north_star keeps this step on the CPU).
+//
+// Behavioural spec (file:line in /root/reference), the same one stereotracking_amd/trackers.py follows in Python:
+//   OCSORTTracker_Disparity.track            mmtrack/models/trackers/ocsort_tracker_disparity.py:345-618
+//     init_track / update_track              :105-146  (+ kalman_tracker_base.py:55-76, base_tracker.py:54-141)
+//     vel_direction(_batch), k_step_observation, last_obs      :148-185, :267-271
+//     ocm_assign_ids / ocr_assign_ids / online_smooth          :187-265, :273-317, :319-343
+//   KalmanTrackerBase.pop_invalid_tracks     kalman_tracker_base.py:78-88
+//   KalmanFilter initiate/predict/project/update               mmtrack/models/motion/kalman_filter.py:60-189
+//   lap.lapjv                                -> st_lapjv_extended (lapjv.cpp)
+//
+// Why native: the dense path delivers a frame every ~0.75 ms per GPU; the Python tracker (a few hundred tiny
+// torch / numpy calls per frame) needs 1-3 ms per frame on 6 objects and would be the bottleneck of
+// BASELINE configs[2]/[3].  This routine does the same arithmetic in ~10-20 us.
+//
+// Numerics.  Everything that DECIDES an assignment is computed in the reference's precision and operation order:
+// box conversions, IoU, the velocity-direction term and the cost matrix in float32 (single IEEE operations, file
+// compiled with -ffp-contract=off), the assignment in float64 by the same Jonker-Volgenant procedure.  Two things
+// can differ from the Python stack in the last bit and are documented rather than hidden: acosf (glibc vs the SLEEF
+// routine behind torch.acos: <= 1 ulp, i.e. <= 1e-8 on a cost) and the 4x4 Cholesky / 8x8 products of the Kalman
+// update (plain loops here, LAPACK / BLAS there: ~1e-16 relative on the state, invisible after the float32 cast
+// the cost matrix applies).  Exact ties (duplicate boxes) stay exact ties, because both sides of a tie go through
+// identical instructions.  tests/test_cpu_tracker_oracle.py holds the ids, boxes, scores, depth and scales of
+// every frame EQUAL to the oracle's and the Kalman state equal to 1e-9.
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <memory>
+#include <vector>
+
+#include "st_common.h"
+
+extern "C" int st_lapjv_extended(const double* cost, int n_rows, int n_cols, double cost_limit, int32_t* x_out,
+                                 int32_t* y_out);
+
+namespace {
+
+struct Box { float v[4]; };
+
+// ---- Kalman filter (kalman_filter.py:38-189), float64 ---------------------------------------------------------
+constexpr double kWPos = 1.0 / 20, kWVel = 1.0 / 160;
+
+struct KState { double mean[8]; double cov[64]; };
+
+void kf_initiate(const float meas[4], KState& s) {
+  for (int i = 0; i < 4; ++i) { s.mean[i] = (double)meas[i]; s.mean[4 + i] = 0.0; }
+  const double h = (double)meas[3];
+  const double std[8] = {2 * kWPos * h, 2 * kWPos * h, 1e-2, 2 * kWPos * h,
+                         10 * kWVel * h, 10 * kWVel * h, 1e-5, 10 * kWVel * h};
+  std::memset(s.cov, 0, sizeof(s.cov));
+  for (int i = 0; i < 8; ++i) s.cov[i * 8 + i] = std[i] * std[i];
+}
+
+void kf_predict(KState& s) {
+  const double h = s.mean[3];
+  const double std[8] = {kWPos * h, kWPos * h, 1e-2, kWPos * h, kWVel * h, kWVel * h, 1e-5, kWVel * h};
+  // mean' = F mean : F = I + shift(4): rows < 4 add the velocity
+  for (int i = 0; i < 4; ++i) s.mean[i] = s.mean[i] + s.mean[i + 4];
+  // cov' = F (cov F^T) + Q   (numpy multi_dot picks A(BC) when both orders cost the same)
+  double t[64];
+  for (int i = 0; i < 8; ++i)
+    for (int j = 0; j < 8; ++j) t[i * 8 + j] = j < 4 ? s.cov[i * 8 + j] + s.cov[i * 8 + j + 4] : s.cov[i * 8 + j];
+  for (int i = 0; i < 8; ++i)
+    for (int j = 0; j < 8; ++j) s.cov[i * 8 + j] = i < 4 ? t[i * 8 + j] + t[(i + 4) * 8 + j] : t[i * 8 + j];
+  for (int i = 0; i < 8; ++i) s.cov[i * 8 + i] += std[i] * std[i];
+}
+
+void kf_update(KState& s, const float meas[4]) {
+  // project: mean_p = mean[:4], S = cov[:4,:4] + diag(std^2)
+  const double h = s.mean[3];
+  const double std[4] = {kWPos * h, kWPos * h, 1e-1, kWPos * h};
+  double S[16];
+  for (int i = 0; i < 4; ++i)
+    for (int j = 0; j < 4; ++j) S[i * 4 + j] = s.cov[i * 8 + j] + (i == j ? std[i] * std[i] : 0.0);
+  // Cholesky S = L L^T (lower)
+  double L[16] = {0};
+  for (int j = 0; j < 4; ++j) {
+    double d = S[j * 4 + j];
+    for (int k = 0; k < j; ++k) d -= L[j * 4 + k] * L[j * 4 + k];
+    d = std::sqrt(d);
+    L[j * 4 + j] = d;
+    for (int i = j + 1; i < 4; ++i) {
+      double v = S[i * 4 + j];
+      for (int k = 0; k < j; ++k) v -= L[i * 4 + k] * L[j * 4 + k];
+      L[i * 4 + j] = v / d;
+    }
+  }
+  // gain^T = S^-1 (cov H^T)^T : solve S X = B with B[r][c] = cov[c][r] (4 x 8), X = gain^T
+  double X[32];
+  for (int c = 0; c < 8; ++c) {
+    double y[4];
+    for (int i = 0; i < 4; ++i) {      // L y = b
+      double v = s.cov[c * 8 + i];
+      for (int k = 0; k < i; ++k) v -= L[i * 4 + k] * y[k];
+      y[i] = v / L[i * 4 + i];
+    }
+    for (int i = 3; i >= 0; --i) {     // L^T x = y
+      double v = y[i];
+      for (int k = i + 1; k < 4; ++k) v -= L[k * 4 + i] * X[k * 8 + c];
+      X[i * 8 + c] = v / L[i * 4 + i];
+    }
+  }
+  double innov[4];
+  for (int i = 0; i < 4; ++i) innov[i] = (double)meas[i] - s.mean[i];
+  // new_mean = mean + innovation . gain^T
+  for (int c = 0; c < 8; ++c) {
+    double acc = 0.0;
+    for (int r = 0; r < 4; ++r) acc += innov[r] * X[r * 8 + c];
+    s.mean[c] += acc;
+  }
+  // new_cov = cov - gain (S gain^T)
+  double SX[32];
+  for (int r = 0; r < 4; ++r)
+    for (int c = 0; c < 8; ++c) {
+      double acc = 0.0;
+      for (int k = 0; k < 4; ++k) acc += S[r * 4 + k] * X[k * 8 + c];
+      SX[r * 8 + c] = acc;
+    }
+  for (int i = 0; i < 8; ++i)
+    for (int j = 0; j < 8; ++j) {
+      double acc = 0.0;
+      for (int k = 0; k < 4; ++k) acc += X[k * 8 + i] * SX[k * 8 + j];
+      s.cov[i * 8 + j] -= acc;
+    }
+}
+
+// ---- float32 box helpers (single IEEE ops, reference order) -----------------------------------------------------
+inline void xyxy_to_cxcyah(const float b[4], float o[4]) {   // structures/bbox/transforms.py:72-86
+  o[0] = (b[2] + b[0]) / 2;
+  o[1] = (b[3] + b[1]) / 2;
+  const float w = b[2] - b[0], h = b[3] - b[1];
+  o[2] = w / h;
+  o[3] = h;
+}
+
+inline void cxcyah_to_xyxy(const float b[4], float o[4]) {   // transforms.py:89-101
+  const float w = b[2] * b[3];
+  o[0] = b[0] - w / 2.0f;
+  o[1] = b[1] - b[3] / 2.0f;
+  o[2] = b[0] + w / 2.0f;
+  o[3] = b[1] + b[3] / 2.0f;
+}
+
+// torch.max / torch.min / clamp propagate NaN (std::fmax would drop it): a NaN box must give a NaN cost
+inline float tmax(float a, float b) { return a != a ? a : (b != b ? b : (a > b ? a : b)); }
+inline float tmin(float a, float b) { return a != a ? a : (b != b ? b : (a < b ? a : b)); }
+
+inline float iou(const float a[4], const float b[4]) {       // mmdet bbox_overlaps, mode='iou', eps 1e-6
+  const float area1 = (a[2] - a[0]) * (a[3] - a[1]);
+  const float area2 = (b[2] - b[0]) * (b[3] - b[1]);
+  const float w = tmax(tmin(a[2], b[2]) - tmax(a[0], b[0]), 0.f);   // (rb - lt).clamp(min=0)
+  const float h = tmax(tmin(a[3], b[3]) - tmax(a[1], b[1]), 0.f);
+  const float overlap = w * h;
+  const float uni = tmax(area1 + area2 - overlap, 1e-6f);           // torch.max(union, eps)
+  return overlap / uni;
+}
+
+struct Track {
+  int64_t id = 0;
+  KState kf{};
+  KState saved{};
+  bool tentative = true, tracked = true;
+  int last_frame = 0;
+  int n_fed = 0;                 // len(track.bboxes): frames this track was fed a detection
+  // observation history (track.obs): only what the algorithm reads back is kept -
+  //   the last vel_delta_t + 1 entries (k_step_observation), the last non-None entry and the trailing None count
+  std::vector<Box> win;          // ring of the most recent entries, oldest first
+  std::vector<char> win_valid;
+  long long n_obs = 0;
+  Box last_valid{};
+  int trailing_none = 0;
+  float vel[2] = {-1.f, -1.f};
+  bool vel_is_placeholder = true;   // velocity == tensor((-1, -1)) (sum == -2 -> "no velocity yet")
+};
+
+}  // namespace
+
+struct StTracker {
+  StTrackerConfig cfg{};
+  std::vector<Track> tracks;     // dict insertion order
+  long long num_tracks = 0;
+
+  void reset() { tracks.clear(); num_tracks = 0; }
+  int find(int64_t id) const {
+    for (size_t i = 0; i < tracks.size(); ++i)
+      if (tracks[i].id == id) return (int)i;
+    return -1;
+  }
+
+  void push_obs(Track& t, const float* box) {
+    const size_t cap = (size_t)cfg.vel_delta_t + 1;
+    Box b{};
+    if (box) std::memcpy(b.v, box, sizeof(b.v));
+    if (t.win.size() == cap) { t.win.erase(t.win.begin()); t.win_valid.erase(t.win_valid.begin()); }
+    t.win.push_back(b);
+    t.win_valid.push_back(box != nullptr);
+    ++t.n_obs;
+    if (box) { t.last_valid = b; t.trailing_none = 0; } else { ++t.trailing_none; }
+  }
+  // obs[num_obs - 1 - vel_delta_t] when it exists and is a detection, else the last detection (:173-185)
+  const float* k_step_observation(const Track& t) const {
+    if (t.n_obs > cfg.vel_delta_t && t.win.size() == (size_t)cfg.vel_delta_t + 1 && t.win_valid[0])
+      return t.win[0].v;
+    return t.last_valid.v;
+  }
+  void set_velocity(Track& t, const float* b1, const float* b2) {   // vel_direction (:148-156)
+    const float s1 = ((b1[0] + b1[1]) + b1[2]) + b1[3], s2 = ((b2[0] + b2[1]) + b2[2]) + b2[3];
+    if (s1 < 0 || s2 < 0) { t.vel[0] = t.vel[1] = -1.f; t.vel_is_placeholder = true; return; }
+    const float cx1 = (b1[0] + b1[2]) / 2.0f, cy1 = (b1[1] + b1[3]) / 2.0f;
+    const float cx2 = (b2[0] + b2[2]) / 2.0f, cy2 = (b2[1] + b2[3]) / 2.0f;
+    const float sy = cy2 - cy1, sx = cx2 - cx1;
+    const float norm = std::sqrt(sy * sy + sx * sx) + 1e-6f;
+    t.vel[0] = sy / norm;
+    t.vel[1] = sx / norm;
+    t.vel_is_placeholder = (t.vel[0] + t.vel[1]) == -2.0f;
+  }
+
+  void init_track(int64_t id, const float* row, int frame_id) {
+    Track t;
+    t.id = id;
+    t.n_fed = 1;
+    t.last_frame = frame_id;
+    t.tentative = frame_id != 0;        // tracks born on frame 0 are confirmed at once (:108-111)
+    float m[4];
+    xyxy_to_cxcyah(row, m);
+    kf_initiate(m, t.kf);
+    push_obs(t, row);
+    t.tracked = true;
+    tracks.push_back(std::move(t));
+  }
+  void update_track(Track& t, const float* row, int frame_id) {
+    ++t.n_fed;
+    t.last_frame = frame_id;
+    if (t.tentative && t.n_fed >= cfg.num_tentatives) t.tentative = false;
+    float m[4];
+    xyxy_to_cxcyah(row, m);
+    kf_update(t.kf, m);
+    t.tracked = true;
+    push_obs(t, row);
+    set_velocity(t, k_step_observation(t), row);
+  }
+  void online_smooth(Track& t, const float* new_box) {   // :319-343
+    const float* last = t.last_valid.v;
+    const int gap = t.trailing_none;
+    float step[4];
+    for (int i = 0; i < 4; ++i) step[i] = (new_box[i] - last[i]) / (float)(gap + 1);
+    t.kf = t.saved;
+    for (int g = 0; g < gap; ++g) {
+      float vb[4], m[4];
+      for (int i = 0; i < 4; ++i) vb[i] = last[i] + (float)(g + 1) * step[i];
+      xyxy_to_cxcyah(vb, m);
+      kf_update(t.kf, m);
+    }
+  }
+
+  // cost matrix of one association stage + assignment; rows = tracks `tidx`, cols = detections `didx`.
+  // with_motion: OCM (KF-predicted boxes + velocity-direction term); else OCR (last observations, IoU only).
+  void assign(const std::vector<int>& tidx, const std::vector<int>& didx, const float* dets, bool with_motion,
+              std::vector<int32_t>& det_to_row) {
+    const int R = (int)tidx.size(), Cn = (int)didx.size();
+    det_to_row.assign(Cn, -1);
+    if (R == 0 || Cn == 0) return;
+    std::vector<double> cost((size_t)R * Cn);
+    for (int r = 0; r < R; ++r) {
+      const Track& t = tracks[tidx[r]];
+      float tb[4];
+      if (with_motion) {
+        const float m[4] = {(float)t.kf.mean[0], (float)t.kf.mean[1], (float)t.kf.mean[2], (float)t.kf.mean[3]};
+        cxcyah_to_xyxy(m, tb);
+      } else {
+        std::memcpy(tb, t.last_valid.v, sizeof(tb));
+      }
+      const float* ko = with_motion ? k_step_observation(t) : nullptr;
+      const bool valid = with_motion && !t.vel_is_placeholder &&
+                         (((ko[0] + ko[1]) + ko[2]) + ko[3]) != -4.0f;
+      for (int c = 0; c < Cn; ++c) {
+        const float* d = dets + (size_t)didx[c] * 8;
+        float v = iou(tb, d);
+        if (cfg.weight_iou_with_det_scores) v = v * d[4];
+        float dist = 1.0f - v;
+        if (with_motion) {
+          // direction from the k-step-old observation to this detection vs the track's velocity direction
+          const float cx1 = (ko[0] + ko[2]) / 2.0f, cy1 = (ko[1] + ko[3]) / 2.0f;
+          const float cx2 = (d[0] + d[2]) / 2.0f, cy2 = (d[1] + d[3]) / 2.0f;
+          const float sy = cy2 - cy1, sx = cx2 - cx1;
+          const float norm = std::sqrt(sy * sy + sx * sx) + 1e-6f;
+          float cosv = (sy / norm) * t.vel[0] + (sx / norm) * t.vel[1];
+          cosv = cosv < -1.f ? -1.f : (cosv > 1.f ? 1.f : cosv);
+          const float ang = (std::acos(cosv) - (float)(M_PI / 2.)) / (float)M_PI;
+          const float term = ang * (valid ? 1.0f : 0.0f);
+          dist = dist + term * cfg.vel_consist_weight;
+        }
+        cost[(size_t)r * Cn + c] = (double)dist;
+      }
+    }
+    std::vector<int32_t> x(R);
+    (void)st_lapjv_extended(cost.data(), R, Cn, 1.0 - (double)cfg.match_iou_thr, x.data(), det_to_row.data());
+  }
+
+  int track(int frame_id, const float* dets, int n, float* out_rows, int64_t* out_ids, int cap, int* out_n) {
+    if (frame_id == 0) reset();
+    std::vector<int> order;            // detections of the output, in output order
+    std::vector<int64_t> ids;
+    if (tracks.empty() || n == 0) {
+      for (int i = 0; i < n; ++i)
+        if (dets[(size_t)i * 8 + 4] > cfg.init_track_thr) { order.push_back(i); ids.push_back(num_tracks++); }
+    } else {
+      std::vector<int> cand;           // detections entering association (:409-421)
+      for (int i = 0; i < n; ++i) {
+        const float* d = dets + (size_t)i * 8;
+        const float area = (d[2] - d[0]) * (d[3] - d[1]);
+        if (d[4] > cfg.obj_score_thr && area > 100.f) cand.push_back(i);
+      }
+      // 1. KF predict of the confirmed tracks (:431-441)
+      std::vector<int> confirmed, tentative;
+      for (size_t k = 0; k < tracks.size(); ++k) (tracks[k].tentative ? tentative : confirmed).push_back((int)k);
+      for (int k : confirmed) {
+        Track& t = tracks[k];
+        if (t.last_frame != frame_id - 1) t.kf.mean[7] = 0;
+        if (t.tracked) t.saved = t.kf;
+        kf_predict(t.kf);
+      }
+      std::vector<int> matched_det, matched_trk;    // in the order the reference concatenates them
+      std::vector<int32_t> d2r;
+      auto apply = [&](const std::vector<int>& tidx, std::vector<int>& pool) {
+        std::vector<int> rest;
+        for (size_t c = 0; c < pool.size(); ++c) {
+          if (d2r[c] > -1) { matched_det.push_back(pool[c]); matched_trk.push_back(tidx[d2r[c]]); }
+          else rest.push_back(pool[c]);
+        }
+        pool.swap(rest);
+      };
+      // 2. confirmed tracks, 3. tentative tracks (OCM)
+      assign(confirmed, cand, dets, true, d2r);
+      apply(confirmed, cand);
+      assign(tentative, cand, dets, true, d2r);
+      apply(tentative, cand);
+      // 4. observation-centric recovery on every still-unmatched track (dict order)
+      std::vector<char> is_matched(tracks.size(), 0);
+      for (int k : matched_trk) is_matched[k] = 1;
+      std::vector<int> lost;
+      for (size_t k = 0; k < tracks.size(); ++k)
+        if (!is_matched[k]) lost.push_back((int)k);
+      if (!lost.empty()) {
+        assign(lost, cand, dets, false, d2r);
+        apply(lost, cand);
+        for (int k : matched_trk) is_matched[k] = 1;
+      }
+      // 5. re-found tracks: smooth the KF over the gap; unmatched tracks: mark lost (:568-581)
+      for (size_t i = 0; i < matched_det.size(); ++i) {
+        Track& t = tracks[matched_trk[i]];
+        if (!t.tracked) online_smooth(t, dets + (size_t)matched_det[i] * 8);
+      }
+      for (size_t k = 0; k < tracks.size(); ++k)
+        if (!is_matched[k]) { tracks[k].tracked = false; push_obs(tracks[k], nullptr); }
+      for (size_t i = 0; i < matched_det.size(); ++i) { order.push_back(matched_det[i]); ids.push_back(tracks[matched_trk[i]].id); }
+      // 6. new ids for the leftovers (no init threshold on later frames, :588-593)
+      for (int di : cand) { order.push_back(di); ids.push_back(num_tracks++); }
+    }
+    ST_REQUIRE((int)order.size() <= cap, "st_tracker_track: output capacity %d < %zu rows", cap, order.size());
+    // BaseTracker.update (:54-91): feed every output row to its track, then pop the invalid ones
+    for (size_t i = 0; i < order.size(); ++i) {
+      const float* row = dets + (size_t)order[i] * 8;
+      const int k = find(ids[i]);
+      if (k >= 0) update_track(tracks[k], row, frame_id);
+      else init_track(ids[i], row, frame_id);
+      std::memcpy(out_rows + i * 8, row, 8 * sizeof(float));
+      out_ids[i] = ids[i];
+    }
+    for (size_t k = 0; k < tracks.size();) {
+      const Track& t = tracks[k];
+      if (frame_id - t.last_frame >= cfg.num_frames_retain || (t.tentative && t.last_frame != frame_id))
+        tracks.erase(tracks.begin() + k);
+      else
+        ++k;
+    }
+    *out_n = (int)order.size();
+    return ST_OK;
+  }
+};
+
+extern "C" int st_tracker_create(const StTrackerConfig* cfg, StTracker** out) {
+  using namespace st;
+  if (!cfg || !out) return set_error(ST_ERR_INVALID, "st_tracker_create: null argument");
+  ST_REQUIRE(cfg->struct_size == (int)sizeof(StTrackerConfig), "st_tracker_create: struct_size mismatch");
+  ST_REQUIRE(cfg->vel_delta_t >= 0 && cfg->num_tentatives >= 1 && cfg->num_frames_retain >= 1,
+             "st_tracker_create: bad vel_delta_t / num_tentatives / num_frames_retain");
+  auto t = std::make_unique<StTracker>();
+  t->cfg = *cfg;
+  *out = t.release();
+  return ST_OK;
+}
+
+extern "C" int st_tracker_destroy(StTracker* t) {
+  delete t;
+  return ST_OK;
+}
+
+extern "C" int st_tracker_reset(StTracker* t) {
+  if (!t) return st::set_error(ST_ERR_INVALID, "st_tracker_reset: null tracker");
+  t->reset();
+  return ST_OK;
+}
+
+extern "C" int st_tracker_track(StTracker* t, int frame_id, const float* dets, int n, float* out_rows,
+                                int64_t* out_ids, int cap, int* out_n) {
+  using namespace st;
+  if (!t || !out_n) return set_error(ST_ERR_INVALID, "st_tracker_track: null argument");
+  ST_REQUIRE(n >= 0 && cap >= 0 && (n == 0 || dets) && (cap == 0 || (out_rows && out_ids)),
+             "st_tracker_track: bad buffers");
+  return t->track(frame_id, dets, n, out_rows, out_ids, cap, out_n);
+}
+
+extern "C" int st_tracker_num_tracks(const StTracker* t) { return t ? (int)t->tracks.size() : 0; }
+extern "C" long long st_tracker_next_id(const StTracker* t) { return t ? t->num_tracks : 0; }
+
+extern "C" int st_tracker_get_track(const StTracker* t, int index, int64_t* id, double* mean8, double* cov64,
+                                    int* tentative, int* tracked, int* last_frame) {
+  using namespace st;
+  if (!t || index < 0 || index >= (int)t->tracks.size())
+    return set_error(ST_ERR_INVALID, "st_tracker_get_track: bad index %d", index);
+  const Track& k = t->tracks[index];
+  if (id) *id = k.id;
+  if (mean8) std::memcpy(mean8, k.kf.mean, sizeof(k.kf.mean));
+  if (cov64) std::memcpy(cov64, k.kf.cov, sizeof(k.kf.cov));
+  if (tentative) *tentative = k.tentative;
+  if (tracked) *tracked = k.tracked;
+  if (last_frame) *last_frame = k.last_frame;
+  return ST_OK;
+}

@@ -123,8 +123,21 @@ def scale_bbox(bboxes, scales):
 
 @MODELS.register_module(name=['OCSORT_Disparity'])
 class OCSORT_Disparity(nn.Module):
+    """MOT shell (reference mmtrack/models/mot/ocsort_disparity.py:16-220).  `predict` accepts N >= 1 frames of ONE
+    video in frame order and drives the batched dense path (pipeline.InflightPipelines): the frames go through the
+    HIP launch plan `dense_batch` at a time on `inflight` contexts / streams; per chunk there is ONE device->host
+    copy of the fixed-size detection records and ONE batched st_box_depth launch for the tracks' depth column - no
+    per-frame launches, no per-frame syncs.  The association step consumes the frames sequentially on the CPU while
+    the GPU works on the following chunks.
+
+    New (optional) constructor arguments next to the reference's: `stereo` (StereoCostVolume config), `dense_batch`,
+    `inflight`, `max_det` (rows of the detection buffer: a capacity, overflow raises) and `results_device`
+    ('cpu': results stay where the CPU tracker produced them - the consumers are the host-side evaluator / CSV
+    writer; 'input': moved back to the device of the inputs like the reference's tensors)."""
+
     def __init__(self, detector=None, tracker=None, motion=None, data_preprocessor=None, init_cfg=None,
-                 baseline=0.25, focal_length=640, stereo=None):
+                 baseline=0.25, focal_length=640, stereo=None, dense_batch=8, inflight=3, max_det=1000,
+                 results_device='cpu', autotune=True, tuning_cache=None):
         super().__init__()
         self.data_preprocessor = MODELS.build(data_preprocessor) if data_preprocessor is not None else None
         self.detector = MODELS.build(detector) if detector is not None else None
@@ -134,7 +147,14 @@ class OCSORT_Disparity(nn.Module):
         self.stereo = MODELS.build(stereo) if stereo is not None else None  # StereoCostVolume (new module)
         if self.stereo is not None and self.detector is not None:
             self.detector.__dict__['stereo'] = self.stereo   # plain reference: registered once, under the shell
+        self.dense_batch, self.inflight, self.max_det = int(dense_batch), int(inflight), int(max_det)
+        if results_device not in ('cpu', 'input'):
+            raise ValueError("results_device must be 'cpu' or 'input'")
+        self.results_device = results_device
+        self.autotune, self.tuning_cache = bool(autotune), tuning_cache
         self.lib = _lib.load()
+        self._dense = {}          # (batch, ori_h, ori_w, stereo) -> [InflightPipelines, weights version]
+        self.timings = dict(frames=0, tracker_s=0.0, host_s=0.0)   # cumulative host-side cost of predict()
 
     # ---- reference plumbing (mot/base.py:68-113) -----------------------------------------------------
     def init_weights(self):
@@ -152,70 +172,191 @@ class OCSORT_Disparity(nn.Module):
             raise NotImplementedError('training is out of scope of the HIP hot path (SURVEY.md §3.3)')
         raise NotImplementedError('tensor mode is not supported (reference mot/base.py:144-145)')
 
+    # ---- the batched dense path behind the plugin surface ----------------------------------------------
+    def _weights_version(self):
+        return tuple(t._version for t in self.state_dict(keep_vars=True).values())
+
+    def dense_runner(self, ori_hw, stereo, batch=None):
+        """InflightPipelines context set for (batch, ori_hw, stereo), built from this model's config and
+        loaded from its state_dict (reference keys `detector.*`, plus `stereo.agg.*` of the new module)."""
+        from .pipeline import InflightPipelines
+        det = self.detector
+        cfg = det.test_cfg
+        nms = cfg.get('nms', dict(type='nms', iou_threshold=0.65))
+        if nms.get('type', 'nms') != 'nms':
+            raise NotImplementedError(f"nms type {nms.get('type')} (only greedy 'nms')")
+        if not cfg.get('yolox_style', False):
+            raise NotImplementedError('the batched dense path implements the shipped yolox_style=True post-processing '
+                                      '(no max_per_img cut); use detector.predict for other test_cfg')
+        batch = int(batch or self.dense_batch)
+        key = (batch, int(ori_hw[0]), int(ori_hw[1]), bool(stereo))
+        ent = self._dense.get(key)
+        if ent is None:
+            sm = self.stereo
+            runner = InflightPipelines(
+                max(1, self.inflight), batch, (key[1], key[2]), det.widen_factor, det.deepen_factor,
+                det.num_classes, stereo=bool(stereo), max_disp=sm.max_disp if stereo else 192,
+                feat_stride=sm.feat_stride if stereo else 4, temperature=sm.temperature if stereo else 32.0,
+                score_thr=cfg.get('score_thr', 0.01), iou_thr=nms.get('iou_threshold', 0.65), max_det=self.max_det,
+                baseline=self.baseline, focal_length=self.focal_length,
+                pad_size_divisor=getattr(self.data_preprocessor, 'pad_size_divisor', 32) or 32,
+                agg_layers=sm.agg_layers if stereo else 0)
+            ent = self._dense[key] = [runner, None]
+        ver = self._weights_version()
+        if ent[1] != ver:
+            sd = {k[len('detector.'):]: v for k, v in self.state_dict().items() if k.startswith('detector.')}
+            sd.update({k: v for k, v in self.state_dict().items() if k.startswith('stereo.')})
+            ent[0].load_state_dict(sd, autotune=self.autotune, tuning_cache=self.tuning_cache)
+            ent[1] = ver
+        return ent[0]
+
     # ---- per-box depth on the device (ocsort_disparity.py:113-175) -------------------------------------
     def bbox_postp_depth(self, pred_instances, disp, gt_depth=None):
-        """disp: (1,3,H,W) disp_postp.  Returns (instances with scaled `bboxes`, `scales`, `depth`), depth dict."""
+        """disp: (1,3,H,W) disp_postp.  Returns (instances with scaled `bboxes`, `scales`, `depth`), depth dict.
+        Single-frame form of the reference method (predict() uses the batched launch instead)."""
         boxes = pred_instances['bboxes'].float().contiguous()
-        d_values, scales, scaled = self._box_depth(disp, boxes, self.baseline, self.focal_length)
-        depth_values = dict(d_values=d_values)
+        d_values, scales, scaled = self._box_depth(disp, boxes[None], None, self.baseline, self.focal_length)
+        depth_values = dict(d_values=d_values[0])
         if gt_depth is not None:
-            depth_values['gt_d_values'], _, _ = self._box_depth(gt_depth, boxes, -1.0, 1.0)
-        pred_instances['bboxes'] = scaled
-        pred_instances['scales'] = scales
-        pred_instances['depth'] = d_values
+            depth_values['gt_d_values'] = self._box_depth(gt_depth, boxes[None], None, -1.0, 1.0)[0][0]
+        pred_instances['bboxes'] = scaled[0]
+        pred_instances['scales'] = scales[0]
+        pred_instances['depth'] = d_values[0]
         return pred_instances, depth_values
 
-    def _box_depth(self, disp, boxes, baseline, focal):
-        M = boxes.shape[0]
+    def _box_depth(self, disp, boxes, counts, baseline, focal):
+        """ONE st_box_depth launch for a whole batch: disp (N,C,H,W), boxes (N,M,4), counts (N,) int32 or None
+        (= all M rows) -> depth (N,M), scales (N,M), scaled boxes (N,M,4)."""
+        N, M = boxes.shape[0], boxes.shape[1]
         dev = boxes.device
+        depth = torch.zeros(N, M, device=dev)
+        scales = torch.zeros(N, M, device=dev)
+        sboxes = torch.zeros(N, M, 4, device=dev)
         if M == 0:
-            z = boxes.new_zeros(0)
-            return z, z.clone(), boxes.new_zeros(0, 4)
+            return depth, scales, sboxes
         _, Cc, H, W = disp.shape
         disp = disp.float().contiguous()
-        counts = torch.tensor([M], dtype=torch.int32, device=dev)
-        depth = torch.empty(1, M, device=dev)
-        scales = torch.empty(1, M, device=dev)
-        sboxes = torch.empty(1, M, 4, device=dev)
-        check(self.lib.st_box_depth(ptr(disp), Cc * H * W, 1, H, W, ptr(boxes), ptr(counts), M, float(baseline),
-                                    float(focal), None, 0, current_stream(), ptr(depth), ptr(scales), ptr(sboxes)),
-              'st_box_depth')
-        return depth[0], scales[0], sboxes[0]
+        if counts is None:
+            counts = torch.full((N,), M, dtype=torch.int32, device=dev)
+        check(self.lib.st_box_depth(ptr(disp), Cc * H * W, N, H, W, ptr(boxes.float().contiguous()), ptr(counts), M,
+                                    float(baseline), float(focal), None, 0, current_stream(), ptr(depth), ptr(scales),
+                                    ptr(sboxes)), 'st_box_depth')
+        return depth, scales, sboxes
 
     # ---- predict (ocsort_disparity.py:50-111) ------------------------------------------------------------
     def predict(self, inputs, data_samples, **kwargs):
+        import time
+        from .dist import DetectionOverflow
         img, disp_postp = inputs['img'], inputs.get('disp_postp')
-        disp_mask = inputs.get('disp_mask')
         depth_postp = inputs.get('depth_postp', None)
         assert img.dim() == 5, 'The img must be 5D Tensor (N, T, C, H, W).'
         assert img.size(1) == 1, 'one key frame per sample (T = 1)'
         N = img.size(0)
         assert len(data_samples) == N
-        data = dict(img=img[:, 0])
-        if disp_postp is not None:
-            data['disp_postp'] = disp_postp[:, 0]
-        elif self.stereo is not None and inputs.get('right') is not None:
-            data['right'] = inputs['right'][:, 0]   # disp_postp is computed by the stereo module
+        img = img[:, 0]
+        if not img.is_cuda:
+            raise RuntimeError('OCSORT_Disparity runs on the HIP path only: inputs must be CUDA tensors')
+        stereo = disp_postp is None
+        if stereo:
+            if self.stereo is None or inputs.get('right') is None:
+                raise KeyError("inputs need 'disp_postp', or 'right' with a stereo module configured")
+            second = inputs['right'][:, 0]
         else:
-            raise KeyError("inputs need 'disp_postp', or 'right' with a stereo module configured")
-        if disp_mask is not None:
-            data['disp_mask'] = disp_mask[:, 0]
-        det_results = self.detector.predict(data, data_samples)   # batched dense path
-        outs = []
-        for n in range(N):                                      # sequential association, frame order
-            sample = data_samples[n]
-            det = det_results[n].pred_instances
-            disp_n = data['disp_postp'][n:n + 1]
-            gt_n = depth_postp[n] if depth_postp is not None else None
-            scaled, _ = self.bbox_postp_depth(det.clone(), disp_n, gt_n)
-            sample.pred_det_instances = scaled
-            tracks = self.tracker.track(model=self, img=data['img'][n:n + 1], feats=None, data_sample=sample,
-                                        **kwargs)
-            tracks['bboxes'] = scale_bbox(tracks.bboxes, 1 / tracks.scales)      # unscale
-            _, depth = self.bbox_postp_depth(tracks.clone(), disp_n, gt_n)
-            tracks['depth'] = depth['d_values']
-            tracks['gt_depth'] = depth.get('gt_d_values', depth['d_values'])
-            sample.pred_det_instances = det.clone()
-            sample.pred_track_instances = tracks
-            outs.append(sample)
+            second = disp_postp[:, 0]
+        gt = depth_postp[:, 0] if depth_postp is not None else None
+        metas = [s.metainfo for s in data_samples]
+        ori = tuple(int(v) for v in metas[0].get('ori_shape', img.shape[-2:])[:2])
+        for m in metas[1:]:
+            if tuple(int(v) for v in m.get('ori_shape', ori)[:2]) != ori:
+                raise NotImplementedError('one batched launch plan needs a uniform ori_shape')
+        B = min(self.dense_batch, N)      # a call with fewer frames than dense_batch gets a plan of its own size
+        runner = self.dense_runner(ori, stereo, B)
+        dev = img.device
+        chunks = [(s, min(s + B, N)) for s in range(0, N, B)]
+        t_host0 = time.perf_counter()
+
+        def padded(t, s, e):
+            t = t[s:e].float().contiguous()
+            if e - s < B:      # last chunk: repeat its last frame (results of the padding are ignored)
+                t = torch.cat([t, t[-1:].expand(B - (e - s), *t.shape[1:])])
+            return t
+
+        def submit(ci):
+            s, e = chunks[ci]
+            a, b = padded(img, s, e), padded(second, s, e)
+            holder = {}
+
+            def post(out, ctx):   # under the context's stream: pack + start the ONE device->host copy of this chunk
+                rec = runner.pipes[ctx].pack_detections(out, scaled='both', n_real=e - s)
+                host = torch.empty(rec.shape, dtype=rec.dtype, pin_memory=True)
+                host.copy_(rec, non_blocking=True)
+                holder.update(ctx=ctx, disp=out['disp_postp'], host=host)
+                return out
+            _, ev = runner.submit(a, right=b if stereo else None, disp_postp=None if stereo else b, post=post)
+            return dict(s=s, e=e, ev=ev, **holder)
+
+        jobs = {ci: submit(ci) for ci in range(min(len(chunks), len(runner)))}
+        outs, pending = [None] * N, []
+        for ci in range(len(chunks)):
+            job = jobs.pop(ci)
+            job['ev'].synchronize()                       # the only wait of this chunk's forward pass
+            rec = job['host']
+            s, e = job['s'], job['e']
+            tracks_of = []
+            t0 = time.perf_counter()
+            for n in range(s, e):
+                r = rec[n - s]
+                k, cap = int(r[0, 0]), int(r[0, 1])
+                if k > cap:
+                    raise DetectionOverflow(f'frame {n}: {k} detections kept but the detection buffer has {cap} rows; '
+                                            f'build the model with a larger max_det')
+                rows = r[1:1 + k]
+                labels = rows[:, 5].long()
+                sample = data_samples[n]
+                # reference :82-86: the tracker consumes the depth-SCALED boxes + scales + depth
+                sample.pred_det_instances = InstanceData(bboxes=rows[:, 8:12], scores=rows[:, 4], labels=labels,
+                                                         scales=rows[:, 7], depth=rows[:, 6])
+                tracks = self.tracker.track(model=self, img=None, feats=None, data_sample=sample, **kwargs)
+                tracks['bboxes'] = scale_bbox(tracks.bboxes, 1 / tracks.scales)      # unscale (:95-97)
+                sample.pred_det_instances = InstanceData(bboxes=rows[:, 0:4].clone(), scores=rows[:, 4].clone(),
+                                                         labels=labels, prior_idx=rows[:, 12].long())   # (:107-108)
+                tracks_of.append(tracks)
+            self.timings['tracker_s'] += time.perf_counter() - t0
+            # reference :99-104: depth (and gt depth) of the UNSCALED track boxes - ONE batched launch per chunk,
+            # enqueued on the chunk's own stream (its disp_postp buffer is still intact there)
+            mt = max([len(t) for t in tracks_of] + [1])
+            tb = torch.zeros(B, mt, 4, pin_memory=True)
+            tc = torch.zeros(B, dtype=torch.int32, pin_memory=True)
+            for i, t in enumerate(tracks_of):
+                tb[i, :len(t)] = t.bboxes
+                tc[i] = len(t)
+            stream = runner.streams[job['ctx']]
+            with torch.cuda.stream(stream):
+                tbd, tcd = tb.to(dev, non_blocking=True), tc.to(dev, non_blocking=True)
+                d = self._box_depth(job['disp'], tbd, tcd, self.baseline, self.focal_length)[0]
+                cols = [d]
+                if gt is not None:
+                    cols.append(self._box_depth(padded(gt, s, e), tbd, tcd, -1.0, 1.0)[0])
+                dh = torch.empty(len(cols), B, mt, pin_memory=True)
+                dh.copy_(torch.stack(cols), non_blocking=True)
+                ev2 = torch.cuda.Event()
+                ev2.record(stream)
+            pending.append((s, e, tracks_of, dh, ev2, (tbd, tcd)))
+            nxt = ci + len(runner)
+            if nxt < len(chunks):                          # reuse this context (stream order: after the depth launch)
+                jobs[nxt] = submit(nxt)
+        for s, e, tracks_of, dh, ev2, _keep in pending:
+            ev2.synchronize()
+            for i, tracks in enumerate(tracks_of):
+                k = len(tracks)
+                tracks['depth'] = dh[0, i, :k].clone()
+                tracks['gt_depth'] = dh[-1, i, :k].clone()   # = depth when no gt depth map was given (:104)
+                sample = data_samples[s + i]
+                if self.results_device == 'input':
+                    tracks = tracks.to(dev)
+                    sample.pred_det_instances = sample.pred_det_instances.to(dev)
+                sample.pred_track_instances = tracks
+                outs[s + i] = sample
+        self.timings['frames'] += N
+        self.timings['host_s'] += time.perf_counter() - t_host0
         return outs

@@ -147,13 +147,18 @@ class StereoDensePipeline:
     def pack_detections(out, scaled=False, n_real=None):
         """Fixed-size, self-describing frame records for the all-gather: (N, M + 1, 8) fp32.
         Row 0 = header [count kept (true, may exceed M = overflow), M, valid frame flag, 0...]; rows 1..M =
-        x1,y1,x2,y2,score,label,depth,scale (`scaled`: the depth-scaled boxes the tracker consumes).  A fresh
-        tensor: safe to keep after the context's buffers are reused.  Frames >= n_real are batch padding."""
-        boxes = out['scaled_boxes'] if scaled else out['boxes']
-        rows = torch.cat([boxes, out['scores'][..., None], out['labels'][..., None].float(),
-                          out['depth'][..., None], out['scales'][..., None]], dim=-1)
+        x1,y1,x2,y2,score,label,depth,scale (`scaled`: the depth-scaled boxes the tracker consumes;
+        scaled='both': 13 columns, the unscaled box first, then the scaled box and the kept prior index appended -
+        what the MOT shell copies to the host in ONE transfer per batch).  A fresh tensor: safe to keep after the context's buffers are reused.
+        Frames >= n_real are batch padding."""
+        boxes = out['scaled_boxes'] if scaled is True else out['boxes']
+        cols = [boxes, out['scores'][..., None], out['labels'][..., None].float(), out['depth'][..., None],
+                out['scales'][..., None]]
+        if scaled == 'both':
+            cols += [out['scaled_boxes'], out['prior_idx'][..., None].float()]   # prior index < 2^24: exact in fp32
+        rows = torch.cat(cols, dim=-1)
         N, M = rows.shape[0], rows.shape[1]
-        head = rows.new_zeros(N, 1, 8)
+        head = rows.new_zeros(N, 1, rows.shape[2])
         head[:, 0, 0] = out['counts'].float()
         head[:, 0, 1] = float(M)
         head[:, 0, 2] = 1.0

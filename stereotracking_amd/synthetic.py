@@ -168,3 +168,33 @@ def synthetic_batch(seeds, height=720, width=1280, max_disp=192, device='cpu'):
                disp_postp=torch.from_numpy(np.stack(disps)))
     out['disp_mask'] = (out['disp_postp'][:, :1] > 0).float()
     return {k: v.to(device) for k, v in out.items()}
+
+
+def synthetic_detection_stream(seed=51, T=64, K=6, occlusion=(3, 20, 28), duplicates=False):
+    """Seeded synthetic DETECTION stream for the association step (SURVEY.md §8c fixture iv / §8d config 3): K objects
+    with constant velocity + noise, 10 % dropped detections, one object occluded for a few frames, depth-consistent
+    scales; boxes are the depth-SCALED boxes the tracker consumes.  `duplicates`: every 7th frame repeats a detection
+    exactly (equal IoU => the assignment optimum is not unique and the solver's tie behaviour decides the ids).
+    -> float32 rows [t, x1, y1, x2, y2, score, depth, scale]."""
+    rng = np.random.RandomState(seed)
+    pos = rng.uniform([100, 80], [1100, 600], (K, 2))
+    vel = rng.uniform(-4, 4, (K, 2))
+    size = rng.uniform(12, 50, (K, 2))
+    depth = rng.uniform(5, 60, K)
+    score = rng.uniform(0.35, 0.95, K)
+    rows = []
+    for t in range(T):
+        p = pos + vel * t + rng.normal(0, 0.4, (K, 2))
+        keep = (rng.uniform(size=K) > 0.1) | (t == 0)
+        k_occ, t0, t1 = occlusion
+        keep[k_occ] &= not (t0 <= t < t1)          # an occlusion: the track must be re-identified
+        b = np.concatenate([p - size / 2, p + size / 2], 1)[keep].astype(np.float32)
+        sc = (score[keep] + rng.normal(0, 0.02, keep.sum())).astype(np.float32)
+        dp = (depth[keep] + rng.normal(0, 0.2, keep.sum())).astype(np.float32)
+        scl = np.clip(dp * dp / 400.0, 1.0, 3.0).astype(np.float32)
+        if duplicates and t % 7 == 3 and len(b):
+            j = t % len(b)
+            b, sc, dp, scl = (np.concatenate([a, a[j:j + 1]]) for a in (b, sc, dp, scl))
+        for i in range(len(b)):
+            rows.append([t, *b[i], sc[i], dp[i], scl[i]])
+    return np.asarray(rows, np.float32)

@@ -232,7 +232,8 @@ def test_tracker_reference_semantics_first_frame_tentative_and_retain():
     # was fed THIS frame, so it survives pop_invalid_tracks
     assert out[4].instances_id.tolist() == [2]
     trk2, _ = run_tracker([f0, far, empty, far, strong], num_frames_retain=2)
-    assert sorted(trk2.tracks.keys()) == [2] and trk2.tracks[2].tentative
+    state = trk2.native_state() if trk2.backend == 'native' else [dict(id=i, tentative=t.tentative) for i, t in trk2.tracks.items()]
+    assert [t['id'] for t in state] == [2] and state[0]['tentative']
     # small boxes (area <= 100) never enter association
     tiny = dict(bboxes=torch.tensor([[10., 10, 19, 19]]), scores=torch.tensor([0.95]),
                 labels=torch.zeros(1, dtype=torch.long), scales=torch.ones(1), depth=torch.ones(1))

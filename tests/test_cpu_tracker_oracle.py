@@ -102,8 +102,8 @@ class _ProductModel:
     motion = KalmanFilter()
 
 
-def run_product_tracker(det, num_frames, with_state=False, **cfg):
-    trk = OCSORTTracker_Disparity(**cfg)
+def run_product_tracker(det, num_frames, with_state=False, backend='native', **cfg):
+    trk = OCSORTTracker_Disparity(backend=backend, **cfg)
     out = []
     for t in range(num_frames):
         d = det[det[:, 0] == t]
@@ -136,29 +136,44 @@ def run_oracle_with_state(det, num_frames, **cfg):
 VARIANT = dict(SHIPPED_TRACKER, weight_iou_with_det_scores=True, match_iou_thr=0.3, num_frames_retain=10)
 
 
+@pytest.mark.parametrize('backend', ['native', 'python'])
 @pytest.mark.parametrize('seed,K,dup,cfg', [(51, 6, False, SHIPPED_TRACKER), (52, 9, False, SHIPPED_TRACKER),
                                            (53, 6, True, SHIPPED_TRACKER), (54, 12, True, SHIPPED_TRACKER),
-                                           (55, 8, False, VARIANT), (56, 10, True, VARIANT)])
-def test_product_tracker_reproduces_the_oracle_frame_by_frame(seed, K, dup, cfg):
-    """Same detection stream through the oracle classes and the product tracker: ids, boxes, scores, depth and
-    scales of every returned track are EQUAL in every frame; so are the Kalman states of the tracks alive at the
-    end (same float64 arithmetic in the same order)."""
+                                           (55, 8, False, VARIANT), (56, 10, True, VARIANT),
+                                           (57, 40, True, SHIPPED_TRACKER), (58, 25, False, VARIANT)])
+def test_product_tracker_reproduces_the_oracle_frame_by_frame(seed, K, dup, cfg, backend):
+    """Same detection stream through the oracle classes and the product tracker (native C++ routine and the pure
+    Python restatement): ids, boxes, scores, depth and scales of every returned track are EQUAL in every frame.  The
+    Kalman states of the tracks alive at the end are bit-equal for the Python backend (same numpy / scipy calls) and
+    equal to 1e-9 for the native one (plain loops instead of BLAS / LAPACK: last-bit differences, see the header of
+    csrc/ocsort_tracker.cpp)."""
     T = 48
     det = detection_stream(seed, T, K, occlusion=(K // 2, 15, 23), duplicates=dup)
     ref = run_oracle_tracker(det, T, **cfg)
-    got, trk = run_product_tracker(det, T, with_state=True, **cfg)
+    got, trk = run_product_tracker(det, T, with_state=True, backend=backend, **cfg)
     assert len(ref) > T and len(set(ref[:, 1].astype(int))) >= K
     for t in range(T):
         a, b = got[got[:, 0] == t], ref[ref[:, 0] == t]
         assert a[:, 1].astype(int).tolist() == b[:, 1].astype(int).tolist(), f'frame {t}: track ids differ'
         assert np.array_equal(a, b), f'frame {t}: boxes / scores / depth / scales differ'
     otrk = run_oracle_with_state(det, T, **cfg)
-    assert sorted(trk.tracks) == sorted(otrk.tracks) and int(trk.num_tracks) == int(otrk.num_tracks)
-    for tid, tr in trk.tracks.items():
-        o = otrk.tracks[tid]
-        assert np.array_equal(np.asarray(tr.mean, np.float64), np.asarray(o.mean, np.float64)), tid
-        assert np.array_equal(tr.covariance, o.covariance), tid
-        assert bool(tr.tentative) == bool(o.tentative) and bool(tr.tracked) == bool(o.tracked)
+    assert int(trk.num_tracks) == int(otrk.num_tracks)
+    if backend == 'python':
+        assert sorted(trk.tracks) == sorted(otrk.tracks)
+        for tid, tr in trk.tracks.items():
+            o = otrk.tracks[tid]
+            assert np.array_equal(np.asarray(tr.mean, np.float64), np.asarray(o.mean, np.float64)), tid
+            assert np.array_equal(tr.covariance, o.covariance), tid
+            assert bool(tr.tentative) == bool(o.tentative) and bool(tr.tracked) == bool(o.tracked)
+    else:
+        state = trk.native_state()
+        assert [t['id'] for t in state] == list(otrk.tracks)          # same tracks alive, same creation order
+        for t in state:
+            o = otrk.tracks[t['id']]
+            assert np.allclose(t['mean'], np.asarray(o.mean, np.float64), rtol=1e-9, atol=1e-9), t['id']
+            assert np.allclose(t['covariance'], o.covariance, rtol=1e-9, atol=1e-12), t['id']
+            assert t['tentative'] == bool(o.tentative) and t['tracked'] == bool(o.tracked)
+            assert t['last_frame'] == int(o.frame_ids[-1])
 
 
 def test_tracker_golden_sequence():
@@ -169,8 +184,9 @@ def test_tracker_golden_sequence():
     det, ref, T = g['detections'], g['tracks'], int(g['num_frames'])
     assert np.array_equal(det, detection_stream(51, T))               # the committed stream is the seeded one
     assert np.array_equal(ref, run_oracle_tracker(det, T, **SHIPPED_TRACKER))   # and the oracle reproduces its fixture
-    got = run_product_tracker(det, T, **SHIPPED_TRACKER)
-    assert got.shape == ref.shape and np.array_equal(got, ref)
+    for backend in ('native', 'python'):
+        got = run_product_tracker(det, T, backend=backend, **SHIPPED_TRACKER)
+        assert got.shape == ref.shape and np.array_equal(got, ref), backend
     ids = lambda t: set(ref[ref[:, 0] == t][:, 1].astype(int).tolist())   # noqa: E731
     assert len(ids(28)) == 6 and ids(28) == ids(63)
 
@@ -183,8 +199,8 @@ def test_empty_and_first_frame_semantics():
                     [2, 12, 10, 42, 40, 0.9, 10, 1], [2, 300, 300, 330, 330, 0.35, 10, 1],
                     [2, 500, 300, 505, 305, 0.99, 10, 1]], np.float32)   # last box: area 25 < 100 => dropped
     ref = run_oracle_tracker(det, 3, **SHIPPED_TRACKER)
-    got = run_product_tracker(det, 3, **SHIPPED_TRACKER)
-    assert np.array_equal(got, ref)
+    for backend in ('native', 'python'):
+        assert np.array_equal(run_product_tracker(det, 3, backend=backend, **SHIPPED_TRACKER), ref), backend
     assert ref[ref[:, 0] == 0][:, 1].tolist() == [0.0]                  # only the 0.9 box starts a track
     assert len(ref[ref[:, 0] == 1]) == 0
     assert sorted(ref[ref[:, 0] == 2][:, 1].tolist()) == [0.0, 1.0]     # re-found + a new track at score 0.35

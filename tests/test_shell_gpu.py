@@ -136,14 +136,19 @@ def oracle_frame(ora, img, disp, ori_hw, score_thr=0.01, iou_thr=0.5):
 
 
 def test_mot_shell_matches_oracle_composition(cuda):
-    from stereotracking_amd.structures import InstanceData, TrackDataSample
-    from stereotracking_amd.trackers import OCSORTTracker_Disparity
+    """model.test_step (config-built plugin surface, batched dense path underneath) frame by frame against the ORACLE
+    composition: oracle detector + C decode/NMS + numpy extract_depth feeding the ORACLE tracker (oracle/tracker.py)."""
+    from oracle import tracker as otr
+    from stereotracking_amd.structures import TrackDataSample
     model, sd, cfg = build_model(CFG, cuda)
     ora = OracleDetector(0.33, 0.375, 1).eval()
     ora.load_state_dict(sd, strict=False)
     ori = (80, 160)
     frames = [synthetic_batch([40 + (t // 2)], ori[0], ori[1], 32) for t in range(6)]  # pairs of identical frames
-    ref_trk = OCSORTTracker_Disparity(**{k: v for k, v in cfg.model.tracker.items() if k != 'type'})
+    ref_trk = otr.OCSORTTracker_Disparity(**{k: v for k, v in cfg.model.tracker.items() if k != 'type'})
+
+    class _OracleModel:
+        motion = otr.KalmanFilter()
     n_tracked = 0
     for t, fr in enumerate(frames):
         sample = TrackDataSample(dict(frame_id=t, ori_shape=ori, img_shape=ori, scale_factor=(1.0, 1.0)))
@@ -163,14 +168,13 @@ def test_mot_shell_matches_oracle_composition(cuda):
         assert (det.bboxes.cpu() - boxes).abs().max() <= 1e-3 * 160
         assert (det.scores.cpu() - scores).abs().max() <= 1e-3
         # tracker fed with the ORACLE detections must produce the same ids / boxes as the HIP shell
-        s2 = TrackDataSample(dict(frame_id=t))
-        s2.pred_det_instances = InstanceData(bboxes=sboxes, scores=scores, labels=torch.zeros(len(boxes), dtype=torch.long),
-                                             scales=scales, depth=depth)
-        ref = ref_trk.track(model, None, None, s2)
+        s2 = otr.Sample(t, otr.Instances(bboxes=sboxes, scores=scores, labels=torch.zeros(len(boxes), dtype=torch.long),
+                                         scales=scales, depth=depth))
+        ref = ref_trk.track(_OracleModel(), None, None, s2)
         trk = out.pred_track_instances
         assert trk.instances_id.cpu().tolist() == ref.instances_id.tolist()
-        n_tracked += len(ref)
-        if len(ref):
+        n_tracked += len(ref.instances_id)
+        if len(ref.instances_id):
             from stereotracking_amd.mot import scale_bbox
             unscaled = scale_bbox(ref.bboxes, 1 / ref.scales)
             assert (trk.bboxes.cpu() - unscaled).abs().max() <= 1e-3 * 160
