@@ -184,7 +184,44 @@ def conv_roofline(pipe, img, right, steps):
                                         bytes_per_launch=int(cv_bytes), avg_launch_us=round(cv_us, 2),
                                         achieved=round(cv_bytes / (cv_us * 1e-6) / 1e9, 1) if cv_us > 0 else None,
                                         frac=round(cv_bytes / (cv_us * 1e-6) / 8e12, 4) if cv_us > 0 else None)
+    roof['secondary_costvolume_fullres'] = costvolume_fullres(lib)
     return roof
+
+
+def costvolume_fullres(lib, reps=5):
+    """SURVEY.md §8(d)'s OTHER cost-volume sizing, as a kernel measurement: the full-resolution materialised volume
+    D=192 x 720 x 1280 (176.9 M cells, 708 MB fp32) from C=8 synthetic feature maps, one pair per launch.  The product
+    pipeline correlates stage-1 features at 1/4 resolution (48 levels, 2.83 M cells); this line only shows what the
+    same kernel family does at the full-resolution sizing.  Algorithmic bytes = both feature maps read once + the
+    volume written once (the soft-argmin then reads it once more: st_softargmin, not timed here)."""
+    import ctypes as C
+    try:
+        Hf, Wf, Cf, D = 720, 1280, 8, 192
+        dev = torch.device('cuda', torch.cuda.current_device())
+        g = torch.Generator(device='cpu').manual_seed(0)
+        fl = torch.randn(1, Hf, Wf, Cf, generator=g).to(dev)
+        fr = torch.randn(1, Hf, Wf, Cf, generator=g).to(dev)
+        vol = torch.empty(1, Hf, Wf, D, device=dev)
+        stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ms = []
+        for _ in range(reps + 1):
+            e0.record()
+            rc = lib.st_costvolume_softargmin(C.c_void_p(fl.data_ptr()), C.c_void_p(fr.data_ptr()), 1, Hf, Wf, Cf, Cf, D,
+                                              1.0, C.c_void_p(vol.data_ptr()), None, stream)
+            e1.record()
+            e1.synchronize()
+            if rc != 0:
+                return dict(error=lib.st_last_error().decode())
+            ms.append(e0.elapsed_time(e1))
+        us = sorted(ms[1:])[len(ms[1:]) // 2] * 1e3
+        nbytes = 4.0 * Hf * Wf * (2 * Cf + D)
+        return dict(bound='hbm', kernel='st::costvolume_kernel', unit='GB/s', peak=8000.0, cells=Hf * Wf * D,
+                    bytes_per_launch=int(nbytes), launch_us=round(us, 1), achieved=round(nbytes / (us * 1e-6) / 1e9, 1),
+                    frac=round(nbytes / (us * 1e-6) / 8e12, 4),
+                    workload='1 pair, full-resolution volume D=192 x 720 x 1280 from C=8 features (kernel only)')
+    except Exception as e:   # a secondary line must never cost the headline
+        return dict(error=repr(e))
 
 
 def cpu_baseline(sd, batch_cpu, max_disp, seconds, agg_layers):
@@ -278,7 +315,7 @@ def test_step_leg(args, sd, batch_cpu, dev, pairs_target):
     for _ in range(2):
         outs = call()
     torch.cuda.synchronize()
-    model.timings.update(frames=0, tracker_s=0.0, host_s=0.0)
+    model.timings.update(frames=0, tracker_s=0.0, host_s=0.0, wait_s=0.0, pre_s=0.0)
     calls = max(2, -(-pairs_target // F))
     t0 = time.perf_counter()
     for _ in range(calls):
@@ -290,6 +327,8 @@ def test_step_leg(args, sd, batch_cpu, dev, pairs_target):
                 ms_per_call=round(dt / calls * 1e3, 3),
                 path='Config.fromfile(stereo_yolox_s_mot_airdrone_costvolume.py) -> MODELS.build -> model.test_step',
                 tracker_ms_per_frame=round(tm['tracker_s'] / max(tm['frames'], 1) * 1e3, 4),
+                host_ms_per_call=dict(preprocessor=round(tm['pre_s'] / calls * 1e3, 3), predict=round(tm['host_s'] / calls * 1e3, 3),
+                                      of_which_waiting_for_gpu=round(tm['wait_s'] / calls * 1e3, 3)),
                 tracks_last_frame=int(len(outs[-1].pred_track_instances)),
                 detections_last_frame=int(len(outs[-1].pred_det_instances)),
                 note='includes the preprocessor (uint8 -> fp32, pad, stack), the dense path on the model\'s in-flight '

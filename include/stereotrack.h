@@ -75,16 +75,24 @@ typedef struct StConvDesc {
   int res_ld, res_off;
   float post_scale;
   int act; /* 0 = identity, 1 = SiLU */
+  /* optional: the same weights in Winograd F(2x2,3x3) form (st_wino_pack_weights of wgt, fragment order); enables
+   * kernel instance 43 for 3x3 / stride-1 layers with Cin % 32 == 0 and Cout % 64 == 0.  NULL = not available. */
+  const float* wgt_wino_dev;
 } StConvDesc;
 
 int st_conv2d_nhwc(const StConvDesc* d, st_stream_t stream);
 /* The same convolution with the kernel instance chosen by the caller instead of the library's heuristic:
  * variant 0..21 = tile instances of the implicit-GEMM kernel (st_conv_variant_name), 41 = streaming 1x1 kernel,
- * 42 = direct 3x3 kernel, -1 = heuristic.  Returns ST_ERR_INVALID when the instance cannot run this layer (tile
+ * 42 = direct 3x3 kernel, 43 = Winograd F(2x2,3x3) kernel (needs wgt_wino_dev), -1 = heuristic.  Returns ST_ERR_INVALID when the instance cannot run this layer (tile
  * does not divide the padded Cout, ...), so callers can autotune per layer by timing the valid ones — which is
  * what st_detector_autotune does internally and StereoCostVolume.autotune does for the aggregation convs.
  * Results are the same convolution for every valid variant (fp32 rounding differs with the summation order). */
 int st_conv2d_nhwc_variant(const StConvDesc* d, st_stream_t stream, int variant);
+/* Winograd form of a 3x3 weight tensor.  packed_wgt_host: the [CoutPad][Kpad] matrix st_conv_pack_weights produced
+ * (host memory); out_host: st_wino_packed_floats(Cout, Cin) floats, to be uploaded and passed as wgt_wino_dev.
+ * U = G g G^T is evaluated in fp64 on the folded fp32 weights and rounded once. */
+size_t st_wino_packed_floats(int Cout, int Cin);
+int st_wino_pack_weights(const float* packed_wgt_host, int Cout, int Cin, float* out_host);
 
 /* Pack one Conv2d weight [Cout][Cin][KH][KW] (+ optional BN, folded in fp64)
  * into the kernel layout above.  Host function; out buffers are host memory

@@ -32,7 +32,7 @@ class StConvDesc(C.Structure):
         ('out2_dev', C.c_void_p), ('out2_ld', C.c_int), ('out2_off', C.c_int),
         ('up_dev', C.c_void_p), ('up_ld', C.c_int), ('up_off', C.c_int),
         ('res_dev', C.c_void_p), ('res_ld', C.c_int), ('res_off', C.c_int),
-        ('post_scale', C.c_float), ('act', C.c_int),
+        ('post_scale', C.c_float), ('act', C.c_int), ('wgt_wino_dev', C.c_void_p),
     ]
 
 
@@ -71,6 +71,8 @@ _PROTOS = {
     'st_conv2d_nhwc_variant': (_i, [C.POINTER(StConvDesc), _vp, _i]),
     'st_conv1x1_chain': (_i, [C.POINTER(StConvDesc), C.POINTER(StConvDesc), _vp]),
     'st_conv_packed_floats': (_sz, [_i, _i, _i, _i]),
+    'st_wino_packed_floats': (_sz, [_i, _i]),
+    'st_wino_pack_weights': (_i, [_vp, _i, _i, _vp]),
     'st_conv_pack_weights': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, C.c_double, _i, _i, _i, _i, _vp, _vp]),
     'st_focus_pack': (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
     'st_stem_packed_floats': (_sz, [_i]),

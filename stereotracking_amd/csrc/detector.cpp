@@ -34,6 +34,9 @@ int conv2d_launch(const StConvDesc& d, hipStream_t stream, int force_variant, in
 bool pw_conv_applicable(const StConvDesc& d);
 bool pw_chain_applicable(const StConvDesc& d, const StConvDesc& c);
 bool dc_conv_applicable(const StConvDesc& d);
+bool wino_conv_applicable(const StConvDesc& d);
+size_t wino_packed_floats(int Cout, int Cin);
+int wino_pack_weights(const float* packed, int Cout, int Cin, float* out);
 int pw_conv_launch(const StConvDesc& d, hipStream_t stream, const StConvDesc* chain);
 int conv_variant_count();
 bool conv_variant_valid(int id, int cout);
@@ -80,6 +83,8 @@ struct PackedConv {
   std::vector<ConvSrc> srcs;
   int cin = 0, k = 1, cout = 0;
   size_t wgt_off = 0, bias_off = 0;  // float offsets inside the packed weight arena
+  size_t wino_off = 0;               // Winograd-form copy of the weights (3x3 / stride-1 users only), 0 = none
+  bool wino = false;
   bool stem = false;                 // fused Focus+stem layout (st_stem_pack_weights), cin = 12, k = 3
   int stem_planes = 3;               // image planes the fused stem reads (1: identical planes, summed weights)
 };
@@ -152,6 +157,7 @@ struct StDetector {
   bool timing = false;
   std::vector<hipEvent_t> events;  // 2 per op
   int force_variant = -1;          // autotune only
+  bool no_wino = false;            // keep the autotuner off the Winograd instance (exact-MFMA-order A/B runs)
   bool allow_chain = true;         // fuse CSP main_conv -> bottleneck conv1 when both run on the streaming kernel
 #ifdef ST_ABLATION
   std::vector<char> skip;          // tools-only: ops whose launches are dropped (st_detector_set_skip)
@@ -248,6 +254,10 @@ struct StDetector {
     const int Wo = (in.W + 2 * o.pad - convs[pc].k) / stride + 1;
     o.macs = (double)in.N * groups[cur_group].count * Ho * Wo * convs[pc].k * convs[pc].k * convs[pc].cin *
              convs[pc].cout;
+    // wide 3x3 / stride-1 layers also get their weights in Winograd form (kernel instance 43, picked by the autotuner)
+    if (convs[pc].k == 3 && stride == 1 && convs[pc].cin % 32 == 0 && convs[pc].cout % 64 == 0 && o.split == convs[pc].cout &&
+        !up.valid())
+      convs[pc].wino = true;
     macs += o.macs;
     ops.push_back(o);
   }
@@ -472,6 +482,11 @@ int StDetector::build() {
     pc.bias_off = wgt_floats;
     wgt_floats += round_up(pc.cout, 32);
     wgt_floats = (wgt_floats + 63) & ~(size_t)63;
+    if (pc.wino) {
+      pc.wino_off = wgt_floats;
+      wgt_floats += wino_packed_floats(pc.cout, pc.cin);
+      wgt_floats = (wgt_floats + 63) & ~(size_t)63;
+    }
   }
   return ST_OK;
 }
@@ -559,6 +574,7 @@ extern "C" int st_detector_finalize(StDetector* det) {
       std::memcpy(host.data() + pc.bias_off + row, btmp.data(), sizeof(float) * (size_t)s.cout);
       row += s.cout;
     }
+    if (pc.wino) ST_CHECK(wino_pack_weights(host.data() + pc.wgt_off, pc.cout, pc.cin, host.data() + pc.wino_off));
   }
   if (!det->wgt_dev) ST_CHECK_HIP(hipMalloc(reinterpret_cast<void**>(&det->wgt_dev), det->wgt_floats * sizeof(float)));
   ST_CHECK_HIP(hipMemcpy(det->wgt_dev, host.data(), det->wgt_floats * sizeof(float), hipMemcpyHostToDevice));
@@ -605,6 +621,7 @@ StConvDesc conv_desc(const StDetector* det, const Op& o, int img0, float* ws, fl
   d.up_dev = resolve(det, o.up, ws, head, img0); d.up_ld = o.up.ld; d.up_off = o.up.off;
   d.res_dev = resolve(det, o.res, ws, head, img0); d.res_ld = o.res.ld; d.res_off = o.res.off;
   d.post_scale = o.post_scale; d.act = o.act;
+  d.wgt_wino_dev = pc.wino ? det->wgt_dev + pc.wino_off : nullptr;
   return d;
 }
 
@@ -831,10 +848,13 @@ extern "C" int st_detector_autotune(StDetector* det, void* workspace_dev, size_t
     probe.out1_off = so.out1.off; probe.res_off = so.res.off;
     const bool pw_ok = pw_conv_applicable(probe);
     const bool dc_ok = dc_conv_applicable(probe);   // + variant 42, the direct 3x3 kernel (direct_conv.hip)
+    probe.wgt_wino_dev = det->convs[so.pc].wino ? det->wgt_dev + det->convs[so.pc].wino_off : nullptr;
+    const bool wn_ok = !det->no_wino && wino_conv_applicable(probe);   // + variant 43, Winograd F(2x2,3x3) (wino_conv.hip)
     const int ncand = std::min(conv_variant_count(), 22);
-    for (int vi = 0; vi <= ncand + 1 && rc == ST_OK; ++vi) {
-      const int v = vi < ncand ? vi : vi == ncand ? 41 : 42;
-      if (v == 41 ? !pw_ok : v == 42 ? !dc_ok : !conv_variant_valid(v, det->convs[saved[oi].pc].cout)) continue;
+    for (int vi = 0; vi <= ncand + 2 && rc == ST_OK; ++vi) {
+      const int v = vi < ncand ? vi : vi == ncand ? 41 : vi == ncand + 1 ? 42 : 43;
+      if (v == 41 ? !pw_ok : v == 42 ? !dc_ok : v == 43 ? !wn_ok : !conv_variant_valid(v, det->convs[saved[oi].pc].cout))
+        continue;
       det->force_variant = v;
       rc = run_ops(det, 0, 0, inputs, static_cast<float*>(workspace_dev), head_out_dev, stream);  // warm
       if (rc != ST_OK) break;
@@ -868,10 +888,10 @@ extern "C" int st_detector_autotune(StDetector* det, void* workspace_dev, size_t
 // id 40 = the fused Focus+stem kernel (stem_focus_conv.hip), reported with the conv ops
 // id 41 = the streaming 1x1 kernel for narrow layers (pointwise_conv.hip)
 extern "C" const char* st_conv_variant_name(int id) {
-  return id == 40 ? "stem6x6s2" : id == 41 ? "pw128" : id == 42 ? "dc4x32" : conv_variant_name(id);
+  return id == 40 ? "stem6x6s2" : id == 41 ? "pw128" : id == 42 ? "dc4x32" : id == 43 ? "wino2x2" : conv_variant_name(id);
 }
 extern "C" const char* st_conv_variant_signature(int id) {
-  return id == 40 ? "stem_focus_conv" : id == 41 ? "pw_conv" : id == 42 ? "direct_conv3x3"
+  return id == 40 ? "stem_focus_conv" : id == 41 ? "pw_conv" : id == 42 ? "direct_conv3x3" : id == 43 ? "wino_conv3x3"
                                                               : conv_variant_signature(id);
 }
 
@@ -890,7 +910,7 @@ extern "C" int st_detector_set_tuning(StDetector* det, const int* variants, int 
   for (int i = 0; i < n; ++i) {
     const Op& o = det->ops[i];
     if (variants[i] < 0 || o.type != Op::CONV) continue;
-    if (variants[i] == 41 || variants[i] == 42) continue;   // own applicability checks run at launch
+    if (variants[i] >= 41 && variants[i] <= 43) continue;   // own applicability checks run at launch
     ST_REQUIRE(conv_variant_valid(variants[i], det->convs[o.pc].cout), "st_detector_set_tuning: variant %d invalid for op %d",
                variants[i], i);
   }

@@ -1,0 +1,315 @@
+// Winograd F(2x2, 3x3) convolution on the fp32 matrix cores of gfx950, NHWC, tile variant 43.
+//
+// The 3x3 / stride-1 ConvModules with >= 64 channels (YOLOX head towers, CSP bottleneck conv2 layers, PAFPN blocks:
+// mmdet CSPLayer / mmyolo YOLOXHeadModule as built at reference
+// mmtrack/models/backbones/csp_darknet_disparity_v1.py:145-153 and configs/_base_/yolox_s_8x8_mmyolo.py:38-51) carry
+// 56 % of the multiply-adds of the path.  v_mfma_f32_32x32x2_f32 runs at the fp32 VECTOR rate (157 TFLOP/s), so the
+// only way past that roof is to need fewer multiplies:   Y = A^T [ (G g G^T) .* (B^T d B) ] A   computes a 2x2 output
+// tile from a 4x4 input patch with 16 multiplies per (cin, cout) instead of 36 - 2.25x fewer MFMA instructions for
+// the same convolution (fp32 throughout; the transforms only add / subtract / halve, error ~1e-6 relative, inside
+// the 1e-3 float tolerance of the path and checked against torch conv2d in tests/test_conv_gpu.py).
+//
+// Mapping.  16 independent GEMMs, one per transform coordinate xi = (a, b):  M_xi[tile][co] = sum_ci V_xi[tile][ci] *
+// U_xi[co][ci].  A workgroup = 4 waves = the 4 rows `a` of the transform; it owns 32 tiles (8 x 4 tiles = 16 x 8 output
+// pixels) x 64 couts, i.e. per wave 4 (b) x 2 (cout blocks of 32) accumulator tiles of 32x32.
+//   * raw input window (18 x 10 pixels x 32 cin per K-chunk, 23 KB) -> LDS by LDS-DMA with hardware zero fill (= the
+//     conv padding and the ragged edge), double buffered, source-side XOR swizzle (2-way conflicts at most);
+//   * the input transform never touches memory: a lane (tile, 4 channels) reads its 2 x 4 patch pixels with 8
+//     ds_read_b128, forms its wave's row of B^T d (4 adds) and the 4 values V[a][0..3] (4 adds) in registers - those ARE
+//     the A operands of the next 4 x 2 x 4 MFMAs;
+//   * the transformed weights are pre-packed on the host in FRAGMENT ORDER, so every B operand is one fully coalesced
+//     1 KB wave load straight from L2 into VGPRs (1 MB per layer, shared by every workgroup), prefetched one step ahead;
+//   * output transform: each wave reduces its own row over b in registers (M -> 2 values), the 4 rows meet through
+//     LDS (64 KB, reusing the window buffers), then bias + SiLU (+ residual) and coalesced NHWC stores.
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <vector>
+
+#include "st_common.h"
+
+namespace st {
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int WN_TX = 8, WN_TY = 4;                        // tiles per workgroup (x, y): 32 = one MFMA row block
+constexpr int WN_WW = 2 * WN_TX + 2, WN_WH = 2 * WN_TY + 2;   // input window: 18 x 10 pixels
+constexpr int WN_PIX = WN_WW * WN_WH;                      // 180
+constexpr int WN_PIECES = (WN_PIX + 7) / 8;                // LDS-DMA pieces of 8 pixels x 128 B = 1 KB
+constexpr int WN_WIN_FLOATS = WN_PIECES * 8 * 32;          // one window buffer (32 cin per pixel)
+constexpr int WN_CB = 64;                                  // couts per workgroup
+constexpr int WN_R_FLOATS = 4 * 2 * 32 * WN_CB;            // output-transform exchange: [a][j][tile][co]
+constexpr int WN_LDS_FLOATS = WN_R_FLOATS > 2 * WN_WIN_FLOATS ? WN_R_FLOATS : 2 * WN_WIN_FLOATS;
+constexpr int WN_FRAG_FLOATS = 2 * 64 * 4;                 // one (kc, g, b) step: 2 cout blocks x 64 lanes x 4
+
+struct WinoArgs {
+  const float* in;
+  const float* wino;
+  const float* bias;
+  float* out;
+  const float* res;
+  int N, H, W, in_ld, in_off, Cout;
+  int out_ld, out_off, res_ld, res_off;
+  float post_scale;
+  int act;
+  int tbx, tby, ncb, nkc;
+  unsigned in_bytes, out_bytes, res_bytes, wino_bytes;
+};
+
+__device__ __forceinline__ float wn_silu(float v) { return v * __builtin_amdgcn_rcpf(1.0f + __expf(-v)); }
+
+template <bool RES>
+__global__ __launch_bounds__(256, 2) void wino_conv3x3_kernel(const WinoArgs p) {
+  extern __shared__ float4 wn_smem4[];
+  float* smem = reinterpret_cast<float*>(wn_smem4);
+  const int tid = threadIdx.x, lane = tid & 63, a = tid >> 6;   // wave = transform row a
+  const int i = lane & 31, h = lane >> 5;
+  const int tyi = i >> 3, txi = i & 7;
+  int b_ = blockIdx.x;
+  const int cb = b_ % p.ncb; b_ /= p.ncb;
+  const int bx = b_ % p.tbx; b_ /= p.tbx;
+  const int by = b_ % p.tby;
+  const int n = b_ / p.tby;
+  const int wy0 = by * (2 * WN_TY) - 1, wx0 = bx * (2 * WN_TX) - 1;   // window origin (conv padding = 1)
+
+#if defined(__HIP_DEVICE_COMPILE__)  // device-only builtins; the host pass only needs the kernel stub
+  const __amdgpu_buffer_rsrc_t irsrc =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in), 0, (int)p.in_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t wrsrc =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.wino), 0, (int)p.wino_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, (int)p.out_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rrsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(RES ? p.res : p.in), 0, (int)(RES ? p.res_bytes : 0u), 0x00020000);
+
+  // ---- window DMA: piece j = LDS pixel slots 8j .. 8j+7; lane (pixel slot q, 16-B slot sl) fetches channel quad
+  // sl ^ ((q >> 1) & 7) of window pixel q (zero outside the image / past the window)
+  constexpr int NPW = (WN_PIECES + 3) / 4;   // pieces per wave
+  unsigned poff[NPW];
+#pragma unroll
+  for (int k = 0; k < NPW; ++k) {
+    const int j = a + 4 * k;
+    const int q = 8 * j + (lane >> 3), sl = lane & 7;
+    const int wr = q / WN_WW, wc = q - wr * WN_WW;
+    const int y = wy0 + wr, x = wx0 + wc;
+    const bool ok = j < WN_PIECES && q < WN_PIX && y >= 0 && y < p.H && x >= 0 && x < p.W;
+    const int quad = sl ^ ((q >> 1) & 7);
+    poff[k] = ok ? (unsigned)((((n * p.H + y) * p.W + x) * p.in_ld + p.in_off + 4 * quad) * 4) : 0x80000000u;
+  }
+  auto dma_window = [&](int kc, int buf) {
+#pragma unroll
+    for (int k = 0; k < NPW; ++k) {
+      const int j = a + 4 * k;
+      if (j < WN_PIECES)   // wave-uniform
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(
+            irsrc, (__attribute__((address_space(3))) void*)(smem + buf * WN_WIN_FLOATS + j * 256), 16, poff[k],
+            kc * 128, 0, 0);
+    }
+  };
+
+  // ---- this lane's 2 x 4 patch pixels: rows (r0, r1) of wave a's row of B^T, combined as d[r0] + sgn * d[r1]
+  //   a = 0: d0 - d2    a = 1: d1 + d2    a = 2: d2 - d1    a = 3: d1 - d3
+  const int r0 = a == 0 ? 0 : (a == 2 ? 2 : 1);
+  const int r1 = a == 0 ? 2 : (a == 1 ? 2 : (a == 2 ? 1 : 3));
+  const float sgn = a == 1 ? 1.0f : -1.0f;
+  int qoff[8], qsw[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const int r = k < 4 ? r0 : r1, c = k & 3;
+    const int q = (2 * tyi + r) * WN_WW + 2 * txi + c;
+    qoff[k] = q * 32;
+    qsw[k] = (q >> 1) & 7;
+  }
+
+  // ---- transformed-weight stream of this wave: [cb][a][kc][g][b][nb][lane][4], one step = WN_FRAG_FLOATS
+  const unsigned wbase = (unsigned)((((cb * 4 + a) * p.nkc) * 16) * WN_FRAG_FLOATS + lane * 4) * 4u;
+  auto load_frag = [&](int step, f32x4 (&f)[2]) {   // step = (kc * 4 + g) * 4 + b ; past the end: zeros
+    const unsigned off = wbase + (unsigned)step * (WN_FRAG_FLOATS * 4u);
+    f[0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, off, 0, 0));
+    f[1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, off + 1024u, 0, 0));
+  };
+
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int b = 0; b < 4; ++b)
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[b][nb][r] = 0.f;
+
+  dma_window(0, 0);
+  f32x4 fe[2], fo[2];   // weight fragments of the even / odd steps (16 steps per chunk: static assignment)
+  load_frag(0, fe);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  for (int kc = 0; kc < p.nkc; ++kc) {
+    const int buf = kc & 1;
+    if (kc + 1 < p.nkc) dma_window(kc + 1, buf ^ 1);   // lands during this chunk's 128 MFMAs
+    const float* win = smem + buf * WN_WIN_FLOATS;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      // raw patch -> V[a][0..3] for this lane's 4 channels (8g + 4h .. + 3)
+      f32x4 d[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k)
+        d[k] = *reinterpret_cast<const f32x4*>(win + qoff[k] + (((2 * g + h) ^ qsw[k]) << 2));
+      f32x4 P[4], V[4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) P[c] = d[c] + sgn * d[4 + c];
+      V[0] = P[0] - P[2];
+      V[1] = P[1] + P[2];
+      V[2] = P[2] - P[1];
+      V[3] = P[1] - P[3];
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        const int step = (kc * 4 + g) * 4 + b;
+        if (b & 1) load_frag(step + 1, fe); else load_frag(step + 1, fo);   // next step's weights (L2, 1 KB each)
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+          for (int nb = 0; nb < 2; ++nb)
+            acc[b][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[b][s], (b & 1) ? fo[nb][s] : fe[nb][s], acc[b][nb],
+                                                              0, 0, 0);
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMA of chunk kc + 1 (and the prefetch) landed
+    __syncthreads();
+  }
+
+  // ---- output transform.  Row reduction over b in registers: R[0] = M0 + M1 + M2, R[1] = M1 - M2 - M3
+  float* Rb = smem;   // [a][j][tile][co]: every wave is past its last window read (barrier above)
+#pragma unroll
+  for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m = (r & 3) + 8 * (r >> 2) + 4 * h;
+      const float R0 = (acc[0][nb][r] + acc[1][nb][r]) + acc[2][nb][r];
+      const float R1 = (acc[1][nb][r] - acc[2][nb][r]) - acc[3][nb][r];
+      Rb[((a * 2 + 0) * 32 + m) * WN_CB + nb * 32 + i] = R0;
+      Rb[((a * 2 + 1) * 32 + m) * WN_CB + nb * 32 + i] = R1;
+    }
+  __syncthreads();
+  // column reduction over a + epilogue: wave w takes tiles 8w .. 8w+7 (= tile row w), lane = cout
+  const int co = cb * WN_CB + lane;
+  const float bias = p.bias[co];
+#pragma unroll
+  for (int t8 = 0; t8 < 8; ++t8) {
+    const int t = a * 8 + t8;   // tile (tyi = a, txi = t8)
+    const int oy0 = by * (2 * WN_TY) + 2 * a, ox0 = bx * (2 * WN_TX) + 2 * t8;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const float q0 = Rb[((0 * 2 + j) * 32 + t) * WN_CB + lane], q1 = Rb[((1 * 2 + j) * 32 + t) * WN_CB + lane];
+      const float q2 = Rb[((2 * 2 + j) * 32 + t) * WN_CB + lane], q3 = Rb[((3 * 2 + j) * 32 + t) * WN_CB + lane];
+      const float y[2] = {(q0 + q1) + q2, (q1 - q2) - q3};
+#pragma unroll
+      for (int ii = 0; ii < 2; ++ii) {
+        const int oy = oy0 + ii, ox = ox0 + j;
+        const bool ok = oy < p.H && ox < p.W && co < p.Cout;
+        const int m = (n * p.H + oy) * p.W + ox;
+        float v = y[ii] + bias;
+        if (p.act) v = wn_silu(v);
+        if (RES) {
+          const unsigned roff = ok ? (unsigned)((m * p.res_ld + p.res_off + co) * 4) : 0x80000000u;
+          v = (v + __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rrsrc, roff, 0, 0))) * p.post_scale;
+        }
+        const unsigned off = ok ? (unsigned)((m * p.out_ld + p.out_off + co) * 4) : 0x80000000u;
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), orsrc, off, 0, 0);
+      }
+    }
+  }
+#else
+  (void)smem; (void)i; (void)h; (void)tyi; (void)txi; (void)cb; (void)n; (void)wy0; (void)wx0;
+#endif
+}
+
+}  // namespace
+
+// floats of the fragment-ordered transformed weights of a Cout x Cin 3x3 conv (Cout padded to 64)
+size_t wino_packed_floats(int Cout, int Cin) { return (size_t)16 * round_up(Cout, WN_CB) * Cin; }
+
+// packed: the direct kernels' folded fp32 weights [CoutPad32][Kpad], K index = (kh*3+kw)*Cin + ci (host memory).
+// out: [cb][a][kc][g][b][nb][lane][4] with lane = (h << 5) | j: U_{a,b}[co = cb*64 + nb*32 + j][ci = kc*32 + 8g + 4h + e],
+// U = G g G^T evaluated in fp64 on the fp32 weights and rounded once.
+int wino_pack_weights(const float* packed, int Cout, int Cin, float* out) {
+  ST_REQUIRE(packed && out && Cout > 0 && Cin > 0 && Cin % 32 == 0, "wino_pack_weights: Cin must be a multiple of 32");
+  const int Kpad = round_up(9 * Cin, 32), ncb = round_up(Cout, WN_CB) / WN_CB, nkc = Cin / 32;
+  static const double G[4][3] = {{1, 0, 0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0, 0, 1}};
+  for (int cb = 0; cb < ncb; ++cb)
+    for (int a = 0; a < 4; ++a)
+      for (int kc = 0; kc < nkc; ++kc)
+        for (int g = 0; g < 4; ++g)
+          for (int b = 0; b < 4; ++b)
+            for (int nb = 0; nb < 2; ++nb)
+              for (int l = 0; l < 64; ++l)
+                for (int e = 0; e < 4; ++e) {
+                  const int j = l & 31, h = l >> 5;
+                  const int co = cb * WN_CB + nb * 32 + j, ci = kc * 32 + 8 * g + 4 * h + e;
+                  double u = 0.0;
+                  if (co < Cout)
+                    for (int kh = 0; kh < 3; ++kh)
+                      for (int kw = 0; kw < 3; ++kw)
+                        u += G[a][kh] * (double)packed[(size_t)co * Kpad + (kh * 3 + kw) * Cin + ci] * G[b][kw];
+                  out[(((((((size_t)cb * 4 + a) * nkc + kc) * 4 + g) * 4 + b) * 2 + nb) * 64 + l) * 4 + e] = (float)u;
+                }
+  return ST_OK;
+}
+
+// Shapes: 3x3 / stride 1 / pad 1, Cin a multiple of 32, Cout a multiple of 64, one output tensor (no split / upsample),
+// transformed weights present, every tensor below 2 GiB.
+bool wino_conv_applicable(const StConvDesc& d) {
+  if (!d.wgt_wino_dev) return false;
+  if (d.KH != 3 || d.KW != 3 || d.stride != 1 || d.pad != 1 || d.up_dev || d.out2_dev) return false;
+  if (d.Cin % 32 != 0 || d.Cout % WN_CB != 0) return false;
+  if ((d.in_ld | d.in_off) & 3) return false;
+  if (reinterpret_cast<uintptr_t>(d.in_dev) & 15) return false;
+  const long long M = (long long)d.N * d.Hi * d.Wi, lim = 1ll << 31;
+  if (M * d.in_ld * 4 >= lim || M * d.out1_ld * 4 >= lim) return false;
+  if (d.res_dev && M * d.res_ld * 4 >= lim) return false;
+  return true;
+}
+
+int wino_conv_launch(const StConvDesc& d, hipStream_t stream) {
+  ST_REQUIRE(wino_conv_applicable(d), "winograd conv: shape not supported (3x3 s1 p1, Cin % 32 == 0, Cout % 64 == 0, "
+                                      "transformed weights required)");
+  ST_REQUIRE(d.in_dev && d.bias_dev && d.out1_dev, "winograd conv: null pointer");
+  ST_REQUIRE(d.in_off + d.Cin <= d.in_ld && d.out1_off + d.Cout <= d.out1_ld, "winograd conv: channel slice exceeds ld");
+  if (d.res_dev) ST_REQUIRE(d.res_off + d.Cout <= d.res_ld, "winograd conv: res slice exceeds res_ld");
+  const long long M = (long long)d.N * d.Hi * d.Wi;
+  WinoArgs a;
+  a.in = d.in_dev; a.wino = d.wgt_wino_dev; a.bias = d.bias_dev; a.out = d.out1_dev; a.res = d.res_dev;
+  a.N = d.N; a.H = d.Hi; a.W = d.Wi; a.in_ld = d.in_ld; a.in_off = d.in_off; a.Cout = d.Cout;
+  a.out_ld = d.out1_ld; a.out_off = d.out1_off; a.res_ld = d.res_ld; a.res_off = d.res_off;
+  a.post_scale = d.res_dev ? d.post_scale : 1.0f;
+  a.act = d.act;
+  a.tbx = ceil_div(d.Wi, 2 * WN_TX); a.tby = ceil_div(d.Hi, 2 * WN_TY);
+  a.ncb = d.Cout / WN_CB; a.nkc = d.Cin / 32;
+  a.in_bytes = (unsigned)(M * d.in_ld * 4);
+  a.out_bytes = (unsigned)(M * d.out1_ld * 4);
+  a.res_bytes = d.res_dev ? (unsigned)(M * d.res_ld * 4) : 0u;
+  a.wino_bytes = (unsigned)(wino_packed_floats(d.Cout, d.Cin) * 4);
+  const long long blocks = (long long)d.N * a.tbx * a.tby * a.ncb;
+  ST_REQUIRE(blocks < (1ll << 31), "winograd conv: grid too large");
+  constexpr int lds = WN_LDS_FLOATS * (int)sizeof(float);
+  if (d.res_dev) {
+    static int lds_set = 0;
+    ST_ENSURE_DYNAMIC_LDS(wino_conv3x3_kernel<true>, lds, lds_set);
+    hipLaunchKernelGGL(wino_conv3x3_kernel<true>, dim3((unsigned)blocks), dim3(256), lds, stream, a);
+  } else {
+    static int lds_set = 0;
+    ST_ENSURE_DYNAMIC_LDS(wino_conv3x3_kernel<false>, lds, lds_set);
+    hipLaunchKernelGGL(wino_conv3x3_kernel<false>, dim3((unsigned)blocks), dim3(256), lds, stream, a);
+  }
+  ST_CHECK_HIP(hipGetLastError());
+  return ST_OK;
+}
+
+}  // namespace st
+
+extern "C" size_t st_wino_packed_floats(int Cout, int Cin) { return st::wino_packed_floats(Cout, Cin); }
+
+extern "C" int st_wino_pack_weights(const float* packed_wgt_host, int Cout, int Cin, float* out_host) {
+  return st::wino_pack_weights(packed_wgt_host, Cout, Cin, out_host);
+}

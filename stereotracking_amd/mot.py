@@ -72,13 +72,29 @@ class TrackDataPreprocessor_Disparity_V1(nn.Module):
         out = {}
         for key, imgs in inputs.items():
             imgs = [im.to(dev, non_blocking=self.non_blocking) for im in imgs]
-            if self.channel_conversion and imgs[0].size(1) == 3:
-                imgs = [im[:, [2, 1, 0], ...] for im in imgs]
-            imgs = [im.float() for im in imgs]
-            if self._enable_normalize:
-                imgs = [(im - self.mean) / self.std for im in imgs]
             pad_shapes = [tuple(im.shape[-2:]) for im in imgs]
-            out[key] = stack_batch(imgs, self.pad_size_divisor, self.pad_value)
+            plain = not (self.channel_conversion and imgs[0].size(1) == 3) and not self._enable_normalize
+            if plain and len({tuple(im.shape[:2]) for im in imgs}) == 1:
+                # cast + pad + stack as ONE pass per frame: the (N,T,C,H,W) fp32 result is allocated once, filled with
+                # the pad value, and every frame is converted straight into its slot (same values as
+                # .float() -> F.pad -> torch.stack, reference utils/misc.py:13-64, without two extra full-size passes)
+                d = self.pad_size_divisor
+                H = max(s[0] for s in pad_shapes)
+                W = max(s[1] for s in pad_shapes)
+                if d > 1:
+                    H, W = (H + d - 1) // d * d, (W + d - 1) // d * d
+                T, Cc = imgs[0].shape[:2]
+                batch = torch.full((len(imgs), T, Cc, H, W), float(self.pad_value), dtype=torch.float32, device=dev)
+                for i, im in enumerate(imgs):
+                    batch[i, :, :, :im.shape[-2], :im.shape[-1]].copy_(im)
+                out[key] = batch
+            else:
+                if self.channel_conversion and imgs[0].size(1) == 3:
+                    imgs = [im[:, [2, 1, 0], ...] for im in imgs]
+                imgs = [im.float() for im in imgs]
+                if self._enable_normalize:
+                    imgs = [(im - self.mean) / self.std for im in imgs]
+                out[key] = stack_batch(imgs, self.pad_size_divisor, self.pad_value)
             if samples is not None:
                 prefix = key[:-3]  # 'img' -> '', 'ref_img' -> 'ref_'
                 shape = tuple(out[key].shape[-2:])
@@ -154,7 +170,7 @@ class OCSORT_Disparity(nn.Module):
         self.autotune, self.tuning_cache = bool(autotune), tuning_cache
         self.lib = _lib.load()
         self._dense = {}          # (batch, ori_h, ori_w, stereo) -> [InflightPipelines, weights version]
-        self.timings = dict(frames=0, tracker_s=0.0, host_s=0.0)   # cumulative host-side cost of predict()
+        self.timings = dict(frames=0, tracker_s=0.0, host_s=0.0, wait_s=0.0, pre_s=0.0)   # cumulative host-side costs
 
     # ---- reference plumbing (mot/base.py:68-113) -----------------------------------------------------
     def init_weights(self):
@@ -162,7 +178,10 @@ class OCSORT_Disparity(nn.Module):
             self.detector.init_weights()
 
     def test_step(self, data):
+        import time
+        t0 = time.perf_counter()
         data = self.data_preprocessor(data, False)
+        self.timings['pre_s'] += time.perf_counter() - t0
         return self.forward(data['inputs'], data['data_samples'], mode='predict')
 
     def forward(self, inputs, data_samples=None, mode='predict', **kwargs):
@@ -299,7 +318,9 @@ class OCSORT_Disparity(nn.Module):
         outs, pending = [None] * N, []
         for ci in range(len(chunks)):
             job = jobs.pop(ci)
+            tw = time.perf_counter()
             job['ev'].synchronize()                       # the only wait of this chunk's forward pass
+            self.timings['wait_s'] += time.perf_counter() - tw
             rec = job['host']
             s, e = job['s'], job['e']
             tracks_of = []
@@ -346,7 +367,9 @@ class OCSORT_Disparity(nn.Module):
             if nxt < len(chunks):                          # reuse this context (stream order: after the depth launch)
                 jobs[nxt] = submit(nxt)
         for s, e, tracks_of, dh, ev2, _keep in pending:
+            tw = time.perf_counter()
             ev2.synchronize()
+            self.timings['wait_s'] += time.perf_counter() - tw
             for i, tracks in enumerate(tracks_of):
                 k = len(tracks)
                 tracks['depth'] = dh[0, i, :k].clone()

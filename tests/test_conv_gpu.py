@@ -45,6 +45,13 @@ def run_conv(x_nchw, w, bias, stride, pad, act, dev, variant=-1, res=None, post_
     d.in_dev = xin.data_ptr(); d.N, d.Hi, d.Wi, d.Cin, d.in_ld, d.in_off = N, Hi, Wi, Cin, in_ld, in_off
     d.wgt_dev = wp.data_ptr(); d.bias_dev = bp.data_ptr()
     d.Cout, d.KH, d.KW, d.stride, d.pad = Cout, KH, KW, stride, pad
+    wino = None
+    if variant == 43:   # Winograd instance: the same folded weights in transformed, fragment-ordered form
+        wino = torch.empty(lib.st_wino_packed_floats(Cout, Cin), dtype=torch.float32)
+        wp_host = wp.cpu()   # keep alive: ptr() does not hold a reference
+        check(lib.st_wino_pack_weights(ptr(wp_host), Cout, Cin, ptr(wino)), 'st_wino_pack_weights')
+        wino = wino.to(dev)
+        d.wgt_wino_dev = wino.data_ptr()
     s = Cout if split is None else split
     out1 = torch.full((N, Ho, Wo, s + 4), -777.0, device=dev)  # ld = s+4, off = 4
     d.out1_dev = out1.data_ptr(); d.out1_ld, d.out1_off, d.split = s + 4, 4, s
@@ -387,3 +394,42 @@ def test_experimental_variants_are_not_in_the_product_library(stlib, cuda):
     for v in (22, 25, 29, 100, 103, 600):
         assert stlib.st_conv2d_nhwc_variant(C.byref(d), None, v) != 0, v
     assert not hasattr(stlib, 'st_detector_set_skip')
+
+
+@pytest.mark.parametrize('cin,cout,res,act,shape,in_ld,in_off', [
+    (128, 128, False, 1, (2, 23, 41), None, 0),    # head tower at odd sizes: ragged tile blocks in x and y
+    (64, 64, True, 1, (1, 46, 80), None, 0),       # CSP bottleneck conv2 + identity
+    (128, 256, False, 1, (1, 20, 36), 160, 32),    # fused cls|reg first tower conv, input = a channel slice
+    (256, 256, False, 0, (1, 9, 17), None, 0),     # 8 K-chunks, no activation, one partial tile block
+    (32, 64, True, 1, (2, 7, 5), None, 0),         # single K-chunk, image smaller than one tile block
+])
+def test_winograd_conv_matches_direct_convolution(cin, cout, res, act, shape, in_ld, in_off, cuda):
+    """Tile variant 43 (wino_conv.hip): Winograd F(2x2,3x3) evaluates the SAME 3x3 / stride-1 convolution with 2.25x
+    fewer multiplies; against torch conv2d in fp64 (tolerance 1e-4 of the output scale, as for every MFMA variant) and
+    against the implicit-GEMM kernel on the same packed weights."""
+    N, H, W = shape
+    g = torch.Generator().manual_seed(cin * 1000 + cout + H)
+    x = torch.randn(N, cin, H, W, generator=g)
+    w = torch.randn(cout, cin, 3, 3, generator=g) / (3.0 * cin ** 0.5)
+    b = torch.randn(cout, generator=g) * 0.1
+    r = torch.randn(N, cout, H, W, generator=g) if res else None
+    ref = ref_conv(x, w, b, 1, 1, act, r, 0.5 if res else 1.0)
+    got, _ = run_conv(x, w, b, 1, 1, act, cuda, variant=43, res=r, post_scale=0.5 if res else 1.0, in_ld=in_ld,
+                      in_off=in_off)
+    assert_close(got, ref)
+    base, _ = run_conv(x, w, b, 1, 1, act, cuda, variant=3, res=r, post_scale=0.5 if res else 1.0, in_ld=in_ld,
+                       in_off=in_off)
+    assert_close(got, base.double(), tol=2e-5)
+
+
+def test_winograd_instance_needs_its_weights_and_shapes(stlib, cuda):
+    x = torch.randn(1, 8, 8, 64, device=cuda)
+    d = StConvDesc()
+    d.in_dev = x.data_ptr(); d.N, d.Hi, d.Wi, d.Cin, d.in_ld, d.in_off = 1, 8, 8, 64, 64, 0
+    d.wgt_dev = x.data_ptr(); d.bias_dev = x.data_ptr()
+    d.Cout, d.KH, d.KW, d.stride, d.pad = 64, 3, 3, 1, 1
+    d.out1_dev = x.data_ptr(); d.out1_ld, d.out1_off, d.split = 64, 0, 64
+    assert stlib.st_conv2d_nhwc_variant(C.byref(d), None, 43) != 0      # no transformed weights
+    d.wgt_wino_dev = x.data_ptr()
+    d.stride = 2
+    assert stlib.st_conv2d_nhwc_variant(C.byref(d), None, 43) != 0      # stride 2: not a Winograd layer

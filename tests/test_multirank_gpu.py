@@ -1,0 +1,55 @@
+"""GPU: the multi-rank code paths rehearsed with world_size 2 on the one card of the GPU box ('gloo' backend, the
+collective goes through host memory; the 8-GPU RCCL run itself is the driver's).  Covers BASELINE configs[3]'s driver
+(run_sharded_sequence: ragged shard, 3 in-flight contexts per rank, ONE all-gather of self-describing frame records,
+identical collective order on both ranks) and bench.py's --gpus N path."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        return s.getsockname()[1]
+
+
+def _launch(nproc, script_args, env_extra=None, timeout=600):
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0', **(env_extra or {}))
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={nproc}',
+           '--master-addr', '127.0.0.1', '--master-port', str(_free_port())] + script_args
+    p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+    return [json.loads(l) for l in p.stdout.splitlines() if l.startswith('{')]
+
+
+def test_sharded_sequence_world2_equals_single_process(cuda):
+    T = 13   # ragged: 7 + 6 frames, i.e. 2 batches of 4 per rank with padding on both
+    worker = os.path.join(ROOT, 'tests', 'sharded_worker.py')
+    single = subprocess.run([sys.executable, worker, str(T)], cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert single.returncode == 0, single.stderr[-3000:]
+    ref = [json.loads(l) for l in single.stdout.splitlines() if l.startswith('{')][0]
+    assert ref['world'] == 1 and sum(ref['nboxes']) > T
+    outs = _launch(2, [worker, str(T)])
+    assert sorted(o['rank'] for o in outs) == [0, 1]
+    for o in outs:   # every rank tracked ALL frames from the gathered records: identical to the unsharded run
+        assert o['ids'] == ref['ids'] and o['nboxes'] == ref['nboxes'] and o['box_sum'] == ref['box_sum']
+
+
+def test_bench_multirank_path_world2(cuda):
+    """bench.py --gpus 2 exactly as the driver launches it (torch.distributed.run, one rank per process), with the
+    collective rehearsed over gloo: the barrier / max-over-ranks timing, the per-step all-gather of the frame records
+    from the context streams and the record-vs-local-count check all run; rank 0 prints ONE JSON line."""
+    outs = _launch(2, [os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '4', '--warmup', '2', '--no-cpu-baseline',
+                       '--no-test-step', '--sustain-seconds', '0'], dict(ST_BENCH_BACKEND='gloo'))
+    assert len(outs) == 1
+    line = outs[0]
+    assert line['n_gpus'] == 2 and line['scaling'] == 'weak' and line['value'] > 0
+    assert line['config']['global_batch'] == 16 and line['config']['detections_overflow'] is False
+    assert 'roofline' in line and 'cpu_baseline' not in line

@@ -1,0 +1,27 @@
+#!/bin/bash
+# Round profile on the GPU box (run through gpurun): kernel durations (serialized and with the in-flight contexts),
+# MFMA-pipe utilisation and HBM traffic per kernel.  Outputs under gpurun_out/prof_$1; summaries are then copied to
+# profiles/ by hand.  rocprofv3 gets the program itself after `--` (no wrapper), counters in their own passes.
+set -e
+TAG=${1:-r02}
+OUT=gpurun_out/prof_$TAG
+mkdir -p $OUT
+export ST_TUNE_CACHE=$PWD/$OUT/tune_cache.json
+COMMON="--steps 20 --warmup 5 --no-cpu-baseline --no-test-step --sustain-seconds 0"
+python bench.py $COMMON > $OUT/bench_plain.json 2> $OUT/bench_plain.err          # also fills the tuning cache
+cd /tmp && export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/$OUT/stats_inflight1 -- python3 $R/bench.py $COMMON --inflight 1 > $R/$OUT/bench_rocprof_inflight1.json 2> $R/$OUT/rocprof1.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/$OUT/stats_inflight3 -- python3 $R/bench.py $COMMON > $R/$OUT/bench_rocprof_inflight3.json 2> $R/$OUT/rocprof3.err
+PM="--steps 4 --warmup 2 --no-cpu-baseline --no-test-step --sustain-seconds 0 --inflight 1"
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CU_CYCLES --kernel-trace --output-format csv -d $R/$OUT/pmc_mfma -- python3 $R/bench.py $PM > /dev/null 2> $R/$OUT/pmc_mfma.err
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $R/$OUT/pmc_fetch -- python3 $R/bench.py $PM > /dev/null 2> $R/$OUT/pmc_fetch.err
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $R/$OUT/pmc_write -- python3 $R/bench.py $PM > /dev/null 2> $R/$OUT/pmc_write.err
+cd $R
+find $OUT -name "*_kernel_stats.csv" | head
+python tools/pmc_mfma.py $(find $OUT/pmc_mfma -name "*counter_collection.csv" | head -1) $OUT/mfma_busy.json > $OUT/mfma_busy.txt
+python tools/pmc_summary.py $(find $OUT/pmc_fetch -name "*counter_collection.csv" | head -1) $(find $OUT/pmc_write -name "*counter_collection.csv" | head -1) $OUT/hbm_traffic.json > $OUT/hbm_traffic.txt
+python tools/op_profile.py --out $OUT/op_table.txt > /dev/null
+# keep the merged-back payload small: the raw traces are not needed
+find $OUT -name "*_kernel_trace.csv" -delete; find $OUT -name "*counter_collection.csv" -delete; find $OUT -name "*.db" -delete
+du -sh $OUT
