@@ -125,56 +125,72 @@ def conv_roofline(pipe, img, right, steps):
         per_variant[VARIANT_TILES[v]] = dict(launches=int(sel.sum()) + n_agg // steps, ms_per_step=round(float(t), 4),
                                              gflop_per_step=round(fl / 1e9, 3),
                                              tflops=round(fl / (t * 1e-3) / 1e12, 3) if t > 0 else 0.0)
-    # The dominant kernel of the path is conv_igemm_kernel (every tile instance is the same kernel template; which
-    # instance a layer uses is an autotune outcome that varies from run to run, so the roofline entry aggregates
-    # all instances: algorithmic flop of all its launches / their summed duration).  The fused stem kernel and the
-    # per-instance table are listed next to it.
-    # separate kernels (stem_focus_conv.hip, pointwise_conv.hip, direct_conv.hip), listed in per_variant only
-    OTHER = ('stem6x6s2', 'pw128', 'dc4x32', 'skipped')
-    inst = {k: v for k, v in per_variant.items() if k not in OTHER}
-    n_launch = sum(v['launches'] for v in inst.values())
-    ms_inst = sum(v['ms_per_step'] for v in inst.values())
-    gf_inst = sum(v['gflop_per_step'] for v in inst.values())
-    tf_inst = gf_inst / ms_inst                      # GFLOP / ms = TFLOP/s
-    dom = max(inst, key=lambda k: inst[k]['ms_per_step'])
+    # Kernel families of the MFMA work.  `roofline` describes the DOMINANT one = the family with the largest summed
+    # duration per step.  conv_igemm_kernel's tile instances are one kernel template (which instance a layer uses is
+    # an autotune outcome that varies from run to run) and are aggregated; the Winograd, direct 3x3, streaming 1x1
+    # and fused-stem kernels are families of their own.  `achieved` = ALGORITHMIC flops (2 x MACs of the direct
+    # convolution) / summed duration.  The Winograd kernel executes 2.25x fewer multiplies than
+    # that for the same convolution, so its algorithmic rate may exceed the MFMA peak: `mfma_executed_tflops` is the
+    # rate of the multiplies it actually issues (= what the matrix pipes see).
+    FAMILY = {'stem6x6s2': 'st::stem_focus_conv_kernel', 'pw128': 'st::pw_conv_kernel', 'dc4x32': 'st::direct_conv3x3_kernel',
+              'wino2x2': 'st::wino_conv3x3_kernel', 'skipped': None}
+    fam = {}
+    for name, v in per_variant.items():
+        f = FAMILY.get(name, 'st::conv_igemm_kernel')
+        if f is None:
+            continue
+        e = fam.setdefault(f, dict(launches=0, ms_per_step=0.0, gflop_per_step=0.0, instances=[]))
+        e['launches'] += v['launches']
+        e['ms_per_step'] += v['ms_per_step']
+        e['gflop_per_step'] += v['gflop_per_step']
+        e['instances'].append(name)
+    for f, e in fam.items():
+        e['tflops'] = round(e['gflop_per_step'] / e['ms_per_step'], 3) if e['ms_per_step'] > 0 else 0.0
+        e['frac'] = round(e['tflops'] / PEAK_FP32_MFMA_TFLOPS, 4)
+        e['ms_per_step'] = round(e['ms_per_step'], 4)
+        e['gflop_per_step'] = round(e['gflop_per_step'], 3)
+        if f == 'st::wino_conv3x3_kernel':
+            e['mfma_executed_tflops'] = round(e['tflops'] / 2.25, 3)
+            e['mfma_executed_frac'] = round(e['tflops'] / 2.25 / PEAK_FP32_MFMA_TFLOPS, 4)
+    dom = max(fam, key=lambda k: fam[k]['ms_per_step'])
+    D = fam[dom]
     conv_ms = float((tot_ms[kind == 1].sum() + sum(a[1] for a in agg.values())) / steps)
     conv_fl = 2.0 * float(macs[kind == 1].sum() + agg_macs * sum(a[0] for a in agg.values()) / steps)
-    # HBM bytes per launch from the committed rocprofv3 PMC passes (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE,
-    # separate passes; tools/pmc_summary.py): launch-weighted mean over the instances of this run
+    # HBM bytes per launch of the dominant family from the committed rocprofv3 PMC passes of this command (FETCH_SIZE
+    # x2 gfx950 correction + WRITE_SIZE, separate passes; tools/pmc_summary.py) - NOT measured inside this run
     traffic, traffic_src = None, None
     tpath = os.path.join(ROOT, 'profiles', 'r02_hbm_traffic.json')
     if os.path.exists(tpath):
         tj = json.load(open(tpath))
         tot_b, cov = 0.0, 0
-        for name, v in inst.items():
-            vid = next(i for i, n in VARIANT_TILES.items() if n == name)
-            row = tj.get('st::conv_igemm_kernel<%s>' % lib.st_conv_variant_signature(vid).decode())
-            if not row or row.get('fetch_bytes_corrected_per_launch') is None:
-                continue   # this run's autotune picked an instance the committed PMC passes did not see
-            tot_b += v['launches'] * (row['fetch_bytes_corrected_per_launch'] + (row.get('write_bytes_per_launch') or 0))
-            cov += v['launches']
-        if cov >= 0.5 * n_launch and tot_b > 0:
+        for kname, row in tj.items():
+            if kname.startswith(dom) and row.get('fetch_bytes_corrected_per_launch') is not None:
+                n = row.get('fetch_calls') or 0
+                tot_b += n * (row['fetch_bytes_corrected_per_launch'] + (row.get('write_bytes_per_launch') or 0))
+                cov += n
+        if cov:
             traffic = int(tot_b / cov)
-            traffic_src = ('profiles/r02_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, NOT '
-                           'measured inside this run), launch-weighted '
-                           'over the %d of %d launches whose tile instance is in that profile' % (cov, n_launch))
-    roof = dict(bound='mfma',
-                kernel='st::conv_igemm_kernel<...> (all tile instances; the fused stem kernel, the streaming 1x1 '
-                       'kernel and the direct 3x3 kernel are listed in per_variant as stem6x6s2 / pw128 / dc4x32)',
-                achieved=round(tf_inst, 3), peak=PEAK_FP32_MFMA_TFLOPS, unit='TFLOP/s',
-                frac=round(tf_inst / PEAK_FP32_MFMA_TFLOPS, 4), traffic=traffic, traffic_source=traffic_src,
-                flop_per_launch=round(gf_inst * 1e9 / n_launch),
-                avg_launch_us=round(ms_inst * 1e3 / n_launch, 2),
-                launches_per_step=n_launch, event_pair_overhead_us=round(null_ms * 1e3, 2), event_overhead_subtracted=False,
-                largest_instance=dict(tile=dom, **inst[dom],
-                                      symbol='st::conv_igemm_kernel<%s>' % lib.st_conv_variant_signature(
-                                          next(i for i, n in VARIANT_TILES.items() if n == dom)).decode()),
-                all_conv_incl_stem=dict(ms_per_step=round(conv_ms, 4),
-                                        tflops=round(conv_fl / (conv_ms * 1e-3) / 1e12, 3),
-                                        frac=round(conv_fl / (conv_ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4)),
+            traffic_src = ('profiles/r02_hbm_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command '
+                           '(separate runs, not measured inside this one), launch-weighted over %s*' % dom)
+    roof = dict(bound='mfma', kernel=dom + ('<...> (all tile instances)' if dom == 'st::conv_igemm_kernel' else ''),
+                achieved=D['tflops'], peak=PEAK_FP32_MFMA_TFLOPS, unit='TFLOP/s', frac=D['frac'],
+                traffic=traffic, traffic_source=traffic_src,
+                flop_per_launch=round(D['gflop_per_step'] * 1e9 / max(D['launches'], 1)),
+                avg_launch_us=round(D['ms_per_step'] * 1e3 / max(D['launches'], 1), 2),
+                launches_per_step=D['launches'], event_pair_overhead_us=round(null_ms * 1e3, 2),
+                event_overhead_subtracted=False,
+                definition='achieved = algorithmic flops of the direct convolution / summed HIP-event duration of the '
+                           'family\'s launches in a serialized pass',
+                families=fam,
+                all_mfma_kernels=dict(ms_per_step=round(conv_ms, 4),
+                                      tflops=round(conv_fl / (conv_ms * 1e-3) / 1e12, 3),
+                                      frac=round(conv_fl / (conv_ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4)),
                 per_variant=per_variant,
                 other_kernels_ms_per_step={k: round(v / steps, 4) for k, v in other.items()},
                 focus_spp_ms_per_step=round(float(tot_ms[kind != 1].sum() / steps), 4))
+    if 'mfma_executed_tflops' in D:
+        roof['mfma_executed_tflops'] = D['mfma_executed_tflops']
+        roof['mfma_executed_frac'] = D['mfma_executed_frac']
     # secondary roofline (SURVEY.md §8d "cost volume: HBM-bound scan", materialised form at 1/4 resolution):
     # algorithmic bytes of one costvolume launch = both feature maps read once + the volume written once
     Cf = pipe.det.tap('stage1_rgb').shape[-1]

@@ -35,6 +35,7 @@ bool pw_conv_applicable(const StConvDesc& d);
 bool pw_chain_applicable(const StConvDesc& d, const StConvDesc& c);
 bool dc_conv_applicable(const StConvDesc& d);
 bool wino_conv_applicable(const StConvDesc& d);
+bool wino_shape_ok(int Cin, int Cout);
 size_t wino_packed_floats(int Cout, int Cin);
 int wino_pack_weights(const float* packed, int Cout, int Cin, float* out);
 int pw_conv_launch(const StConvDesc& d, hipStream_t stream, const StConvDesc* chain);
@@ -255,7 +256,7 @@ struct StDetector {
     o.macs = (double)in.N * groups[cur_group].count * Ho * Wo * convs[pc].k * convs[pc].k * convs[pc].cin *
              convs[pc].cout;
     // wide 3x3 / stride-1 layers also get their weights in Winograd form (kernel instance 43, picked by the autotuner)
-    if (convs[pc].k == 3 && stride == 1 && convs[pc].cin % 32 == 0 && convs[pc].cout % 64 == 0 && o.split == convs[pc].cout &&
+    if (convs[pc].k == 3 && stride == 1 && wino_shape_ok(convs[pc].cin, convs[pc].cout) && o.split == convs[pc].cout &&
         !up.valid())
       convs[pc].wino = true;
     macs += o.macs;

@@ -40,10 +40,11 @@ constexpr int WN_WW = 2 * WN_TX + 2, WN_WH = 2 * WN_TY + 2;   // input window: 1
 constexpr int WN_PIX = WN_WW * WN_WH;                      // 180
 constexpr int WN_PIECES = (WN_PIX + 7) / 8;                // LDS-DMA pieces of 8 pixels x 128 B = 1 KB
 constexpr int WN_WIN_FLOATS = WN_PIECES * 8 * 32;          // one window buffer (32 cin per pixel)
-constexpr int WN_CB = 64;                                  // couts per workgroup
-constexpr int WN_R_FLOATS = 4 * 2 * 32 * WN_CB;            // output-transform exchange: [a][j][tile][co]
-constexpr int WN_LDS_FLOATS = WN_R_FLOATS > 2 * WN_WIN_FLOATS ? WN_R_FLOATS : 2 * WN_WIN_FLOATS;
-constexpr int WN_FRAG_FLOATS = 2 * 64 * 4;                 // one (kc, g, b) step: 2 cout blocks x 64 lanes x 4
+// couts per workgroup = 32 * CBN (CBN = cout blocks of 32 per wave): 64 for the wide layers, 32 for Cout = 32;
+// Cout = 48 runs as one padded block of 64 (zero weights, stores masked)
+constexpr int wn_lds_floats(int cbn) {
+  return 4 * 2 * 32 * 32 * cbn > 2 * WN_WIN_FLOATS ? 4 * 2 * 32 * 32 * cbn : 2 * WN_WIN_FLOATS;   // R exchange vs windows
+}
 
 struct WinoArgs {
   const float* in;
@@ -51,7 +52,7 @@ struct WinoArgs {
   const float* bias;
   float* out;
   const float* res;
-  int N, H, W, in_ld, in_off, Cout;
+  int N, H, W, Cin, in_ld, in_off, Cout;
   int out_ld, out_off, res_ld, res_off;
   float post_scale;
   int act;
@@ -61,8 +62,10 @@ struct WinoArgs {
 
 __device__ __forceinline__ float wn_silu(float v) { return v * __builtin_amdgcn_rcpf(1.0f + __expf(-v)); }
 
-template <bool RES>
+template <int CBN, bool RES>
 __global__ __launch_bounds__(256, 2) void wino_conv3x3_kernel(const WinoArgs p) {
+  constexpr int WN_CB = 32 * CBN;                       // couts per workgroup
+  constexpr int WN_FRAG_FLOATS = CBN * 64 * 4;          // one (kc, g, b) step: CBN cout blocks x 64 lanes x 4
   extern __shared__ float4 wn_smem4[];
   float* smem = reinterpret_cast<float*>(wn_smem4);
   const int tid = threadIdx.x, lane = tid & 63, a = tid >> 6;   // wave = transform row a
@@ -88,6 +91,7 @@ __global__ __launch_bounds__(256, 2) void wino_conv3x3_kernel(const WinoArgs p) 
   // sl ^ ((q >> 1) & 7) of window pixel q (zero outside the image / past the window)
   constexpr int NPW = (WN_PIECES + 3) / 4;   // pieces per wave
   unsigned poff[NPW];
+  unsigned tail_ok = 0;                      // bit k: this lane's channel quad exists in the LAST K-chunk (Cin % 32 != 0)
 #pragma unroll
   for (int k = 0; k < NPW; ++k) {
     const int j = a + 4 * k;
@@ -97,14 +101,17 @@ __global__ __launch_bounds__(256, 2) void wino_conv3x3_kernel(const WinoArgs p) 
     const bool ok = j < WN_PIECES && q < WN_PIX && y >= 0 && y < p.H && x >= 0 && x < p.W;
     const int quad = sl ^ ((q >> 1) & 7);
     poff[k] = ok ? (unsigned)((((n * p.H + y) * p.W + x) * p.in_ld + p.in_off + 4 * quad) * 4) : 0x80000000u;
+    if ((p.nkc - 1) * 32 + 4 * quad < p.Cin) tail_ok |= 1u << k;
   }
   auto dma_window = [&](int kc, int buf) {
+    const bool last = kc == p.nkc - 1;
 #pragma unroll
     for (int k = 0; k < NPW; ++k) {
       const int j = a + 4 * k;
+      const unsigned off = (last && !((tail_ok >> k) & 1u)) ? 0x80000000u : poff[k];   // channels >= Cin read as zero
       if (j < WN_PIECES)   // wave-uniform
         __builtin_amdgcn_raw_ptr_buffer_load_lds(
-            irsrc, (__attribute__((address_space(3))) void*)(smem + buf * WN_WIN_FLOATS + j * 256), 16, poff[k],
+            irsrc, (__attribute__((address_space(3))) void*)(smem + buf * WN_WIN_FLOATS + j * 256), 16, off,
             kc * 128, 0, 0);
     }
   };
@@ -125,22 +132,23 @@ __global__ __launch_bounds__(256, 2) void wino_conv3x3_kernel(const WinoArgs p) 
 
   // ---- transformed-weight stream of this wave: [cb][a][kc][g][b][nb][lane][4], one step = WN_FRAG_FLOATS
   const unsigned wbase = (unsigned)((((cb * 4 + a) * p.nkc) * 16) * WN_FRAG_FLOATS + lane * 4) * 4u;
-  auto load_frag = [&](int step, f32x4 (&f)[2]) {   // step = (kc * 4 + g) * 4 + b ; past the end: zeros
+  auto load_frag = [&](int step, f32x4 (&f)[CBN]) {   // step = (kc * 4 + g) * 4 + b ; past the end: zeros
     const unsigned off = wbase + (unsigned)step * (WN_FRAG_FLOATS * 4u);
-    f[0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, off, 0, 0));
-    f[1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, off + 1024u, 0, 0));
+#pragma unroll
+    for (int nb = 0; nb < CBN; ++nb)
+      f[nb] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, off + 1024u * nb, 0, 0));
   };
 
-  f32x16 acc[4][2];
+  f32x16 acc[4][CBN];
 #pragma unroll
   for (int b = 0; b < 4; ++b)
 #pragma unroll
-    for (int nb = 0; nb < 2; ++nb)
+    for (int nb = 0; nb < CBN; ++nb)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[b][nb][r] = 0.f;
 
   dma_window(0, 0);
-  f32x4 fe[2], fo[2];   // weight fragments of the even / odd steps (16 steps per chunk: static assignment)
+  f32x4 fe[CBN], fo[CBN];   // weight fragments of the even / odd steps (16 steps per chunk: static assignment)
   load_frag(0, fe);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
@@ -170,7 +178,7 @@ __global__ __launch_bounds__(256, 2) void wino_conv3x3_kernel(const WinoArgs p) 
 #pragma unroll
         for (int s = 0; s < 4; ++s)
 #pragma unroll
-          for (int nb = 0; nb < 2; ++nb)
+          for (int nb = 0; nb < CBN; ++nb)
             acc[b][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[b][s], (b & 1) ? fo[nb][s] : fe[nb][s], acc[b][nb],
                                                               0, 0, 0);
       }
@@ -182,7 +190,7 @@ __global__ __launch_bounds__(256, 2) void wino_conv3x3_kernel(const WinoArgs p) 
   // ---- output transform.  Row reduction over b in registers: R[0] = M0 + M1 + M2, R[1] = M1 - M2 - M3
   float* Rb = smem;   // [a][j][tile][co]: every wave is past its last window read (barrier above)
 #pragma unroll
-  for (int nb = 0; nb < 2; ++nb)
+  for (int nb = 0; nb < CBN; ++nb)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int m = (r & 3) + 8 * (r >> 2) + 4 * h;
@@ -192,17 +200,21 @@ __global__ __launch_bounds__(256, 2) void wino_conv3x3_kernel(const WinoArgs p) 
       Rb[((a * 2 + 1) * 32 + m) * WN_CB + nb * 32 + i] = R1;
     }
   __syncthreads();
-  // column reduction over a + epilogue: wave w takes tiles 8w .. 8w+7 (= tile row w), lane = cout
-  const int co = cb * WN_CB + lane;
+  // column reduction over a + epilogue: wave w takes tiles 8w .. 8w+7 (= tile row w); lane = cout (CB = 64), or
+  // (tile parity, cout) when a workgroup owns 32 couts
+  constexpr int TPI = 64 / WN_CB;                 // tiles handled per iteration by one wave
+  const int col = lane % WN_CB, tsel = lane / WN_CB;
+  const int co = cb * WN_CB + col;
   const float bias = p.bias[co];
 #pragma unroll
-  for (int t8 = 0; t8 < 8; ++t8) {
-    const int t = a * 8 + t8;   // tile (tyi = a, txi = t8)
-    const int oy0 = by * (2 * WN_TY) + 2 * a, ox0 = bx * (2 * WN_TX) + 2 * t8;
+  for (int t8 = 0; t8 < 8; t8 += TPI) {
+    const int txo = t8 + tsel;
+    const int t = a * 8 + txo;   // tile (tyi = a, txi = txo)
+    const int oy0 = by * (2 * WN_TY) + 2 * a, ox0 = bx * (2 * WN_TX) + 2 * txo;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-      const float q0 = Rb[((0 * 2 + j) * 32 + t) * WN_CB + lane], q1 = Rb[((1 * 2 + j) * 32 + t) * WN_CB + lane];
-      const float q2 = Rb[((2 * 2 + j) * 32 + t) * WN_CB + lane], q3 = Rb[((3 * 2 + j) * 32 + t) * WN_CB + lane];
+      const float q0 = Rb[((0 * 2 + j) * 32 + t) * WN_CB + col], q1 = Rb[((1 * 2 + j) * 32 + t) * WN_CB + col];
+      const float q2 = Rb[((2 * 2 + j) * 32 + t) * WN_CB + col], q3 = Rb[((3 * 2 + j) * 32 + t) * WN_CB + col];
       const float y[2] = {(q0 + q1) + q2, (q1 - q2) - q3};
 #pragma unroll
       for (int ii = 0; ii < 2; ++ii) {
@@ -227,42 +239,59 @@ __global__ __launch_bounds__(256, 2) void wino_conv3x3_kernel(const WinoArgs p) 
 
 }  // namespace
 
-// floats of the fragment-ordered transformed weights of a Cout x Cin 3x3 conv (Cout padded to 64)
-size_t wino_packed_floats(int Cout, int Cin) { return (size_t)16 * round_up(Cout, WN_CB) * Cin; }
+// cout blocks of 32 per workgroup for a layer: 2 (64 couts) when Cout is a multiple of 64 or fits one padded block of
+// 64 (33..63, e.g. the 48-level aggregation convs), 1 (32 couts) for the other multiples of 32; 0 = not a Winograd layer
+int wino_cbn(int Cout) {
+  if (Cout <= 0) return 0;
+  if (Cout % 64 == 0) return 2;
+  if (Cout % 32 == 0) return 1;
+  if (Cout > 32 && Cout < 64) return 2;
+  return 0;
+}
+bool wino_shape_ok(int Cin, int Cout) { return Cin >= 16 && Cin % 4 == 0 && wino_cbn(Cout) != 0; }
+
+// floats of the fragment-ordered transformed weights of a Cout x Cin 3x3 conv (Cout padded to the workgroup's cout
+// block, Cin to the K-chunk of 32)
+size_t wino_packed_floats(int Cout, int Cin) {
+  const int cb = 32 * wino_cbn(Cout);
+  return cb ? (size_t)16 * round_up(Cout, cb) * round_up(Cin, 32) : 0;
+}
 
 // packed: the direct kernels' folded fp32 weights [CoutPad32][Kpad], K index = (kh*3+kw)*Cin + ci (host memory).
-// out: [cb][a][kc][g][b][nb][lane][4] with lane = (h << 5) | j: U_{a,b}[co = cb*64 + nb*32 + j][ci = kc*32 + 8g + 4h + e],
-// U = G g G^T evaluated in fp64 on the fp32 weights and rounded once.
+// out: [cb][a][kc][g][b][nb][lane][4] with lane = (h << 5) | j: U_{a,b}[co = cb*CB + nb*32 + j][ci = kc*32 + 8g + 4h + e]
+// (zero for co >= Cout or ci >= Cin), U = G g G^T evaluated in fp64 on the fp32 weights and rounded once.
 int wino_pack_weights(const float* packed, int Cout, int Cin, float* out) {
-  ST_REQUIRE(packed && out && Cout > 0 && Cin > 0 && Cin % 32 == 0, "wino_pack_weights: Cin must be a multiple of 32");
-  const int Kpad = round_up(9 * Cin, 32), ncb = round_up(Cout, WN_CB) / WN_CB, nkc = Cin / 32;
+  ST_REQUIRE(packed && out && wino_shape_ok(Cin, Cout), "wino_pack_weights: not a Winograd layer shape (Cin %d, Cout %d)",
+             Cin, Cout);
+  const int cbn = wino_cbn(Cout), CB = 32 * cbn;
+  const int Kpad = round_up(9 * Cin, 32), ncb = round_up(Cout, CB) / CB, nkc = round_up(Cin, 32) / 32;
   static const double G[4][3] = {{1, 0, 0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0, 0, 1}};
   for (int cb = 0; cb < ncb; ++cb)
     for (int a = 0; a < 4; ++a)
       for (int kc = 0; kc < nkc; ++kc)
         for (int g = 0; g < 4; ++g)
           for (int b = 0; b < 4; ++b)
-            for (int nb = 0; nb < 2; ++nb)
+            for (int nb = 0; nb < cbn; ++nb)
               for (int l = 0; l < 64; ++l)
                 for (int e = 0; e < 4; ++e) {
                   const int j = l & 31, h = l >> 5;
-                  const int co = cb * WN_CB + nb * 32 + j, ci = kc * 32 + 8 * g + 4 * h + e;
+                  const int co = cb * CB + nb * 32 + j, ci = kc * 32 + 8 * g + 4 * h + e;
                   double u = 0.0;
-                  if (co < Cout)
+                  if (co < Cout && ci < Cin)
                     for (int kh = 0; kh < 3; ++kh)
                       for (int kw = 0; kw < 3; ++kw)
                         u += G[a][kh] * (double)packed[(size_t)co * Kpad + (kh * 3 + kw) * Cin + ci] * G[b][kw];
-                  out[(((((((size_t)cb * 4 + a) * nkc + kc) * 4 + g) * 4 + b) * 2 + nb) * 64 + l) * 4 + e] = (float)u;
+                  out[(((((((size_t)cb * 4 + a) * nkc + kc) * 4 + g) * 4 + b) * cbn + nb) * 64 + l) * 4 + e] = (float)u;
                 }
   return ST_OK;
 }
 
-// Shapes: 3x3 / stride 1 / pad 1, Cin a multiple of 32, Cout a multiple of 64, one output tensor (no split / upsample),
-// transformed weights present, every tensor below 2 GiB.
+// Shapes: 3x3 / stride 1 / pad 1, Cin a multiple of 4 (>= 16), Cout a multiple of 32 or one padded block of 64, one
+// output tensor (no split / upsample), transformed weights present, every tensor below 2 GiB.
 bool wino_conv_applicable(const StConvDesc& d) {
   if (!d.wgt_wino_dev) return false;
   if (d.KH != 3 || d.KW != 3 || d.stride != 1 || d.pad != 1 || d.up_dev || d.out2_dev) return false;
-  if (d.Cin % 32 != 0 || d.Cout % WN_CB != 0) return false;
+  if (!wino_shape_ok(d.Cin, d.Cout)) return false;
   if ((d.in_ld | d.in_off) & 3) return false;
   if (reinterpret_cast<uintptr_t>(d.in_dev) & 15) return false;
   const long long M = (long long)d.N * d.Hi * d.Wi, lim = 1ll << 31;
@@ -271,37 +300,44 @@ bool wino_conv_applicable(const StConvDesc& d) {
   return true;
 }
 
+template <int CBN, bool RES>
+static int wino_launch_instance(const WinoArgs& a, unsigned blocks, hipStream_t stream) {
+  constexpr int lds = wn_lds_floats(CBN) * (int)sizeof(float);
+  static int lds_set = 0;
+  auto kern = wino_conv3x3_kernel<CBN, RES>;
+  ST_ENSURE_DYNAMIC_LDS(kern, lds, lds_set);
+  hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), lds, stream, a);
+  return ST_OK;
+}
+
 int wino_conv_launch(const StConvDesc& d, hipStream_t stream) {
-  ST_REQUIRE(wino_conv_applicable(d), "winograd conv: shape not supported (3x3 s1 p1, Cin % 32 == 0, Cout % 64 == 0, "
-                                      "transformed weights required)");
+  ST_REQUIRE(wino_conv_applicable(d), "winograd conv: shape not supported (3x3 s1 p1, Cin % 4 == 0, Cout a multiple of 32 "
+                                      "or <= 64, transformed weights required)");
   ST_REQUIRE(d.in_dev && d.bias_dev && d.out1_dev, "winograd conv: null pointer");
   ST_REQUIRE(d.in_off + d.Cin <= d.in_ld && d.out1_off + d.Cout <= d.out1_ld, "winograd conv: channel slice exceeds ld");
   if (d.res_dev) ST_REQUIRE(d.res_off + d.Cout <= d.res_ld, "winograd conv: res slice exceeds res_ld");
   const long long M = (long long)d.N * d.Hi * d.Wi;
+  const int cbn = wino_cbn(d.Cout), CB = 32 * cbn;
   WinoArgs a;
   a.in = d.in_dev; a.wino = d.wgt_wino_dev; a.bias = d.bias_dev; a.out = d.out1_dev; a.res = d.res_dev;
-  a.N = d.N; a.H = d.Hi; a.W = d.Wi; a.in_ld = d.in_ld; a.in_off = d.in_off; a.Cout = d.Cout;
+  a.N = d.N; a.H = d.Hi; a.W = d.Wi; a.Cin = d.Cin; a.in_ld = d.in_ld; a.in_off = d.in_off; a.Cout = d.Cout;
   a.out_ld = d.out1_ld; a.out_off = d.out1_off; a.res_ld = d.res_ld; a.res_off = d.res_off;
   a.post_scale = d.res_dev ? d.post_scale : 1.0f;
   a.act = d.act;
   a.tbx = ceil_div(d.Wi, 2 * WN_TX); a.tby = ceil_div(d.Hi, 2 * WN_TY);
-  a.ncb = d.Cout / WN_CB; a.nkc = d.Cin / 32;
+  a.ncb = round_up(d.Cout, CB) / CB; a.nkc = round_up(d.Cin, 32) / 32;
   a.in_bytes = (unsigned)(M * d.in_ld * 4);
   a.out_bytes = (unsigned)(M * d.out1_ld * 4);
   a.res_bytes = d.res_dev ? (unsigned)(M * d.res_ld * 4) : 0u;
   a.wino_bytes = (unsigned)(wino_packed_floats(d.Cout, d.Cin) * 4);
   const long long blocks = (long long)d.N * a.tbx * a.tby * a.ncb;
   ST_REQUIRE(blocks < (1ll << 31), "winograd conv: grid too large");
-  constexpr int lds = WN_LDS_FLOATS * (int)sizeof(float);
-  if (d.res_dev) {
-    static int lds_set = 0;
-    ST_ENSURE_DYNAMIC_LDS(wino_conv3x3_kernel<true>, lds, lds_set);
-    hipLaunchKernelGGL(wino_conv3x3_kernel<true>, dim3((unsigned)blocks), dim3(256), lds, stream, a);
-  } else {
-    static int lds_set = 0;
-    ST_ENSURE_DYNAMIC_LDS(wino_conv3x3_kernel<false>, lds, lds_set);
-    hipLaunchKernelGGL(wino_conv3x3_kernel<false>, dim3((unsigned)blocks), dim3(256), lds, stream, a);
-  }
+  int rc;
+  if (cbn == 2) rc = d.res_dev ? wino_launch_instance<2, true>(a, (unsigned)blocks, stream)
+                               : wino_launch_instance<2, false>(a, (unsigned)blocks, stream);
+  else rc = d.res_dev ? wino_launch_instance<1, true>(a, (unsigned)blocks, stream)
+                      : wino_launch_instance<1, false>(a, (unsigned)blocks, stream);
+  ST_CHECK(rc);
   ST_CHECK_HIP(hipGetLastError());
   return ST_OK;
 }

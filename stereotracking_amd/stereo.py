@@ -80,11 +80,17 @@ class StereoCostVolume(nn.Module):
             bp = torch.empty((D + 31) // 32 * 32, dtype=torch.float32)
             check(self.lib.st_conv_pack_weights(ptr(w), ptr(b), None, None, None, None, 0.0, D, D, 3, 3, ptr(wp),
                                                 ptr(bp)), 'st_conv_pack_weights')
-            packed.append((wp.to(dev), bp.to(dev)))
+            wn = None   # the same weights in Winograd form (kernel instance 43), when the shape allows it
+            nw = self.lib.st_wino_packed_floats(D, D)
+            if nw:
+                wn = torch.empty(nw, dtype=torch.float32)
+                check(self.lib.st_wino_pack_weights(ptr(wp), D, D, ptr(wn)), 'st_wino_pack_weights')
+                wn = wn.to(dev)
+            packed.append((wp.to(dev), bp.to(dev), wn))
         self._packed = (dev, ver, packed)
         return packed
 
-    def _agg_desc(self, l, src, dst, wp, bp):
+    def _agg_desc(self, l, src, dst, wp, bp, wn=None):
         N, Hf, Wf, D = src.shape
         d = StConvDesc()
         d.in_dev = src.data_ptr(); d.N, d.Hi, d.Wi, d.Cin, d.in_ld, d.in_off = N, Hf, Wf, D, D, 0
@@ -92,6 +98,7 @@ class StereoCostVolume(nn.Module):
         d.Cout, d.KH, d.KW, d.stride, d.pad = D, 3, 3, 1, 1
         d.out1_dev = dst.data_ptr(); d.out1_ld, d.out1_off, d.split = D, 0, D
         d.act = 1 if l < self.agg_layers - 1 else 0
+        d.wgt_wino_dev = wn.data_ptr() if wn is not None else None
         return d
 
     def _volumes(self, dev, N, Hf, Wf):
@@ -101,7 +108,7 @@ class StereoCostVolume(nn.Module):
                          torch.zeros(N, Hf, Wf, D, dtype=torch.float32, device=dev))
         return self._vol
 
-    def autotune(self, dev, N, Hf, Wf, reps=5, candidates=tuple(range(22)) + (42,)):
+    def autotune(self, dev, N, Hf, Wf, reps=5, candidates=tuple(range(22)) + (42, 43)):
         """Pick the aggregation convs' tile variant by measurement (same policy as st_detector_autotune:
         min over `reps` individually timed launches).  Returns the chosen variant id."""
         if not self.agg_layers:
@@ -189,8 +196,8 @@ class StereoCostVolume(nn.Module):
             if self.timing:
                 cv1.record()
                 self._cv_events.append((cv0, cv1))
-            for l, (wp, bp) in enumerate(packed):
-                d = self._agg_desc(l, va, vb, wp, bp)
+            for l, (wp, bp, wn) in enumerate(packed):
+                d = self._agg_desc(l, va, vb, wp, bp, wn)
                 if self.timing:
                     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                     e0.record()

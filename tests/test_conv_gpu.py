@@ -402,6 +402,10 @@ def test_experimental_variants_are_not_in_the_product_library(stlib, cuda):
     (128, 256, False, 1, (1, 20, 36), 160, 32),    # fused cls|reg first tower conv, input = a channel slice
     (256, 256, False, 0, (1, 9, 17), None, 0),     # 8 K-chunks, no activation, one partial tile block
     (32, 64, True, 1, (2, 7, 5), None, 0),         # single K-chunk, image smaller than one tile block
+    (48, 48, False, 1, (2, 23, 41), None, 0),      # cost-volume aggregation conv: Cin tail (48 = 32 + 16), Cout padded to 64
+    (32, 32, True, 1, (1, 46, 80), 64, 32),        # stage-1 bottleneck conv2 + identity: 32-cout workgroups
+    (64, 96, False, 0, (1, 12, 20), None, 0),      # three 32-cout blocks
+    (16, 32, False, 1, (1, 9, 9), None, 0),        # half a K-chunk
 ])
 def test_winograd_conv_matches_direct_convolution(cin, cout, res, act, shape, in_ld, in_off, cuda):
     """Tile variant 43 (wino_conv.hip): Winograd F(2x2,3x3) evaluates the SAME 3x3 / stride-1 convolution with 2.25x
@@ -417,7 +421,7 @@ def test_winograd_conv_matches_direct_convolution(cin, cout, res, act, shape, in
     got, _ = run_conv(x, w, b, 1, 1, act, cuda, variant=43, res=r, post_scale=0.5 if res else 1.0, in_ld=in_ld,
                       in_off=in_off)
     assert_close(got, ref)
-    base, _ = run_conv(x, w, b, 1, 1, act, cuda, variant=3, res=r, post_scale=0.5 if res else 1.0, in_ld=in_ld,
+    base, _ = run_conv(x, w, b, 1, 1, act, cuda, variant=4, res=r, post_scale=0.5 if res else 1.0, in_ld=in_ld,
                        in_off=in_off)
     assert_close(got, base.double(), tol=2e-5)
 

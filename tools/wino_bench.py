@@ -37,7 +37,7 @@ def bench(N, H, W, Cin, Cout, res, reps=10):
     stream = _lib.current_stream()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     res_t = {}
-    for v in list(range(22)) + [43]:
+    for v in list(range(22)) + [42, 43]:
         if lib.st_conv2d_nhwc_variant(C.byref(d), stream, v) != 0:
             continue
         best = 1e9
@@ -57,5 +57,6 @@ def bench(N, H, W, Cin, Cout, res, reps=10):
 
 for shape in [(8, 92, 160, 128, 256, False), (8, 92, 160, 128, 128, False), (8, 92, 160, 64, 64, True),
               (8, 46, 80, 128, 128, True), (8, 46, 80, 128, 256, False), (8, 23, 40, 256, 256, False),
-              (8, 23, 40, 128, 256, False), (8, 23, 40, 128, 128, False), (16, 184, 320, 64, 64, False)]:
+              (8, 23, 40, 128, 256, False), (8, 23, 40, 128, 128, False), (16, 184, 320, 64, 64, False),
+              (16, 184, 320, 32, 32, True), (8, 184, 320, 48, 48, False)]:
     bench(*shape)
