@@ -133,7 +133,7 @@ def conv_roofline(pipe, img, right, steps):
     # that for the same convolution, so its algorithmic rate may exceed the MFMA peak: `mfma_executed_tflops` is the
     # rate of the multiplies it actually issues (= what the matrix pipes see).
     FAMILY = {'stem6x6s2': 'st::stem_focus_conv_kernel', 'pw128': 'st::pw_conv_kernel', 'dc4x32': 'st::direct_conv3x3_kernel',
-              'wino2x2': 'st::wino_conv3x3_kernel', 'skipped': None}
+              'wino2x2': 'st::wino_conv3x3_kernel', 'wino2x2n': 'st::wino_conv3x3_kernel', 'skipped': None}
     fam = {}
     for name, v in per_variant.items():
         f = FAMILY.get(name, 'st::conv_igemm_kernel')

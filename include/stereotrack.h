@@ -83,7 +83,8 @@ typedef struct StConvDesc {
 int st_conv2d_nhwc(const StConvDesc* d, st_stream_t stream);
 /* The same convolution with the kernel instance chosen by the caller instead of the library's heuristic:
  * variant 0..21 = tile instances of the implicit-GEMM kernel (st_conv_variant_name), 41 = streaming 1x1 kernel,
- * 42 = direct 3x3 kernel, 43 = Winograd F(2x2,3x3) kernel (needs wgt_wino_dev), -1 = heuristic.  Returns ST_ERR_INVALID when the instance cannot run this layer (tile
+ * 42 = direct 3x3 kernel, 43 / 44 = Winograd F(2x2,3x3) kernel with 64- / 32-cout workgroups (need wgt_wino_dev),
+ * -1 = heuristic.  Returns ST_ERR_INVALID when the instance cannot run this layer (tile
  * does not divide the padded Cout, ...), so callers can autotune per layer by timing the valid ones — which is
  * what st_detector_autotune does internally and StereoCostVolume.autotune does for the aggregation convs.
  * Results are the same convolution for every valid variant (fp32 rounding differs with the summation order). */

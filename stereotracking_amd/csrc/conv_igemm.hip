@@ -680,7 +680,7 @@ int pw_conv_launch(const StConvDesc& d, hipStream_t stream, const StConvDesc* ch
 bool dc_conv_applicable(const StConvDesc& d);          // direct_conv.hip (tile variant 42)
 int dc_conv_launch(const StConvDesc& d, hipStream_t stream);
 bool wino_conv_applicable(const StConvDesc& d);        // wino_conv.hip (tile variant 43)
-int wino_conv_launch(const StConvDesc& d, hipStream_t stream);
+int wino_conv_launch(const StConvDesc& d, hipStream_t stream, bool narrow);
 
 int conv2d_launch(const StConvDesc& d, hipStream_t stream, int force_variant, int* picked_variant) {
   ST_REQUIRE(d.in_dev && d.wgt_dev && d.bias_dev && d.out1_dev, "conv: null pointer");
@@ -692,9 +692,9 @@ int conv2d_launch(const StConvDesc& d, hipStream_t stream, int force_variant, in
     if (picked_variant) *picked_variant = 42;
     return dc_conv_launch(d, stream);
   }
-  if (force_variant == 43) {   // Winograd F(2x2,3x3) kernel for the wide 3x3 / stride-1 layers
-    if (picked_variant) *picked_variant = 43;
-    return wino_conv_launch(d, stream);
+  if (force_variant == 43 || force_variant == 44) {   // Winograd F(2x2,3x3) kernel (44: 32-cout workgroups)
+    if (picked_variant) *picked_variant = force_variant;
+    return wino_conv_launch(d, stream, force_variant == 44);
   }
   ST_REQUIRE(d.Cin % 4 == 0 && d.in_ld % 4 == 0 && d.in_off % 4 == 0,
              "conv: Cin/in_ld/in_off must be multiples of 4 (got %d/%d/%d)", d.Cin, d.in_ld,

@@ -852,9 +852,11 @@ extern "C" int st_detector_autotune(StDetector* det, void* workspace_dev, size_t
     probe.wgt_wino_dev = det->convs[so.pc].wino ? det->wgt_dev + det->convs[so.pc].wino_off : nullptr;
     const bool wn_ok = !det->no_wino && wino_conv_applicable(probe);   // + variant 43, Winograd F(2x2,3x3) (wino_conv.hip)
     const int ncand = std::min(conv_variant_count(), 22);
-    for (int vi = 0; vi <= ncand + 2 && rc == ST_OK; ++vi) {
-      const int v = vi < ncand ? vi : vi == ncand ? 41 : vi == ncand + 1 ? 42 : 43;
-      if (v == 41 ? !pw_ok : v == 42 ? !dc_ok : v == 43 ? !wn_ok : !conv_variant_valid(v, det->convs[saved[oi].pc].cout))
+    const bool wn_narrow_ok = wn_ok && det->convs[so.pc].cout % 64 == 0;   // + variant 44: 32-cout Winograd workgroups
+    for (int vi = 0; vi <= ncand + 3 && rc == ST_OK; ++vi) {
+      const int v = vi < ncand ? vi : 41 + (vi - ncand);
+      if (v == 41 ? !pw_ok : v == 42 ? !dc_ok : v == 43 ? !wn_ok : v == 44 ? !wn_narrow_ok
+                                                                  : !conv_variant_valid(v, det->convs[saved[oi].pc].cout))
         continue;
       det->force_variant = v;
       rc = run_ops(det, 0, 0, inputs, static_cast<float*>(workspace_dev), head_out_dev, stream);  // warm
@@ -889,10 +891,10 @@ extern "C" int st_detector_autotune(StDetector* det, void* workspace_dev, size_t
 // id 40 = the fused Focus+stem kernel (stem_focus_conv.hip), reported with the conv ops
 // id 41 = the streaming 1x1 kernel for narrow layers (pointwise_conv.hip)
 extern "C" const char* st_conv_variant_name(int id) {
-  return id == 40 ? "stem6x6s2" : id == 41 ? "pw128" : id == 42 ? "dc4x32" : id == 43 ? "wino2x2" : conv_variant_name(id);
+  return id == 40 ? "stem6x6s2" : id == 41 ? "pw128" : id == 42 ? "dc4x32" : id == 43 ? "wino2x2" : id == 44 ? "wino2x2n" : conv_variant_name(id);
 }
 extern "C" const char* st_conv_variant_signature(int id) {
-  return id == 40 ? "stem_focus_conv" : id == 41 ? "pw_conv" : id == 42 ? "direct_conv3x3" : id == 43 ? "wino_conv3x3"
+  return id == 40 ? "stem_focus_conv" : id == 41 ? "pw_conv" : id == 42 ? "direct_conv3x3" : id == 43 ? "wino_conv3x3" : id == 44 ? "wino_conv3x3 narrow"
                                                               : conv_variant_signature(id);
 }
 
@@ -911,7 +913,7 @@ extern "C" int st_detector_set_tuning(StDetector* det, const int* variants, int 
   for (int i = 0; i < n; ++i) {
     const Op& o = det->ops[i];
     if (variants[i] < 0 || o.type != Op::CONV) continue;
-    if (variants[i] >= 41 && variants[i] <= 43) continue;   // own applicability checks run at launch
+    if (variants[i] >= 41 && variants[i] <= 44) continue;   // own applicability checks run at launch
     ST_REQUIRE(conv_variant_valid(variants[i], det->convs[o.pc].cout), "st_detector_set_tuning: variant %d invalid for op %d",
                variants[i], i);
   }

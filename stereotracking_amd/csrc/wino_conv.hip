@@ -62,10 +62,13 @@ struct WinoArgs {
 
 __device__ __forceinline__ float wn_silu(float v) { return v * __builtin_amdgcn_rcpf(1.0f + __expf(-v)); }
 
-template <int CBN, bool RES>
+// CBN = cout blocks of 32 a workgroup computes; LCBN = cout blocks per group in the weight LAYOUT (>= CBN).  LCBN = 2 with
+// CBN = 1 (tile variant 44) runs a 64-cout layout with 32-cout workgroups: twice the workgroups, for the small maps
+// (23x40, 46x80) whose grid otherwise fills less than one round of the chip.
+template <int CBN, int LCBN, bool RES>
 __global__ __launch_bounds__(256, 2) void wino_conv3x3_kernel(const WinoArgs p) {
   constexpr int WN_CB = 32 * CBN;                       // couts per workgroup
-  constexpr int WN_FRAG_FLOATS = CBN * 64 * 4;          // one (kc, g, b) step: CBN cout blocks x 64 lanes x 4
+  constexpr int WN_FRAG_FLOATS = LCBN * 64 * 4;         // one (kc, g, b) step in memory: LCBN cout blocks x 64 lanes x 4
   extern __shared__ float4 wn_smem4[];
   float* smem = reinterpret_cast<float*>(wn_smem4);
   const int tid = threadIdx.x, lane = tid & 63, a = tid >> 6;   // wave = transform row a
@@ -131,7 +134,9 @@ __global__ __launch_bounds__(256, 2) void wino_conv3x3_kernel(const WinoArgs p) 
   }
 
   // ---- transformed-weight stream of this wave: [cb][a][kc][g][b][nb][lane][4], one step = WN_FRAG_FLOATS
-  const unsigned wbase = (unsigned)((((cb * 4 + a) * p.nkc) * 16) * WN_FRAG_FLOATS + lane * 4) * 4u;
+  constexpr int SPLIT = LCBN / CBN;   // workgroups sharing one layout group
+  const unsigned wbase = (unsigned)(((((cb / SPLIT) * 4 + a) * p.nkc) * 16) * WN_FRAG_FLOATS + (cb % SPLIT) * CBN * 256 +
+                                    lane * 4) * 4u;
   auto load_frag = [&](int step, f32x4 (&f)[CBN]) {   // step = (kc * 4 + g) * 4 + b ; past the end: zeros
     const unsigned off = wbase + (unsigned)step * (WN_FRAG_FLOATS * 4u);
 #pragma unroll
@@ -300,24 +305,27 @@ bool wino_conv_applicable(const StConvDesc& d) {
   return true;
 }
 
-template <int CBN, bool RES>
+template <int CBN, int LCBN, bool RES>
 static int wino_launch_instance(const WinoArgs& a, unsigned blocks, hipStream_t stream) {
   constexpr int lds = wn_lds_floats(CBN) * (int)sizeof(float);
   static int lds_set = 0;
-  auto kern = wino_conv3x3_kernel<CBN, RES>;
+  auto kern = wino_conv3x3_kernel<CBN, LCBN, RES>;
   ST_ENSURE_DYNAMIC_LDS(kern, lds, lds_set);
   hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), lds, stream, a);
   return ST_OK;
 }
 
-int wino_conv_launch(const StConvDesc& d, hipStream_t stream) {
+// narrow = true: 32-cout workgroups on a 64-cout layout (tile variant 44; only where the layout has 2 blocks)
+int wino_conv_launch(const StConvDesc& d, hipStream_t stream, bool narrow) {
   ST_REQUIRE(wino_conv_applicable(d), "winograd conv: shape not supported (3x3 s1 p1, Cin % 4 == 0, Cout a multiple of 32 "
                                       "or <= 64, transformed weights required)");
   ST_REQUIRE(d.in_dev && d.bias_dev && d.out1_dev, "winograd conv: null pointer");
   ST_REQUIRE(d.in_off + d.Cin <= d.in_ld && d.out1_off + d.Cout <= d.out1_ld, "winograd conv: channel slice exceeds ld");
   if (d.res_dev) ST_REQUIRE(d.res_off + d.Cout <= d.res_ld, "winograd conv: res slice exceeds res_ld");
   const long long M = (long long)d.N * d.Hi * d.Wi;
-  const int cbn = wino_cbn(d.Cout), CB = 32 * cbn;
+  const int lcbn = wino_cbn(d.Cout);
+  ST_REQUIRE(!narrow || (lcbn == 2 && d.Cout % 64 == 0), "winograd conv: the narrow instance needs Cout %% 64 == 0");
+  const int cbn = narrow ? 1 : lcbn, CB = 32 * cbn;
   WinoArgs a;
   a.in = d.in_dev; a.wino = d.wgt_wino_dev; a.bias = d.bias_dev; a.out = d.out1_dev; a.res = d.res_dev;
   a.N = d.N; a.H = d.Hi; a.W = d.Wi; a.Cin = d.Cin; a.in_ld = d.in_ld; a.in_off = d.in_off; a.Cout = d.Cout;
@@ -333,10 +341,12 @@ int wino_conv_launch(const StConvDesc& d, hipStream_t stream) {
   const long long blocks = (long long)d.N * a.tbx * a.tby * a.ncb;
   ST_REQUIRE(blocks < (1ll << 31), "winograd conv: grid too large");
   int rc;
-  if (cbn == 2) rc = d.res_dev ? wino_launch_instance<2, true>(a, (unsigned)blocks, stream)
-                               : wino_launch_instance<2, false>(a, (unsigned)blocks, stream);
-  else rc = d.res_dev ? wino_launch_instance<1, true>(a, (unsigned)blocks, stream)
-                      : wino_launch_instance<1, false>(a, (unsigned)blocks, stream);
+  if (cbn == 2) rc = d.res_dev ? wino_launch_instance<2, 2, true>(a, (unsigned)blocks, stream)
+                               : wino_launch_instance<2, 2, false>(a, (unsigned)blocks, stream);
+  else if (lcbn == 2) rc = d.res_dev ? wino_launch_instance<1, 2, true>(a, (unsigned)blocks, stream)
+                                     : wino_launch_instance<1, 2, false>(a, (unsigned)blocks, stream);
+  else rc = d.res_dev ? wino_launch_instance<1, 1, true>(a, (unsigned)blocks, stream)
+                      : wino_launch_instance<1, 1, false>(a, (unsigned)blocks, stream);
   ST_CHECK(rc);
   ST_CHECK_HIP(hipGetLastError());
   return ST_OK;

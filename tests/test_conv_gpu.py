@@ -46,7 +46,7 @@ def run_conv(x_nchw, w, bias, stride, pad, act, dev, variant=-1, res=None, post_
     d.wgt_dev = wp.data_ptr(); d.bias_dev = bp.data_ptr()
     d.Cout, d.KH, d.KW, d.stride, d.pad = Cout, KH, KW, stride, pad
     wino = None
-    if variant == 43:   # Winograd instance: the same folded weights in transformed, fragment-ordered form
+    if variant in (43, 44):   # Winograd instances: the same folded weights in transformed, fragment-ordered form
         wino = torch.empty(lib.st_wino_packed_floats(Cout, Cin), dtype=torch.float32)
         wp_host = wp.cpu()   # keep alive: ptr() does not hold a reference
         check(lib.st_wino_pack_weights(ptr(wp_host), Cout, Cin, ptr(wino)), 'st_wino_pack_weights')
@@ -424,6 +424,10 @@ def test_winograd_conv_matches_direct_convolution(cin, cout, res, act, shape, in
     base, _ = run_conv(x, w, b, 1, 1, act, cuda, variant=4, res=r, post_scale=0.5 if res else 1.0, in_ld=in_ld,
                        in_off=in_off)
     assert_close(got, base.double(), tol=2e-5)
+    if cout % 64 == 0:   # variant 44: the same layout computed by 32-cout workgroups - bit-identical to variant 43
+        narrow, _ = run_conv(x, w, b, 1, 1, act, cuda, variant=44, res=r, post_scale=0.5 if res else 1.0, in_ld=in_ld,
+                             in_off=in_off)
+        assert torch.equal(narrow, got)
 
 
 def test_winograd_instance_needs_its_weights_and_shapes(stlib, cuda):
