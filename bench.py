@@ -232,7 +232,8 @@ def costvolume_fullres(lib, reps=5):
             ms.append(e0.elapsed_time(e1))
         us = sorted(ms[1:])[len(ms[1:]) // 2] * 1e3
         nbytes = 4.0 * Hf * Wf * (2 * Cf + D)
-        return dict(bound='hbm', kernel='st::costvolume_kernel', unit='GB/s', peak=8000.0, cells=Hf * Wf * D,
+        return dict(bound='hbm', kernel='st::costvolume_tiled_kernel<24> x 2 slabs of 96 disparities', unit='GB/s',
+                    peak=8000.0, cells=Hf * Wf * D,
                     bytes_per_launch=int(nbytes), launch_us=round(us, 1), achieved=round(nbytes / (us * 1e-6) / 1e9, 1),
                     frac=round(nbytes / (us * 1e-6) / 8e12, 4),
                     workload='1 pair, full-resolution volume D=192 x 720 x 1280 from C=8 features (kernel only)')

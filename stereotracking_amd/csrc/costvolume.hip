@@ -152,7 +152,9 @@ __global__ __launch_bounds__(128) void costvolume_tiled_kernel(const float* __re
                                                                const float* __restrict__ featR, int Hf, int Wf,
                                                                int C, int ld, int D, float temperature, int rowL,
                                                                int rowR, float* __restrict__ out_cost,
-                                                               float* __restrict__ out_disp) {
+                                                               float* __restrict__ out_disp, int dbase) {
+  // dbase: first disparity of this launch's slab [dbase, dbase + 4*DG) - wide volumes (D > 128) are materialised
+  // slab by slab (the fused soft-argmin needs all of D in one launch: out_disp must be null when dbase > 0)
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int bufsz = CVT_CC * (rowL + rowR);   // two buffers: [CVT_CC][rowL] + [CVT_CC][rowR] each
   const int x0 = blockIdx.x * CVT_TX;
@@ -161,9 +163,10 @@ __global__ __launch_bounds__(128) void costvolume_tiled_kernel(const float* __re
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int dg = lane >> 4, pgi = lane & 15;
   const int px0 = wave * 64 + 4 * pgi;   // first of this lane's 4 pixels (block-relative)
-  const int d0 = dg * DG;
+  const int dl = dg * DG;                // this lane group's first disparity inside the slab
+  const int d0 = dbase + dl;
   constexpr int NW = DG + 4;             // floats of the R window: x' = x - d0 - DG + i, i = 0 .. DG+3
-  constexpr int RW = CVT_TX + 4 * DG;    // R columns of the block: column j <-> x' = x0 - 4*DG + j
+  constexpr int RW = CVT_TX + 4 * DG;    // R columns of the block: column j <-> x' = x0 - dbase - 4*DG + j
   constexpr int RW16 = (RW + 15) & ~15;
   constexpr int CC4 = CVT_CC / 4;
   constexpr int NL = CVT_TX * CC4 / 128, NR = (RW16 * CC4 + 127) / 128;   // float4 per thread per chunk
@@ -194,7 +197,7 @@ __global__ __launch_bounds__(128) void costvolume_tiled_kernel(const float* __re
     for (int i = 0; i < NR; ++i) {
       const int e = tid + 128 * i;
       const int j = (e & 15) + 16 * (e / (16 * CC4)), c4 = (e >> 4) % CC4;
-      const int x = x0 - 4 * DG + j;
+      const int x = x0 - dbase - 4 * DG + j;
       stR[i] = f32x4{0.f, 0.f, 0.f, 0.f};
       if (c4 < cc4 && j < RW && x >= 0 && x < Wf)
         stR[i] = *reinterpret_cast<const f32x4*>(featR + (rowbase + x) * ld + cb + 4 * c4);
@@ -230,7 +233,7 @@ __global__ __launch_bounds__(128) void costvolume_tiled_kernel(const float* __re
     const bool more = cb + CVT_CC < C;
     if (more) stage_load(cb + CVT_CC);   // in flight during the FMAs below
     const float* lp = smem + buf * bufsz + px0;
-    const float* rp = smem + buf * bufsz + CVT_CC * rowL + px0 + 4 * DG - d0 - DG;   // window start (multiple of 4)
+    const float* rp = smem + buf * bufsz + CVT_CC * rowL + px0 + 4 * DG - dl - DG;   // window start (multiple of 4)
     // ---- accumulate this chunk, operands of channel c+1 prefetched while channel c multiplies
     f32x4 lv[2], rv[2][NW / 4];
     lv[0] = *reinterpret_cast<const f32x4*>(lp);
@@ -423,7 +426,16 @@ extern "C" int st_costvolume_softargmin(const float* featL_dev, const float* fea
   ST_REQUIRE(Hf <= 65535 && N <= 65535, "st_costvolume_softargmin: grid too large");
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   // register-tiled kernel: DG (disparities per lane, 4 lanes share a pixel quad) a multiple of 4, up to 32
-  const int dgt = round_up((D + 3) / 4, 4);
+  int dgt = round_up((D + 3) / 4, 4);
+  // volumes wider than the 128 disparities one launch of the tiled kernel covers are MATERIALISED in equal slabs of
+  // <= 128 (e.g. the full-resolution sizing D = 192 = 2 x 96); with a fused soft-argmin (out_disp) they take the
+  // generic kernel below, which sees all of D at once
+  int slabs = 1;
+  if (dgt > 32 && out_cost_dev && !out_disp_dev && D % 16 == 0) {
+    slabs = ceil_div(D, 128);
+    while (D % (16 * slabs)) ++slabs;
+    dgt = D / slabs / 4;
+  }
   if (dgt <= 32 && (out_cost_dev == nullptr || (reinterpret_cast<uintptr_t>(out_cost_dev) & 15) == 0)) {
     const int rowLt = cvt_row(CVT_TX), rowRt = cvt_row(CVT_TX + 4 * dgt);
     const size_t ldst = (size_t)2 * CVT_CC * (rowLt + rowRt) * sizeof(float);
@@ -433,8 +445,9 @@ extern "C" int st_costvolume_softargmin(const float* featL_dev, const float* fea
     auto kern = costvolume_tiled_kernel<DGV>;                                                                  \
     static int lds_set = 0;                                                                                    \
     ST_ENSURE_DYNAMIC_LDS(kern, ldst, lds_set);                                                                \
-    hipLaunchKernelGGL(kern, gridt, blockt, ldst, stream, featL_dev, featR_dev, Hf, Wf, C, feat_ld, D,         \
-                       temperature, rowLt, rowRt, out_cost_dev, out_disp_dev);                                 \
+    for (int sl = 0; sl < slabs; ++sl)                                                                         \
+      hipLaunchKernelGGL(kern, gridt, blockt, ldst, stream, featL_dev, featR_dev, Hf, Wf, C, feat_ld, D,       \
+                         temperature, rowLt, rowRt, out_cost_dev, out_disp_dev, sl * 4 * DGV);                 \
   } while (0)
     switch (dgt) {
       case 4: ST_CVT_LAUNCH(4); break;

@@ -876,7 +876,9 @@ extern "C" int st_detector_autotune(StDetector* det, void* workspace_dev, size_t
         ms = std::min(ms, t);
       }
       if (rc != ST_OK) break;
-      if (ms < best) { best = ms; best_v = v; }
+      // hysteresis: a later candidate must win by 3 % (min-of-N timings of near-equal kernels are noise: the choice
+      // should not flip between runs, and the tuned plan stays comparable from run to run)
+      if (best_v < 0 || ms < best * 0.97f) { best = ms; best_v = v; }
     }
     saved[oi].tuned = best_v;
   }

@@ -58,6 +58,7 @@ struct WinoArgs {
   int act;
   int tbx, tby, ncb, nkc;
   unsigned in_bytes, out_bytes, res_bytes, wino_bytes;
+  int abl;   // tools-only (ST_ABLATION): 1 = weight fragments loaded once, 2 = window DMA once, 3 = both (wrong results)
 };
 
 __device__ __forceinline__ float wn_silu(float v) { return v * __builtin_amdgcn_rcpf(1.0f + __expf(-v)); }
@@ -138,6 +139,9 @@ __global__ __launch_bounds__(256, 2) void wino_conv3x3_kernel(const WinoArgs p) 
   const unsigned wbase = (unsigned)(((((cb / SPLIT) * 4 + a) * p.nkc) * 16) * WN_FRAG_FLOATS + (cb % SPLIT) * CBN * 256 +
                                     lane * 4) * 4u;
   auto load_frag = [&](int step, f32x4 (&f)[CBN]) {   // step = (kc * 4 + g) * 4 + b ; past the end: zeros
+#ifdef ST_ABLATION
+    if ((p.abl & 1) && step > 1) return;
+#endif
     const unsigned off = wbase + (unsigned)step * (WN_FRAG_FLOATS * 4u);
 #pragma unroll
     for (int nb = 0; nb < CBN; ++nb)
@@ -160,7 +164,11 @@ __global__ __launch_bounds__(256, 2) void wino_conv3x3_kernel(const WinoArgs p) 
 
   for (int kc = 0; kc < p.nkc; ++kc) {
     const int buf = kc & 1;
+#ifdef ST_ABLATION
+    if (kc + 1 < p.nkc && !(p.abl & 2)) dma_window(kc + 1, buf ^ 1);
+#else
     if (kc + 1 < p.nkc) dma_window(kc + 1, buf ^ 1);   // lands during this chunk's 128 MFMAs
+#endif
     const float* win = smem + buf * WN_WIN_FLOATS;
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
@@ -338,6 +346,10 @@ int wino_conv_launch(const StConvDesc& d, hipStream_t stream, bool narrow) {
   a.out_bytes = (unsigned)(M * d.out1_ld * 4);
   a.res_bytes = d.res_dev ? (unsigned)(M * d.res_ld * 4) : 0u;
   a.wino_bytes = (unsigned)(wino_packed_floats(d.Cout, d.Cin) * 4);
+  a.abl = 0;
+#ifdef ST_ABLATION
+  if (const char* e = getenv("ST_WN_ABL")) a.abl = atoi(e);
+#endif
   const long long blocks = (long long)d.N * a.tbx * a.tby * a.ncb;
   ST_REQUIRE(blocks < (1ll << 31), "winograd conv: grid too large");
   int rc;

@@ -129,7 +129,7 @@ class StereoCostVolume(nn.Module):
                 e1.record()
                 e1.synchronize()
                 ms = min(ms, e0.elapsed_time(e1))
-            if ms < best_ms:
+            if best < 0 or ms < best_ms * 0.97:   # 3 % hysteresis, as st_detector_autotune
                 best, best_ms = int(v), ms
         self.variant = best
         return best

@@ -54,6 +54,23 @@ def test_costvolume_bit_exact_and_softargmin(N, Hf, Wf, Cc, ld, D, cuda):
     assert np.array_equal(o.cpu().numpy().view(np.uint32), ref_disp.view(np.uint32))
 
 
+@pytest.mark.parametrize('N,Hf,Wf,Cc,D', [(1, 3, 300, 8, 192), (2, 2, 210, 16, 160), (1, 2, 260, 24, 256)])
+def test_wide_volume_materialised_in_slabs_is_bit_exact(N, Hf, Wf, Cc, D, cuda):
+    """SURVEY.md §8(d)'s full-resolution sizing (D = 192 levels): volumes wider than the 128 disparities one launch of the
+    tiled kernel covers are MATERIALISED slab by slab (st_costvolume_softargmin with out_disp = NULL); every slab must be
+    the same fmaf chain as the oracle, including the x - d < 0 zeros that straddle slab borders."""
+    rng = np.random.RandomState(D)
+    fl = rng.normal(0, 1, (N, Hf, Wf, Cc)).astype(np.float32)
+    fr = rng.normal(0, 1, (N, Hf, Wf, Cc)).astype(np.float32)
+    ref = c_oracle.costvolume(fl, fr, Cc, D)
+    lib = _lib.load()
+    l, r = torch.from_numpy(fl).to(cuda), torch.from_numpy(fr).to(cuda)
+    cost = torch.full((N, Hf, Wf, D), float('nan'), device=cuda)
+    check(lib.st_costvolume_softargmin(ptr(l), ptr(r), N, Hf, Wf, Cc, Cc, D, 1.0, ptr(cost), None, current_stream()))
+    torch.cuda.synchronize()
+    assert np.array_equal(cost.cpu().numpy().view(np.uint32), ref.view(np.uint32))
+
+
 def test_costvolume_recovers_known_shift(cuda):
     """Right = left shifted by a constant disparity: soft-argmin with a sharp temperature returns it."""
     rng = np.random.RandomState(3)
