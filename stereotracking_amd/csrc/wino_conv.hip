@@ -174,6 +174,12 @@ __global__ __launch_bounds__(256, 2) void wino_conv3x3_kernel(const WinoArgs p) 
     for (int g = 0; g < 4; ++g) {
       // raw patch -> V[a][0..3] for this lane's 4 channels (8g + 4h .. + 3)
       f32x4 d[8];
+#ifdef ST_ABLATION
+      if (p.abl & 8) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) d[k] = f32x4{1.f, 2.f, 3.f, (float)(k + g)};
+      } else
+#endif
 #pragma unroll
       for (int k = 0; k < 8; ++k)
         d[k] = *reinterpret_cast<const f32x4*>(win + qoff[k] + (((2 * g + h) ^ qsw[k]) << 2));
@@ -200,6 +206,19 @@ __global__ __launch_bounds__(256, 2) void wino_conv3x3_kernel(const WinoArgs p) 
     __syncthreads();
   }
 
+#ifdef ST_ABLATION
+  if (p.abl & 4) {   // no epilogue: one store per lane keeps the accumulators alive
+    float v = 0.f;
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+#pragma unroll
+      for (int nb = 0; nb < CBN; ++nb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v += acc[b][nb][r];
+    if (v == 12345.678f) p.out[tid] = v;
+    return;
+  }
+#endif
   // ---- output transform.  Row reduction over b in registers: R[0] = M0 + M1 + M2, R[1] = M1 - M2 - M3
   float* Rb = smem;   // [a][j][tile][co]: every wave is past its last window read (barrier above)
 #pragma unroll
@@ -213,12 +232,14 @@ __global__ __launch_bounds__(256, 2) void wino_conv3x3_kernel(const WinoArgs p) 
       Rb[((a * 2 + 1) * 32 + m) * WN_CB + nb * 32 + i] = R1;
     }
   __syncthreads();
-  // column reduction over a + epilogue: wave w takes tiles 8w .. 8w+7 (= tile row w); lane = cout (CB = 64), or
-  // (tile parity, cout) when a workgroup owns 32 couts
-  constexpr int TPI = 64 / WN_CB;                 // tiles handled per iteration by one wave
-  const int col = lane % WN_CB, tsel = lane / WN_CB;
-  const int co = cb * WN_CB + col;
-  const float bias = p.bias[co];
+  // column reduction over a + epilogue: wave w takes tiles 8w .. 8w+7 (= tile row w).  A lane owns 4 consecutive couts
+  // of one tile: 16-byte LDS reads, residual loads and NHWC stores (WN_CB / 4 lanes per tile, 64 / that tiles per pass)
+  constexpr int LPT = WN_CB / 4;                  // lanes per tile: 16 (64 couts) or 8 (32 couts)
+  constexpr int TPI = 64 / LPT;                   // tiles per pass: 4 or 8
+  const int c4 = (lane % LPT) * 4, tsel = lane / LPT;
+  const int co = cb * WN_CB + c4;
+  const f32x4 bias4 = *reinterpret_cast<const f32x4*>(p.bias + co);
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 #pragma unroll
   for (int t8 = 0; t8 < 8; t8 += TPI) {
     const int txo = t8 + tsel;
@@ -226,22 +247,28 @@ __global__ __launch_bounds__(256, 2) void wino_conv3x3_kernel(const WinoArgs p) 
     const int oy0 = by * (2 * WN_TY) + 2 * a, ox0 = bx * (2 * WN_TX) + 2 * txo;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-      const float q0 = Rb[((0 * 2 + j) * 32 + t) * WN_CB + col], q1 = Rb[((1 * 2 + j) * 32 + t) * WN_CB + col];
-      const float q2 = Rb[((2 * 2 + j) * 32 + t) * WN_CB + col], q3 = Rb[((3 * 2 + j) * 32 + t) * WN_CB + col];
-      const float y[2] = {(q0 + q1) + q2, (q1 - q2) - q3};
+      const f32x4 q0 = *reinterpret_cast<const f32x4*>(Rb + ((0 * 2 + j) * 32 + t) * WN_CB + c4);
+      const f32x4 q1 = *reinterpret_cast<const f32x4*>(Rb + ((1 * 2 + j) * 32 + t) * WN_CB + c4);
+      const f32x4 q2 = *reinterpret_cast<const f32x4*>(Rb + ((2 * 2 + j) * 32 + t) * WN_CB + c4);
+      const f32x4 q3 = *reinterpret_cast<const f32x4*>(Rb + ((3 * 2 + j) * 32 + t) * WN_CB + c4);
+      const f32x4 y[2] = {(q0 + q1) + q2, (q1 - q2) - q3};
 #pragma unroll
       for (int ii = 0; ii < 2; ++ii) {
         const int oy = oy0 + ii, ox = ox0 + j;
-        const bool ok = oy < p.H && ox < p.W && co < p.Cout;
+        const bool ok = oy < p.H && ox < p.W && co < p.Cout;   // Cout is a multiple of 4: a quad is in or out as a whole
         const int m = (n * p.H + oy) * p.W + ox;
-        float v = y[ii] + bias;
-        if (p.act) v = wn_silu(v);
+        f32x4 v = y[ii] + bias4;
+        if (p.act) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = wn_silu(v[e]);
+        }
         if (RES) {
           const unsigned roff = ok ? (unsigned)((m * p.res_ld + p.res_off + co) * 4) : 0x80000000u;
-          v = (v + __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rrsrc, roff, 0, 0))) * p.post_scale;
+          const f32x4 rv = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rrsrc, roff, 0, 0));
+          v = (v + rv) * p.post_scale;
         }
         const unsigned off = ok ? (unsigned)((m * p.out_ld + p.out_off + co) * 4) : 0x80000000u;
-        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), orsrc, off, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), orsrc, off, 0, 0);
       }
     }
   }
@@ -305,8 +332,10 @@ bool wino_conv_applicable(const StConvDesc& d) {
   if (!d.wgt_wino_dev) return false;
   if (d.KH != 3 || d.KW != 3 || d.stride != 1 || d.pad != 1 || d.up_dev || d.out2_dev) return false;
   if (!wino_shape_ok(d.Cin, d.Cout)) return false;
-  if ((d.in_ld | d.in_off) & 3) return false;
-  if (reinterpret_cast<uintptr_t>(d.in_dev) & 15) return false;
+  if ((d.in_ld | d.in_off | d.out1_ld | d.out1_off) & 3) return false;
+  if ((reinterpret_cast<uintptr_t>(d.in_dev) | reinterpret_cast<uintptr_t>(d.out1_dev)) & 15) return false;
+  if (d.res_dev && (((d.res_ld | d.res_off) & 3) || (reinterpret_cast<uintptr_t>(d.res_dev) & 15))) return false;
+  if (d.Cout % 4) return false;
   const long long M = (long long)d.N * d.Hi * d.Wi, lim = 1ll << 31;
   if (M * d.in_ld * 4 >= lim || M * d.out1_ld * 4 >= lim) return false;
   if (d.res_dev && M * d.res_ld * 4 >= lim) return false;
