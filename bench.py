@@ -332,7 +332,7 @@ def test_step_leg(args, sd, batch_cpu, dev, pairs_target):
     for _ in range(2):
         outs = call()
     torch.cuda.synchronize()
-    model.timings.update(frames=0, tracker_s=0.0, host_s=0.0, wait_s=0.0, pre_s=0.0)
+    model.timings.update(frames=0, tracker_s=0.0, host_s=0.0, wait_s=0.0, pre_s=0.0, tail_s=0.0, submit_s=0.0, depth_s=0.0)
     calls = max(2, -(-pairs_target // F))
     t0 = time.perf_counter()
     for _ in range(calls):
@@ -345,7 +345,11 @@ def test_step_leg(args, sd, batch_cpu, dev, pairs_target):
                 path='Config.fromfile(stereo_yolox_s_mot_airdrone_costvolume.py) -> MODELS.build -> model.test_step',
                 tracker_ms_per_frame=round(tm['tracker_s'] / max(tm['frames'], 1) * 1e3, 4),
                 host_ms_per_call=dict(preprocessor=round(tm['pre_s'] / calls * 1e3, 3), predict=round(tm['host_s'] / calls * 1e3, 3),
-                                      of_which_waiting_for_gpu=round(tm['wait_s'] / calls * 1e3, 3)),
+                                      of_which_waiting_for_gpu=round(tm['wait_s'] / calls * 1e3, 3),
+                                      submitting_chunks=round(tm['submit_s'] / calls * 1e3, 3),
+                                      association=round(tm['tracker_s'] / calls * 1e3, 3),
+                                      track_depth_launches=round(tm['depth_s'] / calls * 1e3, 3),
+                                      after_last_chunk_left_the_gpu=round(tm['tail_s'] / calls * 1e3, 3)),
                 tracks_last_frame=int(len(outs[-1].pred_track_instances)),
                 detections_last_frame=int(len(outs[-1].pred_det_instances)),
                 note='includes the preprocessor (uint8 -> fp32, pad, stack), the dense path on the model\'s in-flight '

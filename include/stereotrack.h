@@ -103,6 +103,17 @@ int st_wino_pack_weights(const float* packed_wgt_host, int Cout, int Cin, float*
  * DarknetBottleneck conv1 pair (mmdet CSPLayer, built at csp_darknet_disparity_v1.py:113-153).  a's outputs are
  * written as usual; b's in_dev / in_ld / in_off are ignored (its input never leaves the registers). */
 int st_conv1x1_chain(const StConvDesc* a, const StConvDesc* b, st_stream_t stream);
+/* Fused head of a stage-1 CSP branch: `a` = 3x3 / stride-2 / pad-1 ConvModule 32 -> 64 (its own output tensor is never
+ * written: a->out1_dev is ignored), `ms` = CSPLayer main_conv | short_conv on a's output (1x1, 64 -> 32 | 32, split
+ * store to ms->out1 / ms->out2), `c1` = DarknetBottleneck conv1 on the main half (1x1, 32 -> 32, to c1->out1).  One
+ * launch instead of three; the 64-channel stride-2 tensor stays in MFMA accumulators.  Replaces the module sequence
+ * csp_darknet_disparity_v1.py:113-153 builds for `stage1` / `disp_stage1` (ConvModule(c, 2c, 3, stride=2) followed by
+ * mmdet CSPLayer) as run at :176-183.  All three: SiLU, no residual / upsample store / post_scale.  frag_*_dev =
+ * st_front_pack_frags of the ms / c1 packed weight matrices (device copies).  ST_ERR_INVALID when the shapes differ. */
+size_t st_front_frag_floats(int Cout, int Cin);
+int st_front_pack_frags(const float* packed_wgt_host, int Cout, int Cin, float* out_host);
+int st_conv3x3s2_csp_front(const StConvDesc* a, const StConvDesc* ms, const StConvDesc* c1, const float* frag_ms_dev,
+                           const float* frag_c1_dev, st_stream_t stream);
 size_t st_conv_packed_floats(int Cout, int Cin, int KH, int KW);
 int st_conv_pack_weights(const float* w, const float* conv_bias, /* may be NULL */
                          const float* bn_gamma, const float* bn_beta,

@@ -19,6 +19,7 @@
 //   * branch average (rgb + disp)/2                      -> epilogue of disp_stage1's final conv
 //   * head cls-tower conv0 + reg-tower conv0             -> one conv, split store
 //   * head conv_reg + conv_obj                           -> one conv
+//   * stage1.0 (3x3/s2) + stage1.1 main|short + blocks.0.conv1 of both branches -> one launch (front_fused.hip)
 #include <algorithm>
 #include <cmath>
 #include <cstring>
@@ -39,6 +40,11 @@ bool wino_shape_ok(int Cin, int Cout);
 size_t wino_packed_floats(int Cout, int Cin);
 int wino_pack_weights(const float* packed, int Cout, int Cin, float* out);
 int pw_conv_launch(const StConvDesc& d, hipStream_t stream, const StConvDesc* chain);
+bool front_fused_applicable(const StConvDesc& a, const StConvDesc& ms, const StConvDesc& c1);
+int front_fused_launch(const StConvDesc& a, const StConvDesc& ms, const StConvDesc& c1, const float* frag_ms_dev,
+                       const float* frag_c1_dev, hipStream_t stream);
+size_t front_frag_floats(int Cout, int Cin);
+int front_pack_frags(const float* packed, int Cout, int Cin, float* out);
 int conv_variant_count();
 bool conv_variant_valid(int id, int cout);
 const char* conv_variant_name(int id);
@@ -86,6 +92,8 @@ struct PackedConv {
   size_t wgt_off = 0, bias_off = 0;  // float offsets inside the packed weight arena
   size_t wino_off = 0;               // Winograd-form copy of the weights (3x3 / stride-1 users only), 0 = none
   bool wino = false;
+  size_t frag_off = 0;               // MFMA-fragment-ordered copy of a 1x1 weight matrix (fused front kernel), 0 = none
+  bool frag = false;
   bool stem = false;                 // fused Focus+stem layout (st_stem_pack_weights), cin = 12, k = 3
   int stem_planes = 3;               // image planes the fused stem reads (1: identical planes, summed weights)
 };
@@ -127,6 +135,8 @@ struct Op {
   int group = 0;       // sub-batch group (0 = whole batch in one launch)
   bool chain_next = false;  // the NEXT op is a 1x1 conv on this op's out1 (CSP main_conv -> bottleneck conv1):
                             // when both run on the streaming kernel (variant 41) they are launched as one
+  bool front_next2 = false; // this 3x3/s2 conv and the NEXT TWO ops (CSP main|short, blocks.0.conv1) are one launch
+                            // of front_fused.hip (variant 45) whenever the three descriptors qualify
 };
 
 }  // namespace
@@ -160,6 +170,7 @@ struct StDetector {
   int force_variant = -1;          // autotune only
   bool no_wino = false;            // keep the autotuner off the Winograd instance (exact-MFMA-order A/B runs)
   bool allow_chain = true;         // fuse CSP main_conv -> bottleneck conv1 when both run on the streaming kernel
+  bool allow_front = true;         // fuse stage1.0 -> main|short -> conv1 (front_fused.hip)
 #ifdef ST_ABLATION
   std::vector<char> skip;          // tools-only: ops whose launches are dropped (st_detector_set_skip)
 #endif
@@ -294,10 +305,20 @@ struct StDetector {
     const int pc = packed_convmodules({p + ".main_conv", p + ".short_conv"}, x.C, {mid, mid}, 1);
     op_conv(pc, x, 1, mainb, mid, cat.slice(mid, mid));
     if (nblocks > 0 && mid == 32) ops.back().chain_next = true;   // main_conv -> blocks.0.conv1 (reads mainb)
+    // stage-1 shape (32 -> 64 -> 32|32 -> 32): a preceding 3x3/s2 ConvModule can take both 1x1 convs along
+    const bool frontable = nblocks > 0 && mid == 32 && x.C == 64 && ops.size() >= 2 && ops[ops.size() - 2].type == Op::CONV &&
+                           convs[ops[ops.size() - 2].pc].k == 3 && ops[ops.size() - 2].stride == 2 &&
+                           convs[ops[ops.size() - 2].pc].cin == 32 && ops[ops.size() - 2].out1.buf == x.buf &&
+                           ops[ops.size() - 2].group == cur_group && ops[ops.size() - 2].phase == cur_phase;
+    if (frontable) {
+      ops[ops.size() - 2].front_next2 = true;
+      convs[pc].frag = true;
+    }
     TRef tmp = new_tensor(x.N, x.H, x.W, mid);
     for (int b = 0; b < nblocks; ++b) {
       const std::string bp = p + ".blocks." + std::to_string(b);
       const int pc1 = packed_convmodules({bp + ".conv1"}, mid, {mid}, 1);
+      if (b == 0 && frontable) convs[pc1].frag = true;
       op_conv(pc1, mainb, 1, tmp);
       const int pc2 = packed_convmodules({bp + ".conv2"}, mid, {mid}, 3);
       const bool last = b == nblocks - 1;
@@ -338,6 +359,7 @@ int StDetector::build() {
   bool fused_stem = c1 <= 64;
 #ifdef ST_ABLATION   // tools-only build: ST_NO_FUSED_STEM=1 forces the two-kernel path (A/B measurements)
   if (getenv("ST_NO_FUSED_STEM")) fused_stem = false;
+  if (getenv("ST_NO_FUSED_FRONT")) allow_front = false;
 #endif
   TRef packed_rgb, stem_rgb;
   if (fused_stem) {
@@ -488,6 +510,11 @@ int StDetector::build() {
       wgt_floats += wino_packed_floats(pc.cout, pc.cin);
       wgt_floats = (wgt_floats + 63) & ~(size_t)63;
     }
+    if (pc.frag) {
+      pc.frag_off = wgt_floats;
+      wgt_floats += front_frag_floats(pc.cout, pc.cin);
+      wgt_floats = (wgt_floats + 63) & ~(size_t)63;
+    }
   }
   return ST_OK;
 }
@@ -576,6 +603,7 @@ extern "C" int st_detector_finalize(StDetector* det) {
       row += s.cout;
     }
     if (pc.wino) ST_CHECK(wino_pack_weights(host.data() + pc.wgt_off, pc.cout, pc.cin, host.data() + pc.wino_off));
+    if (pc.frag) ST_CHECK(front_pack_frags(host.data() + pc.wgt_off, pc.cout, pc.cin, host.data() + pc.frag_off));
   }
   if (!det->wgt_dev) ST_CHECK_HIP(hipMalloc(reinterpret_cast<void**>(&det->wgt_dev), det->wgt_floats * sizeof(float)));
   ST_CHECK_HIP(hipMemcpy(det->wgt_dev, host.data(), det->wgt_floats * sizeof(float), hipMemcpyHostToDevice));
@@ -681,7 +709,7 @@ int run_ops(StDetector* det, int phase_lo, int phase_hi, const float* const inpu
       while (oe < nops && det->ops[oe].group == first.group && det->ops[oe].phase == first.phase) ++oe;
     const StDetector::Group g = det->groups[first.group];
     for (int sbi = 0; sbi < g.count; ++sbi) {
-      bool chain_done = false;
+      int fused_left = 0, fused_variant = 0;   // ops already computed by a preceding fused launch
       for (size_t k = oi; k < oe; ++k) {
         Op& o = det->ops[k];
         if (det->timing) ST_CHECK_HIP(hipEventRecord(det->events[ev_per_op * k + 2 * sbi], stream));
@@ -691,18 +719,31 @@ int run_ops(StDetector* det, int phase_lo, int phase_hi, const float* const inpu
         constexpr bool skipped = false;
 #endif
         bool chained = false;
-        if (!skipped && chain_done) {   // this op was computed by the previous (chained) launch
-          chain_done = false;
-          o.variant = 41;
+        if (!skipped && fused_left > 0) {   // this op was computed by a previous (chained / fused) launch
+          --fused_left;
+          o.variant = fused_variant;
           chained = true;
-        } else if (!skipped && o.type == Op::CONV && o.chain_next && k + 1 < oe && det->force_variant < 0 &&
+        } else if (!skipped && o.type == Op::CONV && o.front_next2 && k + 2 < oe && det->force_variant < 0 &&
+                   det->allow_front && det->convs[det->ops[k + 1].pc].frag && det->convs[det->ops[k + 2].pc].frag) {
+          const StConvDesc da = conv_desc(det, o, sbi * g.sb, ws, head);
+          const StConvDesc dm = conv_desc(det, det->ops[k + 1], sbi * g.sb, ws, head);
+          const StConvDesc dc = conv_desc(det, det->ops[k + 2], sbi * g.sb, ws, head);
+          if (front_fused_applicable(da, dm, dc)) {
+            ST_CHECK(front_fused_launch(da, dm, dc, det->wgt_dev + det->convs[det->ops[k + 1].pc].frag_off,
+                                        det->wgt_dev + det->convs[det->ops[k + 2].pc].frag_off, stream));
+            o.variant = fused_variant = 45;
+            fused_left = 2;
+            chained = true;
+          }
+        }
+        if (!chained && !skipped && o.type == Op::CONV && o.chain_next && k + 1 < oe && det->force_variant < 0 &&
                    o.tuned == 41 && det->ops[k + 1].tuned == 41 && det->allow_chain) {
           const StConvDesc da = conv_desc(det, o, sbi * g.sb, ws, head);
           const StConvDesc db = conv_desc(det, det->ops[k + 1], sbi * g.sb, ws, head);
           if (pw_chain_applicable(da, db)) {
             ST_CHECK(pw_conv_launch(da, stream, &db));
-            o.variant = 41;
-            chain_done = true;
+            o.variant = fused_variant = 41;
+            fused_left = 1;
             chained = true;
           }
         }
@@ -893,10 +934,10 @@ extern "C" int st_detector_autotune(StDetector* det, void* workspace_dev, size_t
 // id 40 = the fused Focus+stem kernel (stem_focus_conv.hip), reported with the conv ops
 // id 41 = the streaming 1x1 kernel for narrow layers (pointwise_conv.hip)
 extern "C" const char* st_conv_variant_name(int id) {
-  return id == 40 ? "stem6x6s2" : id == 41 ? "pw128" : id == 42 ? "dc4x32" : id == 43 ? "wino2x2" : id == 44 ? "wino2x2n" : conv_variant_name(id);
+  return id == 45 ? "front3x3s2" : id == 40 ? "stem6x6s2" : id == 41 ? "pw128" : id == 42 ? "dc4x32" : id == 43 ? "wino2x2" : id == 44 ? "wino2x2n" : conv_variant_name(id);
 }
 extern "C" const char* st_conv_variant_signature(int id) {
-  return id == 40 ? "stem_focus_conv" : id == 41 ? "pw_conv" : id == 42 ? "direct_conv3x3" : id == 43 ? "wino_conv3x3" : id == 44 ? "wino_conv3x3 narrow"
+  return id == 45 ? "front_s2_csp" : id == 40 ? "stem_focus_conv" : id == 41 ? "pw_conv" : id == 42 ? "direct_conv3x3" : id == 43 ? "wino_conv3x3" : id == 44 ? "wino_conv3x3 narrow"
                                                               : conv_variant_signature(id);
 }
 

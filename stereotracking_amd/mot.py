@@ -84,9 +84,20 @@ class TrackDataPreprocessor_Disparity_V1(nn.Module):
                 if d > 1:
                     H, W = (H + d - 1) // d * d, (W + d - 1) // d * d
                 T, Cc = imgs[0].shape[:2]
-                batch = torch.full((len(imgs), T, Cc, H, W), float(self.pad_value), dtype=torch.float32, device=dev)
-                for i, im in enumerate(imgs):
-                    batch[i, :, :, :im.shape[-2], :im.shape[-1]].copy_(im)
+                if len(set(pad_shapes)) == 1 and len({im.dtype for im in imgs}) == 1:
+                    # equal-sized frames (a video): one concatenation in the source dtype, one converting copy into
+                    # the padded batch, and the pad value written to the pad strips only
+                    h, w = pad_shapes[0]
+                    batch = torch.empty((len(imgs), T, Cc, H, W), dtype=torch.float32, device=dev)
+                    batch[..., :h, :w].copy_(torch.stack(imgs, dim=0))
+                    if h < H:
+                        batch[..., h:, :] = float(self.pad_value)
+                    if w < W:
+                        batch[..., :h, w:] = float(self.pad_value)
+                else:
+                    batch = torch.full((len(imgs), T, Cc, H, W), float(self.pad_value), dtype=torch.float32, device=dev)
+                    for i, im in enumerate(imgs):
+                        batch[i, :, :, :im.shape[-2], :im.shape[-1]].copy_(im)
                 out[key] = batch
             else:
                 if self.channel_conversion and imgs[0].size(1) == 3:
@@ -170,7 +181,8 @@ class OCSORT_Disparity(nn.Module):
         self.autotune, self.tuning_cache = bool(autotune), tuning_cache
         self.lib = _lib.load()
         self._dense = {}          # (batch, ori_h, ori_w, stereo) -> [InflightPipelines, weights version]
-        self.timings = dict(frames=0, tracker_s=0.0, host_s=0.0, wait_s=0.0, pre_s=0.0)   # cumulative host-side costs
+        self._staging = {}        # name -> pinned host buffer (grow-only): no pinned allocation on the per-chunk path
+        self.timings = dict(frames=0, tracker_s=0.0, host_s=0.0, wait_s=0.0, pre_s=0.0, tail_s=0.0, submit_s=0.0, depth_s=0.0)   # cumulative host-side costs
 
     # ---- reference plumbing (mot/base.py:68-113) -----------------------------------------------------
     def init_weights(self):
@@ -228,6 +240,19 @@ class OCSORT_Disparity(nn.Module):
             ent[0].load_state_dict(sd, autotune=self.autotune, tuning_cache=self.tuning_cache)
             ent[1] = ver
         return ent[0]
+
+    def _pinned(self, name, shape, dtype=torch.float32):
+        """View of a cached page-locked staging buffer.  Allocating pinned memory per chunk (hipHostMalloc) stalls the
+        host until the device is idle, which serialises the in-flight contexts; these buffers are allocated once and
+        grow only when a chunk needs more room."""
+        n = 1
+        for v in shape:
+            n *= int(v)
+        buf = self._staging.get(name)
+        if buf is None or buf.dtype != dtype or buf.numel() < n:
+            cap = max(256, 1 << max(n - 1, 1).bit_length())
+            buf = self._staging[name] = torch.empty(cap, dtype=dtype, pin_memory=True)
+        return buf[:n].view(*shape)
 
     # ---- per-box depth on the device (ocsort_disparity.py:113-175) -------------------------------------
     def bbox_postp_depth(self, pred_instances, disp, gt_depth=None):
@@ -301,26 +326,45 @@ class OCSORT_Disparity(nn.Module):
             return t
 
         def submit(ci):
+            ts = time.perf_counter()
             s, e = chunks[ci]
             a, b = padded(img, s, e), padded(second, s, e)
             holder = {}
 
             def post(out, ctx):   # under the context's stream: pack + start the ONE device->host copy of this chunk
                 rec = runner.pipes[ctx].pack_detections(out, scaled='both', n_real=e - s)
-                host = torch.empty(rec.shape, dtype=rec.dtype, pin_memory=True)
-                host.copy_(rec, non_blocking=True)
+                host = self._pinned(('records', id(runner), ctx), rec.shape, rec.dtype)   # free again: the chunk that
+                host.copy_(rec, non_blocking=True)                                     # used it was consumed
                 holder.update(ctx=ctx, disp=out['disp_postp'], host=host)
                 return out
             _, ev = runner.submit(a, right=b if stereo else None, disp_postp=None if stereo else b, post=post)
+            self.timings['submit_s'] += time.perf_counter() - ts
             return dict(s=s, e=e, ev=ev, **holder)
 
         jobs = {ci: submit(ci) for ci in range(min(len(chunks), len(runner)))}
         outs, pending = [None] * N, []
+        t_tail0 = time.perf_counter()
+
+        def finalize(entry):   # depth of the unscaled track boxes has arrived: complete the chunk's samples
+            s, e, tracks_of, dh, _ev2, _keep = entry
+            for i, tracks in enumerate(tracks_of):
+                k = len(tracks)
+                tracks['depth'] = dh[0, i, :k].clone()
+                tracks['gt_depth'] = dh[-1, i, :k].clone()   # = depth when no gt depth map was given (:104)
+                sample = data_samples[s + i]
+                if self.results_device == 'input':
+                    tracks = tracks.to(dev)
+                    sample.pred_det_instances = sample.pred_det_instances.to(dev)
+                sample.pred_track_instances = tracks
+                outs[s + i] = sample
+
         for ci in range(len(chunks)):
             job = jobs.pop(ci)
             tw = time.perf_counter()
             job['ev'].synchronize()                       # the only wait of this chunk's forward pass
             self.timings['wait_s'] += time.perf_counter() - tw
+            if ci == len(chunks) - 1:
+                t_tail0 = time.perf_counter()
             rec = job['host']
             s, e = job['s'], job['e']
             tracks_of = []
@@ -331,7 +375,7 @@ class OCSORT_Disparity(nn.Module):
                 if k > cap:
                     raise DetectionOverflow(f'frame {n}: {k} detections kept but the detection buffer has {cap} rows; '
                                             f'build the model with a larger max_det')
-                rows = r[1:1 + k]
+                rows = r[1:1 + k].clone()      # the staging buffer is reused by a later chunk
                 labels = rows[:, 5].long()
                 sample = data_samples[n]
                 # reference :82-86: the tracker consumes the depth-SCALED boxes + scales + depth
@@ -345,9 +389,10 @@ class OCSORT_Disparity(nn.Module):
             self.timings['tracker_s'] += time.perf_counter() - t0
             # reference :99-104: depth (and gt depth) of the UNSCALED track boxes - ONE batched launch per chunk,
             # enqueued on the chunk's own stream (its disp_postp buffer is still intact there)
+            td = time.perf_counter()
             mt = max([len(t) for t in tracks_of] + [1])
-            tb = torch.zeros(B, mt, 4, pin_memory=True)
-            tc = torch.zeros(B, dtype=torch.int32, pin_memory=True)
+            tb = self._pinned(('track_boxes', id(runner), job['ctx']), (B, mt, 4)).zero_()
+            tc = self._pinned(('track_counts', id(runner), job['ctx']), (B,), torch.int32).zero_()
             for i, t in enumerate(tracks_of):
                 tb[i, :len(t)] = t.bboxes
                 tc[i] = len(t)
@@ -358,28 +403,23 @@ class OCSORT_Disparity(nn.Module):
                 cols = [d]
                 if gt is not None:
                     cols.append(self._box_depth(padded(gt, s, e), tbd, tcd, -1.0, 1.0)[0])
-                dh = torch.empty(len(cols), B, mt, pin_memory=True)
+                dh = self._pinned(('track_depth', id(runner), ci), (len(cols), B, mt))   # read at the end of the call
                 dh.copy_(torch.stack(cols), non_blocking=True)
                 ev2 = torch.cuda.Event()
                 ev2.record(stream)
             pending.append((s, e, tracks_of, dh, ev2, (tbd, tcd)))
+            self.timings['depth_s'] += time.perf_counter() - td
             nxt = ci + len(runner)
             if nxt < len(chunks):                          # reuse this context (stream order: after the depth launch)
                 jobs[nxt] = submit(nxt)
-        for s, e, tracks_of, dh, ev2, _keep in pending:
+            while pending and pending[0][4].query():       # earlier chunks whose track depth has landed: complete
+                finalize(pending.pop(0))                   # them now, while the device works on the next chunks
+        for entry in pending:
             tw = time.perf_counter()
-            ev2.synchronize()
+            entry[4].synchronize()
             self.timings['wait_s'] += time.perf_counter() - tw
-            for i, tracks in enumerate(tracks_of):
-                k = len(tracks)
-                tracks['depth'] = dh[0, i, :k].clone()
-                tracks['gt_depth'] = dh[-1, i, :k].clone()   # = depth when no gt depth map was given (:104)
-                sample = data_samples[s + i]
-                if self.results_device == 'input':
-                    tracks = tracks.to(dev)
-                    sample.pred_det_instances = sample.pred_det_instances.to(dev)
-                sample.pred_track_instances = tracks
-                outs[s + i] = sample
+            finalize(entry)
+        self.timings['tail_s'] += time.perf_counter() - t_tail0
         self.timings['frames'] += N
         self.timings['host_s'] += time.perf_counter() - t_host0
         return outs

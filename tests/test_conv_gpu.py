@@ -441,3 +441,82 @@ def test_winograd_instance_needs_its_weights_and_shapes(stlib, cuda):
     d.wgt_wino_dev = x.data_ptr()
     d.stride = 2
     assert stlib.st_conv2d_nhwc_variant(C.byref(d), None, 43) != 0      # stride 2: not a Winograd layer
+
+
+@pytest.mark.parametrize('N,H,W,in_ld,in_off', [
+    (2, 23, 41, 32, 0),      # odd input sizes: ragged tiles in both directions, bottom/right padding row
+    (1, 64, 128, 32, 0),     # exact tiles
+    (3, 10, 134, 40, 8),     # input channel slice of a wider buffer; 67 output columns (3 column tiles)
+])
+def test_fused_stage1_front_matches_separate_convolutions(N, H, W, in_ld, in_off, cuda):
+    """st_conv3x3s2_csp_front: 3x3/s2 ConvModule (32 -> 64) + CSP main|short 1x1 (64 -> 32|32) + bottleneck conv1
+    (32 -> 32) as ONE launch == the three convolutions run one after the other (fp64 torch reference, and the
+    library's own three launches within fp32 rounding)."""
+    lib = _lib.load()
+    torch.manual_seed(H * W + N)
+    x = torch.randn(N, 32, H, W)
+    w3, b3 = torch.randn(64, 32, 3, 3) / 288 ** 0.5, torch.randn(64) * 0.5
+    wm, bm = torch.randn(64, 64, 1, 1) / 8.0, torch.randn(64) * 0.5
+    wc, bc = torch.randn(32, 32, 1, 1) / 32 ** 0.5, torch.randn(32) * 0.5
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    xin = torch.randn(N, H, W, in_ld) * 3.0
+    xin[..., in_off:in_off + 32] = x.permute(0, 2, 3, 1)
+    xin = xin.contiguous().to(cuda)
+    packed = [pack(w3, b3), pack(wm, bm), pack(wc, bc)]
+    dev = [(w.to(cuda), b.to(cuda)) for w, b in packed]
+    frags = []
+    for (wp, _), (co, ci) in zip(packed[1:], [(64, 64), (32, 32)]):
+        f = torch.empty(lib.st_front_frag_floats(co, ci), dtype=torch.float32)
+        check(lib.st_front_pack_frags(ptr(wp), co, ci, ptr(f)), 'st_front_pack_frags')
+        frags.append(f.to(cuda))
+
+    def descs(s3, main, cat, tmp):
+        a = StConvDesc()
+        a.in_dev = xin.data_ptr(); a.N, a.Hi, a.Wi, a.Cin, a.in_ld, a.in_off = N, H, W, 32, in_ld, in_off
+        a.wgt_dev, a.bias_dev = dev[0][0].data_ptr(), dev[0][1].data_ptr()
+        a.Cout, a.KH, a.KW, a.stride, a.pad, a.act, a.post_scale = 64, 3, 3, 2, 1, 1, 1.0
+        a.out1_dev = s3.data_ptr(); a.out1_ld, a.out1_off, a.split = 64, 0, 64
+        m = StConvDesc()
+        m.in_dev = s3.data_ptr(); m.N, m.Hi, m.Wi, m.Cin, m.in_ld, m.in_off = N, Ho, Wo, 64, 64, 0
+        m.wgt_dev, m.bias_dev = dev[1][0].data_ptr(), dev[1][1].data_ptr()
+        m.Cout, m.KH, m.KW, m.stride, m.pad, m.act, m.post_scale = 64, 1, 1, 1, 0, 1, 1.0
+        m.out1_dev = main.data_ptr(); m.out1_ld, m.out1_off, m.split = 32, 0, 32
+        m.out2_dev = cat.data_ptr(); m.out2_ld, m.out2_off = 64, 32
+        c = StConvDesc()
+        c.in_dev = main.data_ptr(); c.N, c.Hi, c.Wi, c.Cin, c.in_ld, c.in_off = N, Ho, Wo, 32, 32, 0
+        c.wgt_dev, c.bias_dev = dev[2][0].data_ptr(), dev[2][1].data_ptr()
+        c.Cout, c.KH, c.KW, c.stride, c.pad, c.act, c.post_scale = 32, 1, 1, 1, 0, 1, 1.0
+        c.out1_dev = tmp.data_ptr(); c.out1_ld, c.out1_off, c.split = 36, 4, 32
+        return a, m, c
+
+    def bufs():
+        return (torch.full((N, Ho, Wo, 64), -777.0, device=cuda), torch.full((N, Ho, Wo, 32), -777.0, device=cuda),
+                torch.full((N, Ho, Wo, 64), -777.0, device=cuda), torch.full((N, Ho, Wo, 36), -777.0, device=cuda))
+
+    s3, main, cat, tmp = bufs()
+    a, m, c = descs(s3, main, cat, tmp)
+    stream = _lib.current_stream()
+    check(lib.st_conv3x3s2_csp_front(C.byref(a), C.byref(m), C.byref(c), frags[0].data_ptr(), frags[1].data_ptr(), stream),
+          'st_conv3x3s2_csp_front')
+    torch.cuda.synchronize()
+    assert torch.all(s3 == -777.0), 'the 64-channel stride-2 tensor must not be materialised'
+    ya = ref_conv(x, w3, b3, 2, 1, 1)
+    ym = F.silu(F.conv2d(ya, wm.double(), bm.double()))
+    yc = F.silu(F.conv2d(ym[:, :32], wc.double(), bc.double()))
+    assert_close(main.cpu().permute(0, 3, 1, 2), ym[:, :32])
+    assert_close(cat.cpu()[..., 32:].permute(0, 3, 1, 2), ym[:, 32:])
+    assert torch.all(cat.cpu()[..., :32] == -777.0)
+    assert_close(tmp.cpu()[..., 4:].permute(0, 3, 1, 2), yc)
+    assert torch.all(tmp.cpu()[..., :4] == -777.0)
+    # against the library's own three launches: same arithmetic up to fp32 summation order
+    s3b, mainb, catb, tmpb = bufs()
+    a2, m2, c2 = descs(s3b, mainb, catb, tmpb)
+    for d in (a2, m2, c2):
+        check(lib.st_conv2d_nhwc(C.byref(d), stream), 'conv')
+    torch.cuda.synchronize()
+    for got, ref in ((main, mainb), (cat[..., 32:], catb[..., 32:]), (tmp[..., 4:], tmpb[..., 4:])):
+        assert (got - ref).abs().max().item() <= 2e-5 * (ref.abs().max().item() + 1e-6)
+    # shapes the kernel is not built for are refused, not mis-computed
+    a.stride = 1
+    assert lib.st_conv3x3s2_csp_front(C.byref(a), C.byref(m), C.byref(c), frags[0].data_ptr(), frags[1].data_ptr(), stream) != 0
+    assert b'fused front' in lib.st_last_error()
