@@ -6,16 +6,21 @@
 // mmdet CSPLayer(c2, c2, n, add_identity)), at the one place of the network where they are HBM-bound: 184x320 pixels
 // x 16 images, 32-64 channels (16 flop/B for the 1x1 convs).  Unfused this is three launches that write and re-read
 // the 64-channel stride-2 output and the main half (135 MB per image through HBM); fused, the 64-channel tensor never
-// exists: a workgroup computes it for a 2 x 32 pixel tile in MFMA accumulators and feeds it straight into the two
-// 1x1 convs (the swapped-operand accumulator layout D[cout][pixel] IS the B-operand layout of the next MFMA, the
-// trick of pointwise_conv.hip's CHAIN mode).  Outputs: main (32 ch, the bottleneck's residual), short (32 ch, into
-// the CSP concat buffer), conv1(main) (32 ch, the input of the 3x3 bottleneck conv).
+// exists: a wave computes it for 16 pixels in MFMA accumulators and feeds it straight into the two 1x1 convs (the
+// swapped-operand accumulator layout D[cout][pixel] IS the B-operand layout of the next MFMA, the trick of
+// pointwise_conv.hip's CHAIN mode).  Outputs: main (32 ch, the bottleneck's residual), short (32 ch, into the CSP
+// concat buffer), conv1(main) (32 ch, the input of the 3x3 bottleneck conv).
 //
-// Structure (direct_conv.hip's, at stride 2): 4 waves = 2 rows x 2 blocks of 16 pixels; the (2*2+1) x (2*32+1) x 32
-// input window goes to LDS once by LDS-DMA (hardware zero fill = conv padding), pixel stride 36 floats; per-tap
-// weights [64][32] triple-buffered through LDS (tap t + 2 in flight during tap t); `v_mfma_f32_16x16x4_f32`, A = weights, B = pixels.  The 1x1 weights
-// (16 KB + 4 KB) are pre-packed in fragment order and loaded from L2 into registers at kernel start, so the chained
-// GEMMs run on registers only.  Same arithmetic as the three separate launches up to fp32 summation order.
+// Structure: ONE persistent workgroup of 8 waves per CU.  Every weight of the three convolutions lives in LDS for the
+// whole kernel (3x3: 72 KB, XOR-swizzled rows so the A-fragment ds_read_b128 are conflict-free; 1x1: 20 KB in MFMA
+// fragment order), loaded once by LDS-DMA; after that single barrier the waves never synchronise again.  A wave
+// walks over tiles of 16 output pixels of one row (XCD-contiguous order: the 32 CUs of an XCD share input rows in
+// their L2).  The B operands (pixels) do not go through LDS at all: a lane's fragment for tap (ky, kx) and channel
+// group g is 16 contiguous bytes of the NHWC input, so the 18 fragments of a tile are 18 `buffer_load_dwordx4`
+// (range-checked descriptor: out-of-image = conv padding = zeros), issued one tile AHEAD into the registers the
+// current tile has just finished with - a full tile of MFMAs (~5 us) hides the HBM latency, and no window staging,
+// barrier or LDS footprint per tile is left.  `v_mfma_f32_16x16x4_f32`, A = weights, B = pixels.  Same arithmetic as
+// the three separate launches up to fp32 summation order.
 #include <algorithm>
 #include <cstdint>
 #include <cstdlib>
@@ -29,17 +34,15 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int FF_CIN = 32, FF_C2 = 64, FF_MID = 32;
-constexpr int FF_TH = 2, FF_TW = 32;                          // output tile
-constexpr int FF_WH = 2 * FF_TH + 1, FF_WW = 2 * FF_TW + 1;   // input window 5 x 65
-constexpr int FF_PQ = FF_CIN / 4 + 1, FF_PS = 4 * FF_PQ;      // 9 slots / 36 floats per pixel
-constexpr int FF_WIN_SLOTS = FF_WH * FF_WW * FF_PQ;
-constexpr int FF_WIN_DMA = (FF_WIN_SLOTS + 255) / 256;
-constexpr int FF_WIN_FLOATS = FF_WIN_DMA * 256 * 4;
-constexpr int FF_WT_SLOTS = FF_C2 * FF_PQ;                    // one tap: [64][32 + 4]
-constexpr int FF_WT_DMA = (FF_WT_SLOTS + 255) / 256;
-constexpr int FF_WT_FLOATS = FF_WT_DMA * 256 * 4;
-constexpr int FF_NBUF = 3;                                   // tap-weight buffers: tap t + 2 is in flight during tap t
-constexpr int FF_LDS_FLOATS = FF_WIN_FLOATS + FF_NBUF * FF_WT_FLOATS;
+#ifndef FF_WAVES_PER_CU
+#define FF_WAVES_PER_CU 8
+#endif
+constexpr int FF_WAVES = FF_WAVES_PER_CU, FF_THREADS = 64 * FF_WAVES;
+constexpr int FF_W3_FLOATS = 9 * FF_C2 * FF_CIN;      // [tap][cout][32 ch], 16-byte quads of a row XOR-swizzled
+constexpr int FF_MS_FLOATS = 2 * FF_MID * FF_C2;      // [c2 4][c 4][lane][4]
+constexpr int FF_C1_FLOATS = FF_MID * FF_MID;         // [c3 2][c2 2][lane][4]
+constexpr int FF_BIAS_FLOATS = 256;                   // a 64 | ms 64 | c1 32 (+ pad)
+constexpr int FF_LDS_FLOATS = FF_W3_FLOATS + FF_MS_FLOATS + FF_C1_FLOATS + FF_BIAS_FLOATS;
 
 struct FrontArgs {
   const float* in;
@@ -54,210 +57,242 @@ struct FrontArgs {
   float* out_tmp;
   int N, Hi, Wi, Ho, Wo, in_ld, in_off;
   int main_ld, main_off, short_ld, short_off, tmp_ld, tmp_off;
-  int tiles_x, tiles_y;
+  int tiles_x;             // 16-pixel tiles per output row
+  int ntiles;              // N * Ho * tiles_x
+  int slots_per_xcd;       // wave slots (workgroups x 8) of one XCD; gridDim.x is a multiple of 8
   unsigned in_bytes, wgt_bytes, main_bytes, short_bytes, tmp_bytes;
-  int abl;   // tools-only (ST_ABLATION) timing experiments, wrong results: 1 no per-tap weight DMA, 2 no per-tap barrier,
-             // 4 no chained GEMMs, 8 no window DMA, 16 no stores
+  int abl;   // tools-only (ST_ABLATION) timing experiments, wrong results: 1 no pixel loads, 4 no chained GEMMs,
+             // 16 no stores, 32 no LDS weight reads
 };
 
 __device__ __forceinline__ float ff_silu(float v) { return v * __builtin_amdgcn_rcpf(1.0f + __expf(-v)); }
 
-__global__ __launch_bounds__(256, 2) void front_s2_csp_kernel(const FrontArgs p) {
+__global__ __launch_bounds__(FF_THREADS, 1) void front_s2_csp_kernel(const FrontArgs p) {
   extern __shared__ float4 ff_smem4[];
-  float* win = reinterpret_cast<float*>(ff_smem4);
-  float* wbuf = win + FF_WIN_FLOATS;
+  float* w3 = reinterpret_cast<float*>(ff_smem4);
+  float* wms = w3 + FF_W3_FLOATS;
+  float* wc1 = wms + FF_MS_FLOATS;
+  float* bias = wc1 + FF_C1_FLOATS;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int i16 = lane & 15, kq = lane >> 4;
-  const int row = wave >> 1, pb = wave & 1;
-  int b = blockIdx.x;
-  const int tx = b % p.tiles_x; b /= p.tiles_x;
-  const int ty = b % p.tiles_y;
-  const int n = b / p.tiles_y;
-  const int oy0 = ty * FF_TH, ox0 = tx * FF_TW;
 
 #if defined(__HIP_DEVICE_COMPILE__)  // device-only builtins; the host pass only needs the kernel stub
   const __amdgpu_buffer_rsrc_t irsrc =
       __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in), 0, (int)p.in_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t wrsrc =
       __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.wgt_a), 0, (int)p.wgt_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t mfrsrc =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.frag_ms), 0, FF_MS_FLOATS * 4, 0x00020000);
+  const __amdgpu_buffer_rsrc_t cfrsrc =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.frag_c1), 0, FF_C1_FLOATS * 4, 0x00020000);
 
-  // ---- input window: slot e <-> (row, col, quad); outside the image and the pad quad read zeros.  Within a window row
-  // the even columns come first, then the odd ones: the 16 pixels of a stride-2 B fragment are then 36 floats apart
-  // (conflict-free ds_read_b128) instead of 72 (2-way conflicts).
+  // ---- one-time fill of the weight image.  LDS slot e (16 bytes) of the 3x3 part = (tap, cout, stored quad); the
+  // quad it holds is (stored ^ ((cout >> 1) & 7)): with 128-byte rows, 16 lanes reading the same quad of 16
+  // consecutive couts would hit 2 x 8 banks 8 times over; swizzled they cover all 64 banks once.
 #pragma unroll
-  for (int j = 0; j < FF_WIN_DMA; ++j) {
-#ifdef ST_ABLATION
-    if (p.abl & 8) break;
-#endif
-    const int e = tid + 256 * j;
-    const int pix = e / FF_PQ, q = e - pix * FF_PQ;
-    const int r = pix / FF_WW, cc = pix - r * FF_WW;
-    const int c = cc < FF_TW + 1 ? 2 * cc : 2 * (cc - FF_TW - 1) + 1;   // row = [even columns | odd columns]
-    const int gy = 2 * oy0 - 1 + r, gx = 2 * ox0 - 1 + c;
-    const bool ok = e < FF_WIN_SLOTS && q < FF_CIN / 4 && gy >= 0 && gy < p.Hi && gx >= 0 && gx < p.Wi;
-    const unsigned off = ok ? (unsigned)((((n * p.Hi + gy) * p.Wi + gx) * p.in_ld + p.in_off + 4 * q) * 4) : 0x80000000u;
+  for (int j = 0; j < (FF_W3_FLOATS / 4 + FF_THREADS - 1) / FF_THREADS; ++j) {
+    const int e = tid + FF_THREADS * j;
+    if (j * FF_THREADS + wave * 64 >= FF_W3_FLOATS / 4) break;   // whole waves only: 64 divides every part
+    const int tap = e >> 9, co = (e >> 3) & 63, qd = e & 7;
+    const unsigned off = (unsigned)((co * (9 * FF_CIN) + tap * FF_CIN + 4 * (qd ^ ((co >> 1) & 7))) * 4);
     __builtin_amdgcn_raw_ptr_buffer_load_lds(
-        irsrc, (__attribute__((address_space(3))) void*)(win + (j * 256 + wave * 64) * 4), 16, off, 0, 0, 0);
+        wrsrc, (__attribute__((address_space(3))) void*)(w3 + (j * FF_THREADS + wave * 64) * 4), 16, off, 0, 0, 0);
   }
-  auto wt_dma = [&](int tap, int buf) {
 #pragma unroll
-    for (int j = 0; j < FF_WT_DMA; ++j) {
-      const int e = tid + 256 * j;
-      const int co = e / FF_PQ, q = e - co * FF_PQ;
-      const bool ok = e < FF_WT_SLOTS && q < FF_CIN / 4;
-      const unsigned off = ok ? (unsigned)((co * (9 * FF_CIN) + tap * FF_CIN + 4 * q) * 4) : 0x80000000u;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(
-          wrsrc, (__attribute__((address_space(3))) void*)(wbuf + buf * FF_WT_FLOATS + (j * 256 + wave * 64) * 4), 16,
-          off, 0, 0, 0);
+  for (int j = 0; j < (FF_MS_FLOATS / 4 + FF_THREADS - 1) / FF_THREADS; ++j) {
+    if (j * FF_THREADS + wave * 64 >= FF_MS_FLOATS / 4) break;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(
+        mfrsrc, (__attribute__((address_space(3))) void*)(wms + (j * FF_THREADS + wave * 64) * 4), 16,
+        (unsigned)((tid + FF_THREADS * j) * 16), 0, 0, 0);
+  }
+  if (wave < FF_C1_FLOATS / 256)
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(cfrsrc, (__attribute__((address_space(3))) void*)(wc1 + wave * 256), 16,
+                                             (unsigned)(tid * 16), 0, 0, 0);
+  if (tid < 64) bias[tid] = p.bias_a[tid];
+  else if (tid < 128) bias[tid] = p.bias_ms[tid - 64];
+  else if (tid < 160) bias[tid] = p.bias_c1[tid - 128];
+
+  // ---- per-lane constants
+  const int sw = (i16 >> 1) & 7;
+  // A fragment (cb, tap, g): couts cb*16 + i16, channels 16g + 4kq..: float offset tap*2048 + cb*512 + wq[g]
+  int wq[2];
+#pragma unroll
+  for (int g = 0; g < 2; ++g) wq[g] = i16 * 32 + (((4 * g + kq) ^ sw) << 2);
+
+  // wave slot -> tiles: slot order is XCD-major (workgroup b runs on XCD b % 8), so in every sweep the 32 CUs of an
+  // XCD take a contiguous run of tiles (a band of ~13 output rows whose input rows they share in that XCD's L2)
+  const int xcd = blockIdx.x & 7, wg = blockIdx.x >> 3;
+  const int slot = xcd * p.slots_per_xcd + wg * FF_WAVES + wave;
+  const int stride = 8 * p.slots_per_xcd;
+
+  // pixel-fragment loads of tile t into X[2*tap + g]; tiles past the end (and everything outside the image) read zeros.
+  // Per lane: one byte offset per kx (column 2ox - 1 + kx of input row 2oy - 1, channel 4kq; 0x80000000 = does not
+  // exist -> the descriptor's range check returns zeros); the row / channel-group displacement of a tap is
+  // wave-uniform and rides in the scalar offset.
+  unsigned xcol[3] = {0x80000000u, 0x80000000u, 0x80000000u};
+  unsigned rowmask = 0;              // bit ky set = input row 2oy - 1 + ky exists
+  auto locate = [&](int t) {
+    const bool live = t < p.ntiles;
+    const int tx = t % p.tiles_x;
+    const int r = t / p.tiles_x;     // n * Ho + oy
+    const int oy = r % p.Ho, n = r / p.Ho;
+    const int ox = tx * 16 + i16;
+    const int gy0 = 2 * oy - 1, gx0 = 2 * ox - 1;
+    const unsigned base = (unsigned)((((n * p.Hi + gy0) * p.Wi + gx0) * p.in_ld + p.in_off + 4 * kq) * 4);
+    rowmask = 0;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      rowmask |= (live && gy0 + k >= 0 && gy0 + k < p.Hi) ? 1u << k : 0u;
+      xcol[k] = (ox < p.Wo && gx0 + k >= 0 && gx0 + k < p.Wi) ? base + (unsigned)(k * p.in_ld * 4) : 0x80000000u;
     }
   };
-  wt_dma(0, 0);
-  wt_dma(1, 1);
-
-  // ---- 1x1 weights in fragment order: 16 + 4 coalesced 1 KB loads from L2, issued now, consumed after the 3x3 loop
-  f32x4 fms[4][4], fc1[2][2];
-#pragma unroll
-  for (int c2 = 0; c2 < 4; ++c2)
-#pragma unroll
-    for (int c = 0; c < 4; ++c)
-      fms[c2][c] = *reinterpret_cast<const f32x4*>(p.frag_ms + ((c2 * 4 + c) * 64 + lane) * 4);
-#pragma unroll
-  for (int c3 = 0; c3 < 2; ++c3)
-#pragma unroll
-    for (int c2 = 0; c2 < 2; ++c2)
-      fc1[c3][c2] = *reinterpret_cast<const f32x4*>(p.frag_c1 + ((c3 * 2 + c2) * 64 + lane) * 4);
-
-  // biases of the three stages in accumulator layout (couts cb*16 + 4kq + e), loaded up front for the same reason
-  f32x4 ba[4], bm[4], bc[2];
-#pragma unroll
-  for (int cb = 0; cb < 4; ++cb) {
-    ba[cb] = *reinterpret_cast<const f32x4*>(p.bias_a + cb * 16 + 4 * kq);
-    bm[cb] = *reinterpret_cast<const f32x4*>(p.bias_ms + cb * 16 + 4 * kq);
-  }
-#pragma unroll
-  for (int cb = 0; cb < 2; ++cb) bc[cb] = *reinterpret_cast<const f32x4*>(p.bias_c1 + cb * 16 + 4 * kq);
-
-  f32x4 acc[4];
-#pragma unroll
-  for (int cb = 0; cb < 4; ++cb) acc[cb] = f32x4{0.f, 0.f, 0.f, 0.f};
-  // lane = (pixel i16 of this wave's 16-pixel block, k quarter kq)
-  const float* xlane = win + ((2 * row) * FF_WW + pb * 16 + i16) * FF_PS + 4 * kq;
-  const float* wlane = wbuf + i16 * FF_PS + 4 * kq;
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // window, tap 0 (and the fragment loads) landed
-#pragma unroll
-  for (int cb = 0; cb < 4; ++cb) asm volatile("" : "+v"(ba[cb]), "+v"(bm[cb]));   // keep the loads up here
-#pragma unroll
-  for (int cb = 0; cb < 2; ++cb) asm volatile("" : "+v"(bc[cb]));
-  __syncthreads();
-
-#pragma unroll
-  for (int tap = 0; tap < 9; ++tap) {
-    const int buf = tap % FF_NBUF;
-#ifdef ST_ABLATION
-    if (!(p.abl & 1))
-#endif
-    if (tap + 2 < 9) wt_dma(tap + 2, (tap + 2) % FF_NBUF);   // two taps (64 MFMAs per wave) to land
+  const int row_bytes = p.Wi * p.in_ld * 4;
+  auto xload = [&](int tap, int g) -> f32x4 {
     const int ky = tap / 3, kx = tap - 3 * ky;
-    const float* xt = xlane + (ky * FF_WW + (kx == 1 ? FF_TW + 1 : kx >> 1)) * FF_PS;   // column 2 px + kx of the window
-    const float* wt = wlane + buf * FF_WT_FLOATS;
+    const unsigned off = ((rowmask >> ky) & 1u) ? xcol[kx] : 0x80000000u;
+    // a row of -1 makes base "negative" (wraps): only ever used with ky >= 1, where base + ky * row_bytes is back in range
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(irsrc, off + (unsigned)(ky * row_bytes + 64 * g), 0, 0));
+  };
+
+  f32x4 X[18];
+  int tile = slot;
+  locate(tile);
 #pragma unroll
-    for (int g = 0; g < 2; ++g) {
-      const f32x4 xf = *reinterpret_cast<const f32x4*>(xt + 16 * g);
-      f32x4 wf[4];
+  for (int k = 0; k < 18; ++k) X[k] = xload(k >> 1, k & 1);
+
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // weight image (this wave's share) landed
+  __syncthreads();                                    // the only barrier of the kernel
+
+  const __amdgpu_buffer_rsrc_t mrsrc = __builtin_amdgcn_make_buffer_rsrc(p.out_main, 0, (int)p.main_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t srsrc = __builtin_amdgcn_make_buffer_rsrc(p.out_short, 0, (int)p.short_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t trsrc = __builtin_amdgcn_make_buffer_rsrc(p.out_tmp, 0, (int)p.tmp_bytes, 0x00020000);
+
+  for (; tile < p.ntiles; tile += stride) {
+    // where this tile's results go (before `locate` moves on to the next tile)
+    const int tx = tile % p.tiles_x, orow = tile / p.tiles_x;
+    const int ox = tx * 16 + i16;
+    const bool st_ok = ox < p.Wo;
+    const int m = orow * p.Wo + ox;
+    locate(tile + stride);
+
+    f32x4 acc[4];
 #pragma unroll
-      for (int cb = 0; cb < 4; ++cb) wf[cb] = *reinterpret_cast<const f32x4*>(wt + cb * 16 * FF_PS + 16 * g);
+    for (int cb = 0; cb < 4; ++cb) acc[cb] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // 18 steps (tap, g) of 16 MFMAs.  The A fragments of step k + 1 are read from LDS before the MFMAs of step k; the
+    // scheduling barrier after every step keeps the compiler from hoisting the next tile's pixel loads above the MFMAs
+    // that still read the current ones (which would double the 72 fragment registers and spill).
+    f32x4 wf[2][4];
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb) wf[0][cb] = *reinterpret_cast<const f32x4*>(w3 + cb * 512 + wq[0]);
+#pragma unroll
+    for (int k = 0; k < 18; ++k) {
+      const int tap = k >> 1, g = k & 1;
+#ifdef ST_ABLATION
+      if (p.abl & 32) {
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb) wf[(k + 1) & 1][cb] = wf[k & 1][cb] + f32x4{1.f, 1.f, 1.f, 1.f};
+      } else
+#endif
+      if (k + 1 < 18) {
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb)
+          wf[(k + 1) & 1][cb] = *reinterpret_cast<const f32x4*>(w3 + ((k + 1) >> 1) * 2048 + cb * 512 + wq[(k + 1) & 1]);
+      }
+      __builtin_amdgcn_sched_barrier(0);   // ... and keeps these LDS reads ABOVE the MFMAs they overlap with
+      const f32x4 xf = X[k];
 #pragma unroll
       for (int s = 0; s < 4; ++s)
 #pragma unroll
         for (int cb = 0; cb < 4; ++cb)
-          acc[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[cb][s], xf[s], acc[cb], 0, 0, 0);
-    }
+          acc[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[k & 1][cb][s], xf[s], acc[cb], 0, 0, 0);
 #ifdef ST_ABLATION
-    if (!(p.abl & 2))
+      if (!(p.abl & 1))
 #endif
-    if (tap + 1 < 9) {
-      // this wave's share of tap + 1 landed (the FF_WT_DMA loads of tap + 2 may still be in flight)
-      if (tap + 2 < 9) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(FF_WT_DMA) : "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
+      X[k] = xload(tap, g);   // the next tile's fragment, a whole tile of MFMAs ahead of its use
+      __builtin_amdgcn_sched_barrier(0);
     }
-  }
 
 #ifdef ST_ABLATION
-  if (p.abl & 4) {
-    float v = 0.f;
+    if (p.abl & 4) {
+      float v = 0.f;
 #pragma unroll
-    for (int cb = 0; cb < 4; ++cb) v += acc[cb][0] + acc[cb][1] + acc[cb][2] + acc[cb][3] + fms[cb][cb][0] + fc1[cb & 1][cb >> 1][0];
-    if (v == 12345.678f) p.out_main[tid] = v;
-    return;
-  }
+      for (int cb = 0; cb < 4; ++cb) v += acc[cb][0] + acc[cb][1] + acc[cb][2] + acc[cb][3];
+      if (v == 12345.678f) p.out_main[tid] = v;
+      continue;
+    }
 #endif
-  // ---- stage A epilogue in registers: lane holds couts cb*16 + 4kq + e of its pixel = the B operand of the 1x1 GEMM
-  f32x4 va[4];
+    // ---- stage A epilogue in registers: lane holds couts cb*16 + 4kq + e of its pixel = the B operand of the 1x1 GEMM
+    f32x4 va[4];
 #pragma unroll
-  for (int cb = 0; cb < 4; ++cb) {
+    for (int cb = 0; cb < 4; ++cb) {
+      const f32x4 bq = *reinterpret_cast<const f32x4*>(bias + cb * 16 + 4 * kq);
 #pragma unroll
-    for (int e = 0; e < 4; ++e) va[cb][e] = ff_silu(acc[cb][e] + ba[cb][e]);
-  }
-  // ---- main | short = SiLU(W_ms . va + b)   (K = 64: 4 cout blocks of stage A x 4 steps)
-  f32x4 am[4];
+      for (int e = 0; e < 4; ++e) va[cb][e] = ff_silu(acc[cb][e] + bq[e]);
+    }
+    // ---- main | short = SiLU(W_ms . va + b)   (K = 64: 4 cout blocks of stage A x 4 steps)
+    f32x4 am[4];
 #pragma unroll
-  for (int c2 = 0; c2 < 4; ++c2) am[c2] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int c2 = 0; c2 < 4; ++c2) am[c2] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-  for (int c = 0; c < 4; ++c)
+    for (int c = 0; c < 4; ++c) {
+      f32x4 wf[4];
 #pragma unroll
-    for (int s = 0; s < 4; ++s)
+      for (int c2 = 0; c2 < 4; ++c2) wf[c2] = *reinterpret_cast<const f32x4*>(wms + ((c2 * 4 + c) * 64 + lane) * 4);
 #pragma unroll
-      for (int c2 = 0; c2 < 4; ++c2)
-        am[c2] = __builtin_amdgcn_mfma_f32_16x16x4f32(fms[c2][c][s], va[c][s], am[c2], 0, 0, 0);
-  f32x4 vm[4];
+      for (int s = 0; s < 4; ++s)
 #pragma unroll
-  for (int c2 = 0; c2 < 4; ++c2) {
+        for (int c2 = 0; c2 < 4; ++c2)
+          am[c2] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[c2][s], va[c][s], am[c2], 0, 0, 0);
+    }
+    f32x4 vm[4];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) vm[c2][e] = ff_silu(am[c2][e] + bm[c2][e]);
-  }
-  // ---- conv1(main) = SiLU(W_c1 . vm[0..1] + b)   (K = 32)
-  f32x4 ac[2];
+    for (int c2 = 0; c2 < 4; ++c2) {
+      const f32x4 bq = *reinterpret_cast<const f32x4*>(bias + 64 + c2 * 16 + 4 * kq);
 #pragma unroll
-  for (int c3 = 0; c3 < 2; ++c3) ac[c3] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-  for (int c2 = 0; c2 < 2; ++c2)
-#pragma unroll
-    for (int s = 0; s < 4; ++s)
-#pragma unroll
-      for (int c3 = 0; c3 < 2; ++c3)
-        ac[c3] = __builtin_amdgcn_mfma_f32_16x16x4f32(fc1[c3][c2][s], vm[c2][s], ac[c3], 0, 0, 0);
-
+      for (int e = 0; e < 4; ++e) vm[c2][e] = ff_silu(am[c2][e] + bq[e]);
+    }
 #ifdef ST_ABLATION
-  if (p.abl & 16) {
-    float v = 0.f;
-#pragma unroll
-    for (int c2 = 0; c2 < 4; ++c2) v += vm[c2][0] + vm[c2][1] + vm[c2][2] + vm[c2][3] + ac[c2 & 1][c2];
-    if (v == 12345.678f) p.out_main[tid] = v;
-    return;
-  }
+    const bool no_store = p.abl & 16;
+#else
+    constexpr bool no_store = false;
 #endif
-  // ---- stores: 16 bytes per (pixel, 4 couts); range-checked descriptors, no branches
-  const __amdgpu_buffer_rsrc_t mrsrc = __builtin_amdgcn_make_buffer_rsrc(p.out_main, 0, (int)p.main_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t srsrc = __builtin_amdgcn_make_buffer_rsrc(p.out_short, 0, (int)p.short_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t trsrc = __builtin_amdgcn_make_buffer_rsrc(p.out_tmp, 0, (int)p.tmp_bytes, 0x00020000);
-  const int oy = oy0 + row, ox = ox0 + pb * 16 + i16;
-  const bool ok = oy < p.Ho && ox < p.Wo;
-  const int m = (n * p.Ho + oy) * p.Wo + ox;
+    // stores: 16 bytes per (pixel, 4 couts); range-checked descriptors, no branches
+    if (!no_store) {
 #pragma unroll
-  for (int c2 = 0; c2 < 2; ++c2) {
-    const unsigned om = ok ? (unsigned)((m * p.main_ld + p.main_off + c2 * 16 + 4 * kq) * 4) : 0x80000000u;
-    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, vm[c2]), mrsrc, om, 0, 0);
-    const unsigned os = ok ? (unsigned)((m * p.short_ld + p.short_off + c2 * 16 + 4 * kq) * 4) : 0x80000000u;
-    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, vm[2 + c2]), srsrc, os, 0, 0);
-    f32x4 vt;
+      for (int c2 = 0; c2 < 2; ++c2) {
+        const unsigned om = st_ok ? (unsigned)((m * p.main_ld + p.main_off + c2 * 16 + 4 * kq) * 4) : 0x80000000u;
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, vm[c2]), mrsrc, om, 0, 0);
+        const unsigned os = st_ok ? (unsigned)((m * p.short_ld + p.short_off + c2 * 16 + 4 * kq) * 4) : 0x80000000u;
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, vm[2 + c2]), srsrc, os, 0, 0);
+      }
+    }
+    // ---- conv1(main) = SiLU(W_c1 . vm[0..1] + b)   (K = 32)
+    f32x4 ac[2];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) vt[e] = ff_silu(ac[c2][e] + bc[c2][e]);
-    const unsigned ot = ok ? (unsigned)((m * p.tmp_ld + p.tmp_off + c2 * 16 + 4 * kq) * 4) : 0x80000000u;
-    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, vt), trsrc, ot, 0, 0);
+    for (int c3 = 0; c3 < 2; ++c3) ac[c3] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int c2 = 0; c2 < 2; ++c2) {
+      f32x4 wf[2];
+#pragma unroll
+      for (int c3 = 0; c3 < 2; ++c3) wf[c3] = *reinterpret_cast<const f32x4*>(wc1 + ((c3 * 2 + c2) * 64 + lane) * 4);
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int c3 = 0; c3 < 2; ++c3)
+          ac[c3] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[c3][s], vm[c2][s], ac[c3], 0, 0, 0);
+    }
+#pragma unroll
+    for (int c3 = 0; c3 < 2; ++c3) {
+      const f32x4 bq = *reinterpret_cast<const f32x4*>(bias + 128 + c3 * 16 + 4 * kq);
+      f32x4 vt;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) vt[e] = ff_silu(ac[c3][e] + bq[e]);
+      const unsigned ot = st_ok && !no_store ? (unsigned)((m * p.tmp_ld + p.tmp_off + c3 * 16 + 4 * kq) * 4) : 0x80000000u;
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, vt), trsrc, ot, 0, 0);
+    }
   }
 #else
-  (void)win; (void)wbuf; (void)i16; (void)kq; (void)row; (void)pb; (void)n; (void)oy0; (void)ox0;
+  (void)w3; (void)wms; (void)wc1; (void)bias; (void)i16; (void)kq; (void)wave;
 #endif
 }
 
@@ -317,7 +352,10 @@ int front_fused_launch(const StConvDesc& da, const StConvDesc& dms, const StConv
   a.N = da.N; a.Hi = da.Hi; a.Wi = da.Wi; a.Ho = Ho; a.Wo = Wo; a.in_ld = da.in_ld; a.in_off = da.in_off;
   a.main_ld = dms.out1_ld; a.main_off = dms.out1_off; a.short_ld = dms.out2_ld; a.short_off = dms.out2_off;
   a.tmp_ld = dc1.out1_ld; a.tmp_off = dc1.out1_off;
-  a.tiles_x = ceil_div(Wo, FF_TW); a.tiles_y = ceil_div(Ho, FF_TH);
+  a.tiles_x = ceil_div(Wo, 16);
+  const long long ntiles = (long long)da.N * Ho * a.tiles_x;
+  ST_REQUIRE(ntiles < (1ll << 30), "fused front: too many tiles");
+  a.ntiles = (int)ntiles;
   a.in_bytes = (unsigned)(Mi * da.in_ld * 4);
   a.wgt_bytes = (unsigned)(FF_C2 * 9 * FF_CIN * 4);
   a.main_bytes = (unsigned)(Mo * dms.out1_ld * 4);
@@ -327,12 +365,20 @@ int front_fused_launch(const StConvDesc& da, const StConvDesc& dms, const StConv
 #ifdef ST_ABLATION
   if (const char* e = getenv("ST_FF_ABL")) a.abl = atoi(e);
 #endif
-  const long long blocks = (long long)da.N * a.tiles_x * a.tiles_y;
-  ST_REQUIRE(blocks < (1ll << 31), "fused front: grid too large");
+  // one persistent workgroup per CU (a multiple of 8 so that every XCD gets the same number), fewer for small inputs
+  static int cus = 0;
+  if (cus == 0) {
+    int dev = 0, n = 0;
+    ST_CHECK_HIP(hipGetDevice(&dev));
+    ST_CHECK_HIP(hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev));
+    cus = std::max(8, n / 8 * 8);
+  }
+  const int blocks = std::min(cus, std::max(8, round_up(ceil_div(a.ntiles, FF_WAVES), 8)));
+  a.slots_per_xcd = blocks / 8 * FF_WAVES;
   constexpr int lds = FF_LDS_FLOATS * (int)sizeof(float);
   static int lds_set = 0;
   ST_ENSURE_DYNAMIC_LDS(front_s2_csp_kernel, lds, lds_set);
-  hipLaunchKernelGGL(front_s2_csp_kernel, dim3((unsigned)blocks), dim3(256), lds, stream, a);
+  hipLaunchKernelGGL(front_s2_csp_kernel, dim3((unsigned)blocks), dim3(FF_THREADS), lds, stream, a);
   ST_CHECK_HIP(hipGetLastError());
   return ST_OK;
 }

@@ -24,7 +24,8 @@ def packed(cout, cin, k):
     return wp, bp
 
 
-def bench(N, H, W, reps=10):
+def make(N, H, W):
+    """-> (launch fused, launch the three separate convolutions, GFLOP of the three convolutions)"""
     Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
     x = torch.randn(N, H, W, 32, device=dev)
     host = [packed(64, 32, 3), packed(64, 64, 1), packed(32, 32, 1)]
@@ -53,6 +54,20 @@ def bench(N, H, W, reps=10):
     c.Cout, c.KH, c.KW, c.stride, c.pad, c.act, c.post_scale = 32, 1, 1, 1, 0, 1, 1.0
     c.out1_dev = tmp.data_ptr(); c.out1_ld, c.out1_off, c.split = 32, 0, 32
     stream = _lib.current_stream()
+    keep = (x, devw, frags, s3, main, cat, tmp, a, m, c)
+
+    def fused(_keep=keep):
+        check(lib.st_conv3x3s2_csp_front(C.byref(a), C.byref(m), C.byref(c), frags[0].data_ptr(), frags[1].data_ptr(), stream))
+
+    def three(_keep=keep):
+        for d in (a, m, c):
+            check(lib.st_conv2d_nhwc(C.byref(d), stream))
+
+    return fused, three, 2.0 * N * Ho * Wo * (288 * 64 + 64 * 64 + 32 * 32) / 1e9
+
+
+def bench(N, H, W, reps=10):
+    fused, three, gf = make(N, H, W)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 
     def timed(fn):
@@ -63,13 +78,11 @@ def bench(N, H, W, reps=10):
             best = min(best, e0.elapsed_time(e1))
         return best
 
-    t_f = timed(lambda: check(lib.st_conv3x3s2_csp_front(C.byref(a), C.byref(m), C.byref(c), frags[0].data_ptr(),
-                                                         frags[1].data_ptr(), stream)))
-    t_3 = timed(lambda: [check(lib.st_conv2d_nhwc(C.byref(d), stream)) for d in (a, m, c)])
-    gf = 2.0 * N * Ho * Wo * (288 * 64 + 64 * 64 + 32 * 32) / 1e9
+    t_f, t_3 = timed(fused), timed(three)
     print(f'N={N} {H}x{W}: {gf:6.2f} GF  fused {t_f * 1e3:7.1f} us ({gf / t_f:6.1f} TF/s)   three launches (heuristic '
           f'tiles) {t_3 * 1e3:7.1f} us ({gf / t_3:6.1f} TF/s)')
 
 
-for shape in [(16, 368, 640), (8, 368, 640)]:
-    bench(*shape)
+if __name__ == '__main__':
+    for shape in [(16, 368, 640), (8, 368, 640)]:
+        bench(*shape)
