@@ -84,7 +84,8 @@ int st_conv2d_nhwc(const StConvDesc* d, st_stream_t stream);
 /* The same convolution with the kernel instance chosen by the caller instead of the library's heuristic:
  * variant 0..21 = tile instances of the implicit-GEMM kernel (st_conv_variant_name), 41 = streaming 1x1 kernel,
  * 42 = direct 3x3 kernel, 43 / 44 = Winograd F(2x2,3x3) kernel with 64- / 32-cout workgroups (need wgt_wino_dev),
- * -1 = heuristic.  Returns ST_ERR_INVALID when the instance cannot run this layer (tile
+ * 46 = 1x1 kernel with the weight matrix resident in LDS and register-fed pixels (Cin -> Cout one of 64->64, 128->64,
+ * 128->128, 256->128), -1 = heuristic.  Returns ST_ERR_INVALID when the instance cannot run this layer (tile
  * does not divide the padded Cout, ...), so callers can autotune per layer by timing the valid ones — which is
  * what st_detector_autotune does internally and StereoCostVolume.autotune does for the aggregation convs.
  * Results are the same convolution for every valid variant (fp32 rounding differs with the summation order). */
@@ -101,7 +102,8 @@ int st_wino_pack_weights(const float* packed_wgt_host, int Cout, int Cin, float*
 /* Fused pair of 1x1 convolutions for the narrow high-resolution CSP layers: `b` (Cin = 32, Cout <= 32) consumes
  * output channels [0, 32) of `a` (Cin 32 or 64, 32 < Cout <= 64, no residual) - the CSPLayer main_conv ->
  * DarknetBottleneck conv1 pair (mmdet CSPLayer, built at csp_darknet_disparity_v1.py:113-153).  a's outputs are
- * written as usual; b's in_dev / in_ld / in_off are ignored (its input never leaves the registers). */
+ * written as usual; b's in_dev / in_ld / in_off are ignored (its input never leaves the registers).  The same pair
+ * one stage deeper (a: 128 or 256 -> 64 | 64 split store, b: 64 -> 64) runs on the LDS-resident kernel (variant 46). */
 int st_conv1x1_chain(const StConvDesc* a, const StConvDesc* b, st_stream_t stream);
 /* Fused head of a stage-1 CSP branch: `a` = 3x3 / stride-2 / pad-1 ConvModule 32 -> 64 (its own output tensor is never
  * written: a->out1_dev is ignored), `ms` = CSPLayer main_conv | short_conv on a's output (1x1, 64 -> 32 | 32, split

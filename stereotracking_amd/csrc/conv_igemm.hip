@@ -677,6 +677,8 @@ const char* conv_variant_signature(int id) {
 
 bool pw_conv_applicable(const StConvDesc& d);          // pointwise_conv.hip (tile variant 41)
 int pw_conv_launch(const StConvDesc& d, hipStream_t stream, const StConvDesc* chain);
+int pwr_conv_launch(const StConvDesc& d, hipStream_t stream, const StConvDesc* chain);
+bool pwr_chain_applicable(const StConvDesc& d, const StConvDesc& c);
 bool dc_conv_applicable(const StConvDesc& d);          // direct_conv.hip (tile variant 42)
 int dc_conv_launch(const StConvDesc& d, hipStream_t stream);
 bool wino_conv_applicable(const StConvDesc& d);        // wino_conv.hip (tile variant 43)
@@ -687,6 +689,10 @@ int conv2d_launch(const StConvDesc& d, hipStream_t stream, int force_variant, in
   if (force_variant == 41) {   // streaming 1x1 kernel for narrow layers
     if (picked_variant) *picked_variant = 41;
     return pw_conv_launch(d, stream, nullptr);
+  }
+  if (force_variant == 46) {   // 1x1 kernel with LDS-resident weights, pixels register-fed
+    if (picked_variant) *picked_variant = 46;
+    return pwr_conv_launch(d, stream, nullptr);
   }
   if (force_variant == 42) {   // direct 3x3 kernel for narrow layers
     if (picked_variant) *picked_variant = 42;
@@ -829,6 +835,7 @@ extern "C" int st_conv2d_nhwc(const StConvDesc* d, st_stream_t stream) {
 // main_conv -> bottleneck conv1 pair) straight from registers; a's own outputs are still written.
 extern "C" int st_conv1x1_chain(const StConvDesc* a, const StConvDesc* b, st_stream_t stream) {
   if (!a || !b) return st::set_error(ST_ERR_INVALID, "st_conv1x1_chain: null desc");
+  if (st::pwr_chain_applicable(*a, *b)) return st::pwr_conv_launch(*a, static_cast<hipStream_t>(stream), b);
   return st::pw_conv_launch(*a, static_cast<hipStream_t>(stream), b);
 }
 

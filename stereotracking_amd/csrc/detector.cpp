@@ -40,6 +40,9 @@ bool wino_shape_ok(int Cin, int Cout);
 size_t wino_packed_floats(int Cout, int Cin);
 int wino_pack_weights(const float* packed, int Cout, int Cin, float* out);
 int pw_conv_launch(const StConvDesc& d, hipStream_t stream, const StConvDesc* chain);
+bool pwr_conv_applicable(const StConvDesc& d);
+bool pwr_chain_applicable(const StConvDesc& d, const StConvDesc& c);
+int pwr_conv_launch(const StConvDesc& d, hipStream_t stream, const StConvDesc* chain);
 bool front_fused_applicable(const StConvDesc& a, const StConvDesc& ms, const StConvDesc& c1);
 int front_fused_launch(const StConvDesc& a, const StConvDesc& ms, const StConvDesc& c1, const float* frag_ms_dev,
                        const float* frag_c1_dev, hipStream_t stream);
@@ -134,7 +137,8 @@ struct Op {
   int tuned = -1;      // measured best variant (st_detector_autotune), -1 = heuristic
   int group = 0;       // sub-batch group (0 = whole batch in one launch)
   bool chain_next = false;  // the NEXT op is a 1x1 conv on this op's out1 (CSP main_conv -> bottleneck conv1):
-                            // when both run on the streaming kernel (variant 41) they are launched as one
+                            // when both run on the streaming kernel (variant 41), or both on the LDS-resident
+                            // kernel (variant 46), they are launched as one
   bool front_next2 = false; // this 3x3/s2 conv and the NEXT TWO ops (CSP main|short, blocks.0.conv1) are one launch
                             // of front_fused.hip (variant 45) whenever the three descriptors qualify
 };
@@ -304,7 +308,7 @@ struct StDetector {
     TRef mainb = new_tensor(x.N, x.H, x.W, mid);
     const int pc = packed_convmodules({p + ".main_conv", p + ".short_conv"}, x.C, {mid, mid}, 1);
     op_conv(pc, x, 1, mainb, mid, cat.slice(mid, mid));
-    if (nblocks > 0 && mid == 32) ops.back().chain_next = true;   // main_conv -> blocks.0.conv1 (reads mainb)
+    if (nblocks > 0 && (mid == 32 || mid == 64)) ops.back().chain_next = true;   // main_conv -> blocks.0.conv1 (reads mainb)
     // stage-1 shape (32 -> 64 -> 32|32 -> 32): a preceding 3x3/s2 ConvModule can take both 1x1 convs along
     const bool frontable = nblocks > 0 && mid == 32 && x.C == 64 && ops.size() >= 2 && ops[ops.size() - 2].type == Op::CONV &&
                            convs[ops[ops.size() - 2].pc].k == 3 && ops[ops.size() - 2].stride == 2 &&
@@ -707,6 +711,8 @@ int run_ops(StDetector* det, int phase_lo, int phase_hi, const float* const inpu
     size_t oe = oi + 1;
     if (first.group > 0)
       while (oe < nops && det->ops[oe].group == first.group && det->ops[oe].phase == first.phase) ++oe;
+    else if (first.chain_next && oe < nops && det->ops[oe].group == 0 && det->ops[oe].phase == first.phase)
+      ++oe;   // a chainable pair outside the sub-batch groups is still launched as one
     const StDetector::Group g = det->groups[first.group];
     for (int sbi = 0; sbi < g.count; ++sbi) {
       int fused_left = 0, fused_variant = 0;   // ops already computed by a preceding fused launch
@@ -737,12 +743,12 @@ int run_ops(StDetector* det, int phase_lo, int phase_hi, const float* const inpu
           }
         }
         if (!chained && !skipped && o.type == Op::CONV && o.chain_next && k + 1 < oe && det->force_variant < 0 &&
-                   o.tuned == 41 && det->ops[k + 1].tuned == 41 && det->allow_chain) {
+            (o.tuned == 41 || o.tuned == 46) && det->ops[k + 1].tuned == o.tuned && det->allow_chain) {
           const StConvDesc da = conv_desc(det, o, sbi * g.sb, ws, head);
           const StConvDesc db = conv_desc(det, det->ops[k + 1], sbi * g.sb, ws, head);
-          if (pw_chain_applicable(da, db)) {
-            ST_CHECK(pw_conv_launch(da, stream, &db));
-            o.variant = fused_variant = 41;
+          if (o.tuned == 41 ? pw_chain_applicable(da, db) : pwr_chain_applicable(da, db)) {
+            ST_CHECK(o.tuned == 41 ? pw_conv_launch(da, stream, &db) : pwr_conv_launch(da, stream, &db));
+            o.variant = fused_variant = o.tuned;
             fused_left = 1;
             chained = true;
           }
@@ -894,9 +900,13 @@ extern "C" int st_detector_autotune(StDetector* det, void* workspace_dev, size_t
     const bool wn_ok = !det->no_wino && wino_conv_applicable(probe);   // + variant 43, Winograd F(2x2,3x3) (wino_conv.hip)
     const int ncand = std::min(conv_variant_count(), 22);
     const bool wn_narrow_ok = wn_ok && det->convs[so.pc].cout % 64 == 0;   // + variant 44: 32-cout Winograd workgroups
-    for (int vi = 0; vi <= ncand + 3 && rc == ST_OK; ++vi) {
-      const int v = vi < ncand ? vi : 41 + (vi - ncand);
-      if (v == 41 ? !pw_ok : v == 42 ? !dc_ok : v == 43 ? !wn_ok : v == 44 ? !wn_narrow_ok
+    probe.wgt_dev = det->wgt_dev + det->convs[so.pc].wgt_off;
+    probe.bias_dev = det->wgt_dev + det->convs[so.pc].bias_off;
+    probe.split = so.split; probe.out2_off = so.out2.off;
+    const bool pr_ok = pwr_conv_applicable(probe);   // + variant 46: 1x1 with LDS-resident weights (pointwise_resident.hip)
+    for (int vi = 0; vi <= ncand + 4 && rc == ST_OK; ++vi) {
+      const int v = vi < ncand ? vi : vi == ncand + 4 ? 46 : 41 + (vi - ncand);
+      if (v == 46 ? !pr_ok : v == 41 ? !pw_ok : v == 42 ? !dc_ok : v == 43 ? !wn_ok : v == 44 ? !wn_narrow_ok
                                                                   : !conv_variant_valid(v, det->convs[saved[oi].pc].cout))
         continue;
       det->force_variant = v;
@@ -934,10 +944,10 @@ extern "C" int st_detector_autotune(StDetector* det, void* workspace_dev, size_t
 // id 40 = the fused Focus+stem kernel (stem_focus_conv.hip), reported with the conv ops
 // id 41 = the streaming 1x1 kernel for narrow layers (pointwise_conv.hip)
 extern "C" const char* st_conv_variant_name(int id) {
-  return id == 45 ? "front3x3s2" : id == 40 ? "stem6x6s2" : id == 41 ? "pw128" : id == 42 ? "dc4x32" : id == 43 ? "wino2x2" : id == 44 ? "wino2x2n" : conv_variant_name(id);
+  return id == 46 ? "pwres" : id == 45 ? "front3x3s2" : id == 40 ? "stem6x6s2" : id == 41 ? "pw128" : id == 42 ? "dc4x32" : id == 43 ? "wino2x2" : id == 44 ? "wino2x2n" : conv_variant_name(id);
 }
 extern "C" const char* st_conv_variant_signature(int id) {
-  return id == 45 ? "front_s2_csp" : id == 40 ? "stem_focus_conv" : id == 41 ? "pw_conv" : id == 42 ? "direct_conv3x3" : id == 43 ? "wino_conv3x3" : id == 44 ? "wino_conv3x3 narrow"
+  return id == 46 ? "pw_resident" : id == 45 ? "front_s2_csp" : id == 40 ? "stem_focus_conv" : id == 41 ? "pw_conv" : id == 42 ? "direct_conv3x3" : id == 43 ? "wino_conv3x3" : id == 44 ? "wino_conv3x3 narrow"
                                                               : conv_variant_signature(id);
 }
 
@@ -956,7 +966,7 @@ extern "C" int st_detector_set_tuning(StDetector* det, const int* variants, int 
   for (int i = 0; i < n; ++i) {
     const Op& o = det->ops[i];
     if (variants[i] < 0 || o.type != Op::CONV) continue;
-    if (variants[i] >= 41 && variants[i] <= 44) continue;   // own applicability checks run at launch
+    if (variants[i] >= 41 && variants[i] <= 46) continue;   // own applicability checks run at launch
     ST_REQUIRE(conv_variant_valid(variants[i], det->convs[o.pc].cout), "st_detector_set_tuning: variant %d invalid for op %d",
                variants[i], i);
   }

@@ -520,3 +520,82 @@ def test_fused_stage1_front_matches_separate_convolutions(N, H, W, in_ld, in_off
     a.stride = 1
     assert lib.st_conv3x3s2_csp_front(C.byref(a), C.byref(m), C.byref(c), frags[0].data_ptr(), frags[1].data_ptr(), stream) != 0
     assert b'fused front' in lib.st_last_error()
+
+
+@pytest.mark.parametrize('cin,cout,split,res,act,shape,in_ld,in_off', [
+    (64, 64, None, False, 1, (2, 23, 41), None, 0),      # bottleneck conv1 of stage 2 / final conv of stage 1; ragged M
+    (64, 64, None, True, 1, (1, 16, 64), 96, 32),        # + residual and post_scale (branch average), input slice
+    (128, 128, 64, False, 1, (2, 19, 33), None, 0),      # CSP main | short, split store
+    (128, 128, None, False, 0, (1, 9, 17), None, 0),     # no activation
+    (128, 128, None, True, 1, (1, 12, 20), None, 0),
+    (256, 128, 64, False, 1, (1, 23, 40), None, 0),      # PAFPN top-down main | short
+    (128, 64, None, False, 1, (3, 7, 9), None, 0),
+    (64, 64, 32, False, 1, (1, 5, 3), None, 0),          # fewer pixels than one tile per wave
+])
+def test_resident_pointwise_kernel_matches_torch(cin, cout, split, res, act, shape, in_ld, in_off, cuda):
+    """Tile variant 46 (pointwise_resident.hip): weights resident in LDS, pixels loaded straight into MFMA operand
+    registers; same results as the fp64 torch convolution and as the implicit-GEMM kernel within fp32 rounding."""
+    N, H, W = shape
+    torch.manual_seed(cin + cout + H)
+    x = torch.randn(N, cin, H, W)
+    w, b = torch.randn(cout, cin, 1, 1) / cin ** 0.5, torch.randn(cout)
+    r = torch.randn(N, cout, H, W) if res else None
+    got, _ = run_conv(x, w, b, 1, 0, act, cuda, variant=46, res=r, post_scale=0.5 if res else 1.0, split=split,
+                      in_ld=in_ld, in_off=in_off)
+    assert_close(got, ref_conv(x, w, b, 1, 0, act, res=r, post_scale=0.5 if res else 1.0))
+    base, _ = run_conv(x, w, b, 1, 0, act, cuda, variant=-1, res=r, post_scale=0.5 if res else 1.0, split=split,
+                       in_ld=in_ld, in_off=in_off)
+    assert (got - base).abs().max().item() <= 2e-5 * (base.abs().max().item() + 1e-6)
+
+
+def test_resident_pointwise_kernel_rejects_other_shapes(cuda):
+    lib = _lib.load()
+    for cin, cout, k in ((32, 32, 1), (512, 256, 1), (64, 64, 3), (128, 128, 3)):
+        with pytest.raises(Exception):
+            run_conv(torch.randn(1, cin, 8, 8), torch.randn(cout, cin, k, k), torch.zeros(cout), 1, k // 2, 1, cuda, variant=46)
+        assert b'resident 1x1 conv' in lib.st_last_error()
+
+
+@pytest.mark.parametrize('cin,N,H,W', [(128, 2, 23, 41), (256, 1, 12, 20)])
+def test_chained_resident_pointwise_pair_matches_torch(cin, N, H, W, cuda):
+    """st_conv1x1_chain one stage deeper: main | short (cin -> 64 | 64, split store) with the bottleneck conv1
+    (64 -> 64) chained on the main half from registers, on the LDS-resident kernel."""
+    lib = _lib.load()
+    torch.manual_seed(cin + H)
+    x = torch.randn(N, cin, H, W)
+    wa, ba = torch.randn(128, cin, 1, 1) / cin ** 0.5, torch.randn(128)
+    wb, bb = torch.randn(64, 64, 1, 1) / 8.0, torch.randn(64)
+    xin = x.permute(0, 2, 3, 1).contiguous().to(cuda)
+    (wpa, bpa), (wpb, bpb) = pack(wa, ba), pack(wb, bb)
+    wpa, bpa, wpb, bpb = wpa.to(cuda), bpa.to(cuda), wpb.to(cuda), bpb.to(cuda)
+    main = torch.full((N, H, W, 64), -777.0, device=cuda)
+    cat = torch.full((N, H, W, 128), -777.0, device=cuda)     # short goes to channels [64, 128)
+    tmp = torch.full((N, H, W, 68), -777.0, device=cuda)      # chained output at channel offset 4
+    a = StConvDesc()
+    a.in_dev = xin.data_ptr(); a.N, a.Hi, a.Wi, a.Cin, a.in_ld, a.in_off = N, H, W, cin, cin, 0
+    a.wgt_dev = wpa.data_ptr(); a.bias_dev = bpa.data_ptr()
+    a.Cout, a.KH, a.KW, a.stride, a.pad = 128, 1, 1, 1, 0
+    a.out1_dev = main.data_ptr(); a.out1_ld, a.out1_off, a.split = 64, 0, 64
+    a.out2_dev = cat.data_ptr(); a.out2_ld, a.out2_off = 128, 64
+    a.act, a.post_scale = 1, 1.0
+    b = StConvDesc()
+    b.in_dev = main.data_ptr(); b.N, b.Hi, b.Wi, b.Cin, b.in_ld, b.in_off = N, H, W, 64, 64, 0
+    b.wgt_dev = wpb.data_ptr(); b.bias_dev = bpb.data_ptr()
+    b.Cout, b.KH, b.KW, b.stride, b.pad = 64, 1, 1, 1, 0
+    b.out1_dev = tmp.data_ptr(); b.out1_ld, b.out1_off, b.split = 68, 4, 64
+    b.act, b.post_scale = 1, 1.0
+    check(lib.st_conv1x1_chain(C.byref(a), C.byref(b), _lib.current_stream()))
+    torch.cuda.synchronize()
+    ya = ref_conv(x, wa, ba, 1, 0, 1)
+    yb = F.silu(F.conv2d(ya[:, :64], wb.double(), bb.double()))
+    assert_close(main.cpu().permute(0, 3, 1, 2), ya[:, :64])
+    assert_close(cat.cpu()[..., 64:].permute(0, 3, 1, 2), ya[:, 64:])
+    assert torch.all(cat.cpu()[..., :64] == -777.0)
+    assert_close(tmp.cpu()[..., 4:].permute(0, 3, 1, 2), yb)
+    assert torch.all(tmp.cpu()[..., :4] == -777.0)
+    # bit-identical to running conv1 separately on the stored main output with the same kernel
+    tmp2 = torch.full((N, H, W, 68), -777.0, device=cuda)
+    b.out1_dev = tmp2.data_ptr()
+    check(lib.st_conv2d_nhwc_variant(C.byref(b), _lib.current_stream(), 46))
+    torch.cuda.synchronize()
+    assert torch.equal(tmp, tmp2)
