@@ -167,6 +167,9 @@ __global__ __launch_bounds__(FF_THREADS, 1) void front_s2_csp_kernel(const Front
   const __amdgpu_buffer_rsrc_t srsrc = __builtin_amdgcn_make_buffer_rsrc(p.out_short, 0, (int)p.short_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t trsrc = __builtin_amdgcn_make_buffer_rsrc(p.out_tmp, 0, (int)p.tmp_bytes, 0x00020000);
 
+#ifdef ST_ABLATION
+  if ((p.abl & 64) && ((0x96 >> wave) & 1)) __builtin_amdgcn_s_sleep(90);   // waves 1, 2, 4, 7: half a tile late
+#endif
   for (; tile < p.ntiles; tile += stride) {
     // where this tile's results go (before `locate` moves on to the next tile)
     const int tx = tile % p.tiles_x, orow = tile / p.tiles_x;

@@ -63,6 +63,54 @@ struct WinoArgs {
 
 __device__ __forceinline__ float wn_silu(float v) { return v * __builtin_amdgcn_rcpf(1.0f + __expf(-v)); }
 
+// f32x4 arithmetic as two packed-f32 instructions (v_pk_add_f32 / v_pk_fma_f32: two IEEE fp32 results per lane and
+// instruction).  fp32 MFMA runs on the same FMA lanes as the vector ALU (equal peaks; measured: VALU time adds to MFMA
+// time, tools/micro/mfma_peak.hip), so every VALU instruction of the transforms is taken from the matrix rate.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+// (written as instructions: from <2 x float> IR the compiler scalarises most of them again)
+__device__ __forceinline__ f32x2 wn_pk_add(f32x2 a, f32x2 b) {
+  f32x2 r;
+  asm("v_pk_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ f32x2 wn_pk_sub(f32x2 a, f32x2 b) {
+  f32x2 r;
+  asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ f32x2 wn_pk_fma(f32x2 a, f32x2 b, f32x2 c) {
+  f32x2 r;
+  asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+__device__ __forceinline__ f32x2 wn_lo(f32x4 a) { return __builtin_shufflevector(a, a, 0, 1); }
+__device__ __forceinline__ f32x2 wn_hi(f32x4 a) { return __builtin_shufflevector(a, a, 2, 3); }
+__device__ __forceinline__ f32x4 wn_join(f32x2 lo, f32x2 hi) { return __builtin_shufflevector(lo, hi, 0, 1, 2, 3); }
+__device__ __forceinline__ f32x4 wn_add(f32x4 a, f32x4 b) {
+  return wn_join(wn_pk_add(wn_lo(a), wn_lo(b)), wn_pk_add(wn_hi(a), wn_hi(b)));
+}
+__device__ __forceinline__ f32x4 wn_sub(f32x4 a, f32x4 b) {
+  return wn_join(wn_pk_sub(wn_lo(a), wn_lo(b)), wn_pk_sub(wn_hi(a), wn_hi(b)));
+}
+// a + s * b with s = +-1: s * b is exact, so the single rounding of the fma is the rounding of a +- b
+__device__ __forceinline__ f32x4 wn_addsgn(f32x4 a, f32x2 s, f32x4 b) {
+  return wn_join(wn_pk_fma(s, wn_lo(b), wn_lo(a)), wn_pk_fma(s, wn_hi(b), wn_hi(a)));
+}
+// The same, for values an MFMA consumes next: a VALU write needs 2 wait states before an MFMA reads the register.
+// The compiler inserts them after its own VALU instructions, but it does not look inside an asm statement.
+__device__ __forceinline__ f32x4 wn_add_mfma(f32x4 a, f32x4 b) {
+  f32x2 lo, hi;
+  asm("v_pk_add_f32 %0, %2, %4\n\tv_pk_add_f32 %1, %3, %5\n\ts_nop 1"
+      : "=&v"(lo), "=&v"(hi) : "v"(wn_lo(a)), "v"(wn_hi(a)), "v"(wn_lo(b)), "v"(wn_hi(b)));
+  return wn_join(lo, hi);
+}
+__device__ __forceinline__ f32x4 wn_sub_mfma(f32x4 a, f32x4 b) {
+  f32x2 lo, hi;
+  asm("v_pk_add_f32 %0, %2, %4 neg_lo:[0,1] neg_hi:[0,1]\n\tv_pk_add_f32 %1, %3, %5 neg_lo:[0,1] neg_hi:[0,1]\n\ts_nop 1"
+      : "=&v"(lo), "=&v"(hi) : "v"(wn_lo(a)), "v"(wn_hi(a)), "v"(wn_lo(b)), "v"(wn_hi(b)));
+  return wn_join(lo, hi);
+}
+
 // CBN = cout blocks of 32 a workgroup computes; LCBN = cout blocks per group in the weight LAYOUT (>= CBN).  LCBN = 2 with
 // CBN = 1 (tile variant 44) runs a 64-cout layout with 32-cout workgroups: twice the workgroups, for the small maps
 // (23x40, 46x80) whose grid otherwise fills less than one round of the chip.
@@ -124,7 +172,7 @@ __global__ __launch_bounds__(256, 2) void wino_conv3x3_kernel(const WinoArgs p) 
   //   a = 0: d0 - d2    a = 1: d1 + d2    a = 2: d2 - d1    a = 3: d1 - d3
   const int r0 = a == 0 ? 0 : (a == 2 ? 2 : 1);
   const int r1 = a == 0 ? 2 : (a == 1 ? 2 : (a == 2 ? 1 : 3));
-  const float sgn = a == 1 ? 1.0f : -1.0f;
+  const f32x2 sgn = a == 1 ? f32x2{1.0f, 1.0f} : f32x2{-1.0f, -1.0f};
   int qoff[8], qsw[8];
 #pragma unroll
   for (int k = 0; k < 8; ++k) {
@@ -138,14 +186,16 @@ __global__ __launch_bounds__(256, 2) void wino_conv3x3_kernel(const WinoArgs p) 
   constexpr int SPLIT = LCBN / CBN;   // workgroups sharing one layout group
   const unsigned wbase = (unsigned)(((((cb / SPLIT) * 4 + a) * p.nkc) * 16) * WN_FRAG_FLOATS + (cb % SPLIT) * CBN * 256 +
                                     lane * 4) * 4u;
-  auto load_frag = [&](int step, f32x4 (&f)[CBN]) {   // step = (kc * 4 + g) * 4 + b ; past the end: zeros
-#ifdef ST_ABLATION
+  const int last_step = p.nkc * 16 - 1;
+  auto load_frag = [&](int step, f32x4 (&f)[CBN]) {   // step = (kc * 4 + g) * 4 + b; the prefetch past the last step
+#ifdef ST_ABLATION                                     // re-reads the last one (never used)
     if ((p.abl & 1) && step > 1) return;
 #endif
-    const unsigned off = wbase + (unsigned)step * (WN_FRAG_FLOATS * 4u);
+    // the step displacement is wave-uniform: it rides in the scalar offset, no vector add per load
+    const int soff = (step < last_step ? step : last_step) * (WN_FRAG_FLOATS * 4);
 #pragma unroll
     for (int nb = 0; nb < CBN; ++nb)
-      f[nb] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, off + 1024u * nb, 0, 0));
+      f[nb] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, wbase, soff + 1024 * nb, 0));
   };
 
   f32x16 acc[4][CBN];
@@ -185,11 +235,11 @@ __global__ __launch_bounds__(256, 2) void wino_conv3x3_kernel(const WinoArgs p) 
         d[k] = *reinterpret_cast<const f32x4*>(win + qoff[k] + (((2 * g + h) ^ qsw[k]) << 2));
       f32x4 P[4], V[4];
 #pragma unroll
-      for (int c = 0; c < 4; ++c) P[c] = d[c] + sgn * d[4 + c];
-      V[0] = P[0] - P[2];
-      V[1] = P[1] + P[2];
-      V[2] = P[2] - P[1];
-      V[3] = P[1] - P[3];
+      for (int c = 0; c < 4; ++c) P[c] = wn_addsgn(d[c], sgn, d[4 + c]);
+      V[0] = wn_sub_mfma(P[0], P[2]);
+      V[1] = wn_add_mfma(P[1], P[2]);
+      V[2] = wn_sub_mfma(P[2], P[1]);
+      V[3] = wn_sub_mfma(P[1], P[3]);
 #pragma unroll
       for (int b = 0; b < 4; ++b) {
         const int step = (kc * 4 + g) * 4 + b;
@@ -221,15 +271,26 @@ __global__ __launch_bounds__(256, 2) void wino_conv3x3_kernel(const WinoArgs p) 
 #endif
   // ---- output transform.  Row reduction over b in registers: R[0] = M0 + M1 + M2, R[1] = M1 - M2 - M3
   float* Rb = smem;   // [a][j][tile][co]: every wave is past its last window read (barrier above)
+  // The packed adds below are written as instructions, which the compiler's hazard recogniser does not see as VALU
+  // reads of MFMA results: cover the 32x32 MFMA write -> VALU read distance (18 wait states) by hand.
+  __builtin_amdgcn_sched_barrier(0);
+  asm volatile("s_nop 15\n\ts_nop 3" ::: "memory");
+  __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
   for (int nb = 0; nb < CBN; ++nb)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int m = (r & 3) + 8 * (r >> 2) + 4 * h;
-      const float R0 = (acc[0][nb][r] + acc[1][nb][r]) + acc[2][nb][r];
-      const float R1 = (acc[1][nb][r] - acc[2][nb][r]) - acc[3][nb][r];
-      Rb[((a * 2 + 0) * 32 + m) * WN_CB + nb * 32 + i] = R0;
-      Rb[((a * 2 + 1) * 32 + m) * WN_CB + nb * 32 + i] = R1;
+      if (r & 1) continue;   // accumulator registers r, r + 1 as one packed pair (tile rows m, m + 1)
+      const f32x2 a0{acc[0][nb][r], acc[0][nb][r + 1]}, a1{acc[1][nb][r], acc[1][nb][r + 1]};
+      const f32x2 a2{acc[2][nb][r], acc[2][nb][r + 1]}, a3{acc[3][nb][r], acc[3][nb][r + 1]};
+      const f32x2 R0 = wn_pk_add(wn_pk_add(a0, a1), a2);
+      const f32x2 R1 = wn_pk_sub(wn_pk_sub(a1, a2), a3);
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        Rb[((a * 2 + 0) * 32 + m + e) * WN_CB + nb * 32 + i] = R0[e];
+        Rb[((a * 2 + 1) * 32 + m + e) * WN_CB + nb * 32 + i] = R1[e];
+      }
     }
   __syncthreads();
   // column reduction over a + epilogue: wave w takes tiles 8w .. 8w+7 (= tile row w).  A lane owns 4 consecutive couts
@@ -251,13 +312,13 @@ __global__ __launch_bounds__(256, 2) void wino_conv3x3_kernel(const WinoArgs p) 
       const f32x4 q1 = *reinterpret_cast<const f32x4*>(Rb + ((1 * 2 + j) * 32 + t) * WN_CB + c4);
       const f32x4 q2 = *reinterpret_cast<const f32x4*>(Rb + ((2 * 2 + j) * 32 + t) * WN_CB + c4);
       const f32x4 q3 = *reinterpret_cast<const f32x4*>(Rb + ((3 * 2 + j) * 32 + t) * WN_CB + c4);
-      const f32x4 y[2] = {(q0 + q1) + q2, (q1 - q2) - q3};
+      const f32x4 y[2] = {wn_add(wn_add(q0, q1), q2), wn_sub(wn_sub(q1, q2), q3)};
 #pragma unroll
       for (int ii = 0; ii < 2; ++ii) {
         const int oy = oy0 + ii, ox = ox0 + j;
         const bool ok = oy < p.H && ox < p.W && co < p.Cout;   // Cout is a multiple of 4: a quad is in or out as a whole
         const int m = (n * p.H + oy) * p.W + ox;
-        f32x4 v = y[ii] + bias4;
+        f32x4 v = wn_add(y[ii], bias4);
         if (p.act) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] = wn_silu(v[e]);
