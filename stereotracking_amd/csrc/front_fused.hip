@@ -73,7 +73,8 @@ __global__ __launch_bounds__(FF_THREADS, 1) void front_s2_csp_kernel(const Front
   float* wms = w3 + FF_W3_FLOATS;
   float* wc1 = wms + FF_MS_FLOATS;
   float* bias = wc1 + FF_C1_FLOATS;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: tile bookkeeping runs on the scalar unit
   const int i16 = lane & 15, kq = lane >> 4;
 
 #if defined(__HIP_DEVICE_COMPILE__)  // device-only builtins; the host pass only needs the kernel stub
@@ -180,7 +181,8 @@ __global__ __launch_bounds__(FF_THREADS, 1) void front_s2_csp_kernel(const Front
 
     f32x4 acc[4];
 #pragma unroll
-    for (int cb = 0; cb < 4; ++cb) acc[cb] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int cb = 0; cb < 4; ++cb) acc[cb] = *reinterpret_cast<const f32x4*>(bias + cb * 16 + 4 * kq);   // bias: the
+    // accumulator starts from it (no vector add per output later - VALU time adds to MFMA time)
     // 18 steps (tap, g) of 16 MFMAs.  The A fragments of step k + 1 are read from LDS before the MFMAs of step k; the
     // scheduling barrier after every step keeps the compiler from hoisting the next tile's pixel loads above the MFMAs
     // that still read the current ones (which would double the 72 fragment registers and spill).
@@ -228,14 +230,13 @@ __global__ __launch_bounds__(FF_THREADS, 1) void front_s2_csp_kernel(const Front
     f32x4 va[4];
 #pragma unroll
     for (int cb = 0; cb < 4; ++cb) {
-      const f32x4 bq = *reinterpret_cast<const f32x4*>(bias + cb * 16 + 4 * kq);
 #pragma unroll
-      for (int e = 0; e < 4; ++e) va[cb][e] = ff_silu(acc[cb][e] + bq[e]);
+      for (int e = 0; e < 4; ++e) va[cb][e] = ff_silu(acc[cb][e]);
     }
     // ---- main | short = SiLU(W_ms . va + b)   (K = 64: 4 cout blocks of stage A x 4 steps)
     f32x4 am[4];
 #pragma unroll
-    for (int c2 = 0; c2 < 4; ++c2) am[c2] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int c2 = 0; c2 < 4; ++c2) am[c2] = *reinterpret_cast<const f32x4*>(bias + 64 + c2 * 16 + 4 * kq);
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
       f32x4 wf[4];
@@ -250,9 +251,8 @@ __global__ __launch_bounds__(FF_THREADS, 1) void front_s2_csp_kernel(const Front
     f32x4 vm[4];
 #pragma unroll
     for (int c2 = 0; c2 < 4; ++c2) {
-      const f32x4 bq = *reinterpret_cast<const f32x4*>(bias + 64 + c2 * 16 + 4 * kq);
 #pragma unroll
-      for (int e = 0; e < 4; ++e) vm[c2][e] = ff_silu(am[c2][e] + bq[e]);
+      for (int e = 0; e < 4; ++e) vm[c2][e] = ff_silu(am[c2][e]);
     }
 #ifdef ST_ABLATION
     const bool no_store = p.abl & 16;
@@ -272,7 +272,7 @@ __global__ __launch_bounds__(FF_THREADS, 1) void front_s2_csp_kernel(const Front
     // ---- conv1(main) = SiLU(W_c1 . vm[0..1] + b)   (K = 32)
     f32x4 ac[2];
 #pragma unroll
-    for (int c3 = 0; c3 < 2; ++c3) ac[c3] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int c3 = 0; c3 < 2; ++c3) ac[c3] = *reinterpret_cast<const f32x4*>(bias + 128 + c3 * 16 + 4 * kq);
 #pragma unroll
     for (int c2 = 0; c2 < 2; ++c2) {
       f32x4 wf[2];
@@ -286,10 +286,9 @@ __global__ __launch_bounds__(FF_THREADS, 1) void front_s2_csp_kernel(const Front
     }
 #pragma unroll
     for (int c3 = 0; c3 < 2; ++c3) {
-      const f32x4 bq = *reinterpret_cast<const f32x4*>(bias + 128 + c3 * 16 + 4 * kq);
       f32x4 vt;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) vt[e] = ff_silu(ac[c3][e] + bq[e]);
+      for (int e = 0; e < 4; ++e) vt[e] = ff_silu(ac[c3][e]);
       const unsigned ot = st_ok && !no_store ? (unsigned)((m * p.tmp_ld + p.tmp_off + c3 * 16 + 4 * kq) * 4) : 0x80000000u;
       __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, vt), trsrc, ot, 0, 0);
     }

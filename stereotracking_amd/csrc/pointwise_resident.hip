@@ -55,7 +55,8 @@ __global__ __launch_bounds__(PR_THREADS, 1) void pw_resident_kernel(const PwrArg
   float* wl = reinterpret_cast<float*>(pr_smem4);   // [cb][g][lane][4]
   float* wl2 = wl + CB * KG * 256;                  // [c3][c2][lane][4]
   float* bl = wl2 + CH * CH * 256;                  // bias (16 CB) | bias2 (16 CH)
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: tile bookkeeping on the scalar unit
   const int i16 = lane & 15, kq = lane >> 4;
 
 #if defined(__HIP_DEVICE_COMPILE__)  // device-only builtins; the host pass only needs the kernel stub
@@ -120,7 +121,8 @@ __global__ __launch_bounds__(PR_THREADS, 1) void pw_resident_kernel(const PwrArg
     }
     f32x4 acc[CB];
 #pragma unroll
-    for (int cb = 0; cb < CB; ++cb) acc[cb] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int cb = 0; cb < CB; ++cb) acc[cb] = *reinterpret_cast<const f32x4*>(bl + cb * 16 + 4 * kq);   // starts from
+    // the bias: no vector add per output later (VALU time adds to MFMA time on the fp32 matrix path)
     // KG steps of 4 CB MFMAs; the A fragments of step g + 1 are read from LDS before the MFMAs of step g, and the
     // scheduling barriers keep (a) those reads above the MFMAs they overlap with and (b) the next tile's pixel loads
     // below the MFMAs that still read the current ones
@@ -149,17 +151,13 @@ __global__ __launch_bounds__(PR_THREADS, 1) void pw_resident_kernel(const PwrArg
     f32x4 v[CB];
 #pragma unroll
     for (int cb = 0; cb < CB; ++cb) {
-      const f32x4 bq = *reinterpret_cast<const f32x4*>(bl + cb * 16 + 4 * kq);
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const float t = acc[cb][e] + bq[e];
-        v[cb][e] = p.act ? pr_silu(t) : t;
-      }
+      for (int e = 0; e < 4; ++e) v[cb][e] = p.act ? pr_silu(acc[cb][e]) : acc[cb][e];
     }
     if (CH > 0) {   // chained conv on channels [0, 16 CH) (before any residual: CSP main_conv has none)
       f32x4 ac[CH > 0 ? CH : 1];
 #pragma unroll
-      for (int c3 = 0; c3 < CH; ++c3) ac[c3] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int c3 = 0; c3 < CH; ++c3) ac[c3] = *reinterpret_cast<const f32x4*>(bl + 16 * CB + c3 * 16 + 4 * kq);
 #pragma unroll
       for (int c2 = 0; c2 < CH; ++c2) {
         f32x4 w2[CH > 0 ? CH : 1];
@@ -173,13 +171,9 @@ __global__ __launch_bounds__(PR_THREADS, 1) void pw_resident_kernel(const PwrArg
       }
 #pragma unroll
       for (int c3 = 0; c3 < CH; ++c3) {
-        const f32x4 bq = *reinterpret_cast<const f32x4*>(bl + 16 * CB + c3 * 16 + 4 * kq);
         f32x4 t;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const float u = ac[c3][e] + bq[e];
-          t[e] = p.act2 ? pr_silu(u) : u;
-        }
+        for (int e = 0; e < 4; ++e) t[e] = p.act2 ? pr_silu(ac[c3][e]) : ac[c3][e];
         const unsigned o = st_ok ? (unsigned)((m * p.out3_ld + p.out3_off + c3 * 16 + 4 * kq) * 4) : 0x80000000u;
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, t), o3rsrc, o, 0, 0);
       }
