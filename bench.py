@@ -46,6 +46,9 @@ def parse():
     ap.add_argument('--frames-per-call', type=int, default=64,
                     help='frames of ONE video handed to each model.test_step call of the second leg (BASELINE configs[2] '
                          'is a 64-frame sequence); they run --batch at a time on the model\'s in-flight contexts')
+    ap.add_argument('--frames-per-call-long', type=int, default=256,
+                    help='a second, longer test_step call size: the per-call fill / drain of the in-flight contexts '
+                         '(~5 ms) is amortised over more frames (0 = skip)')
     ap.add_argument('--sustain-seconds', type=float, default=2.0,
                     help='after the K timed steps, keep stepping for this long and report it as `sustained`')
     ap.add_argument('--cpu-seconds', type=float, default=15.0, help='budget of the CPU oracle leg')
@@ -122,18 +125,23 @@ def conv_roofline(pipe, img, right, steps):
         n_agg, ms_agg = agg.get(v, [0, 0.0])
         t = (tot_ms[sel].sum() + ms_agg) / steps
         fl = 2.0 * (macs[sel].sum() + agg_macs * n_agg / steps)
-        per_variant[VARIANT_TILES[v]] = dict(launches=int(sel.sum()) + n_agg // steps, ms_per_step=round(float(t), 4),
+        n_launch = int(sel.sum()) + n_agg // steps
+        if VARIANT_TILES[v] == 'front3x3s2':
+            n_launch //= 3      # one launch computes three ops of the plan (3x3/s2 + main|short + conv1)
+        per_variant[VARIANT_TILES[v]] = dict(launches=n_launch, ms_per_step=round(float(t), 4),
                                              gflop_per_step=round(fl / 1e9, 3),
                                              tflops=round(fl / (t * 1e-3) / 1e12, 3) if t > 0 else 0.0)
     # Kernel families of the MFMA work.  `roofline` describes the DOMINANT one = the family with the largest summed
     # duration per step.  conv_igemm_kernel's tile instances are one kernel template (which instance a layer uses is
     # an autotune outcome that varies from run to run) and are aggregated; the Winograd, direct 3x3, streaming 1x1
-    # and fused-stem kernels are families of their own.  `achieved` = ALGORITHMIC flops (2 x MACs of the direct
+    # fused-stem, fused-front and LDS-resident 1x1 kernels are families of their own (a chained 1x1 pair counts as two
+    # `launches` here: ops of the plan, the second with only the event overhead as duration).  `achieved` = ALGORITHMIC flops (2 x MACs of the direct
     # convolution) / summed duration.  The Winograd kernel executes 2.25x fewer multiplies than
     # that for the same convolution, so its algorithmic rate may exceed the MFMA peak: `mfma_executed_tflops` is the
     # rate of the multiplies it actually issues (= what the matrix pipes see).
     FAMILY = {'stem6x6s2': 'st::stem_focus_conv_kernel', 'pw128': 'st::pw_conv_kernel', 'dc4x32': 'st::direct_conv3x3_kernel',
-              'wino2x2': 'st::wino_conv3x3_kernel', 'wino2x2n': 'st::wino_conv3x3_kernel', 'skipped': None}
+              'wino2x2': 'st::wino_conv3x3_kernel', 'wino2x2n': 'st::wino_conv3x3_kernel', 'skipped': None,
+              'front3x3s2': 'st::front_s2_csp_kernel', 'pwres': 'st::pw_resident_kernel'}
     fam = {}
     for name, v in per_variant.items():
         f = FAMILY.get(name, 'st::conv_igemm_kernel')
@@ -323,11 +331,13 @@ def test_step_leg(args, sd, batch_cpu, dev, pairs_target):
     right = [batch_cpu['right'][i % B:i % B + 1, :, :720].to(torch.uint8).to(dev) for i in range(F)]
     frame = [0]
 
-    def call():
+    def call(nf=None):
+        nf = nf or F
         samples = [TrackDataSample(dict(frame_id=frame[0] + i, ori_shape=(720, 1280), img_shape=(720, 1280),
-                                        scale_factor=(1.0, 1.0))) for i in range(F)]
-        frame[0] += F
-        return model.test_step(dict(inputs=dict(img=list(left), right=list(right)), data_samples=samples))
+                                        scale_factor=(1.0, 1.0))) for i in range(nf)]
+        frame[0] += nf
+        return model.test_step(dict(inputs=dict(img=[left[i % F] for i in range(nf)],
+                                                right=[right[i % F] for i in range(nf)]), data_samples=samples))
 
     for _ in range(2):
         outs = call()
@@ -339,8 +349,19 @@ def test_step_leg(args, sd, batch_cpu, dev, pairs_target):
         outs = call()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    tm = model.timings
-    return dict(value=round(calls * F / dt, 3), unit='stereo frame-pairs/s', calls=calls, frames_per_call=F,
+    tm = dict(model.timings)
+    long_call = None
+    FL = args.frames_per_call_long
+    if FL > F:
+        call(FL)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(2):
+            call(FL)
+        torch.cuda.synchronize()
+        long_call = dict(frames_per_call=FL, calls=2, value=round(2 * FL / (time.perf_counter() - t0), 3),
+                         unit='stereo frame-pairs/s')
+    return dict(value=round(calls * F / dt, 3), long_call=long_call, unit='stereo frame-pairs/s', calls=calls, frames_per_call=F,
                 ms_per_call=round(dt / calls * 1e3, 3),
                 path='Config.fromfile(stereo_yolox_s_mot_airdrone_costvolume.py) -> MODELS.build -> model.test_step',
                 tracker_ms_per_frame=round(tm['tracker_s'] / max(tm['frames'], 1) * 1e3, 4),
@@ -506,6 +527,8 @@ def main():
             del runner   # its three workspaces are not needed any more
             line['test_step'] = test_step_leg(args, sd, batch_cpu, dev, B * args.steps)
             line['test_step']['vs_pipeline'] = round(line['test_step']['value'] / line['value'], 4)
+            if line['test_step'].get('long_call'):
+                line['test_step']['long_call']['vs_pipeline'] = round(line['test_step']['long_call']['value'] / line['value'], 4)
         line['tracker_cpu'] = tracker_cost()
         if world == 1 and not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline(sd, batch_cpu, args.max_disp, args.cpu_seconds, args.agg_layers)
