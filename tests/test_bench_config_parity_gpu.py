@@ -102,6 +102,15 @@ def test_benched_configuration_parity(cuda):
             sel = same_win if key in ('depth', 'scales', 'scaled_boxes') else torch.ones_like(same_win)
             g, r = out[key][n, ia][sel], ref[key][n, ib][sel]
             assert torch.equal(torch.isnan(g), torch.isnan(r)), (n, key)
+            if key == 'scaled_boxes':
+                # The depth-scaled boxes (trackers/utils.py:58-73: centre -+ extent * scale / 2) are NOT clamped to the
+                # image, so a coordinate can be small while the box is hundreds of pixels wide; an edge inherits the
+                # relative error of the EXTENT (exp of a head value held to 1e-3).  Their error is therefore measured
+                # against max(1, |coordinate|, box extent) - the same 1e-3, relative to the quantity that carries it.
+                ext = torch.maximum(r[:, 2] - r[:, 0], r[:, 3] - r[:, 1]).abs().nan_to_num(1.0)[:, None]
+                d = ((g - r).abs() / torch.maximum(r.abs().clamp(min=1.0), ext)).nan_to_num(0.0)
+                a[key] = max(a.get(key, 0.0), float(d.max()) if d.numel() else 0.0)
+                continue
             a[key] = max(a.get(key, 0.0), rel_err(g.nan_to_num(0.0).cpu(), r.nan_to_num(0.0).cpu()))
     rec['tuned_vs_untuned_max_rel_err'] = a
     rec['tuned_vs_untuned_kept'] = tu
@@ -123,7 +132,7 @@ def test_benched_configuration_parity(cuda):
     print(rec)
 
     # ---- the bars ---------------------------------------------------------------------------------------
-    assert any(v in (41, 42) for v in tuned), 'autotune picked neither the streaming 1x1 nor the direct 3x3 kernel'
+    assert any(v >= 41 for v in tuned), 'autotune picked none of the specialised kernels (41-46)'
     assert int(counts.max()) <= M and not rec['overflow'], f'detection buffer of {M} rows overflowed: {counts.tolist()}'
     assert int(counts.min()) > 0
     for key, e in a.items():

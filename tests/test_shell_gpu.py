@@ -90,7 +90,7 @@ def test_golden_costvolume_and_box_depth(cuda):
 
 
 # ---- plugin surface end to end --------------------------------------------------------------------------------
-def build_model(cfg_path, cuda, widen=0.375, seed=5, prior_prob=0.2):
+def build_model(cfg_path, cuda, widen=0.375, seed=5, prior_prob=0.2, autotune=True):
     from stereotracking_amd import mot  # noqa: F401
     from stereotracking_amd.config import Config
     from stereotracking_amd.registry import MODELS
@@ -101,7 +101,7 @@ def build_model(cfg_path, cuda, widen=0.375, seed=5, prior_prob=0.2):
     # random weights give low scores: lower the tracker's score gates so tracks are actually started/matched
     cfg.model.tracker['init_track_thr'] = 0.03
     cfg.model.tracker['obj_score_thr'] = 0.02
-    model = MODELS.build(cfg.model)
+    model = MODELS.build(dict(cfg.model, autotune=autotune))
     # confident synthetic head so that tracks get started (score > init_track_thr = 0.7)
     table = list(model.detector._table)
     if model.stereo is not None:
@@ -184,7 +184,10 @@ def test_mot_shell_matches_oracle_composition(cuda):
 
 def test_batched_predict_equals_sequential_and_stereo_module(cuda):
     from stereotracking_amd.structures import TrackDataSample
-    model, sd, _ = build_model(CFG_STEREO, cuda)
+    # Bit equality between one 3-frame call and three 1-frame calls is a property of ONE kernel plan: the model
+    # builds (and would autotune) a launch plan per batch size, and two plans that pick different kernel instances for
+    # a layer (Winograd vs implicit GEMM, ...) differ by fp32 summation order.  The heuristic plan is the same for both.
+    model, sd, _ = build_model(CFG_STEREO, cuda, autotune=False)
     ori = (80, 160)
     fr = synthetic_batch([50, 51, 52], ori[0], ori[1], 32)
 
