@@ -141,7 +141,8 @@ def conv_roofline(pipe, img, right, steps):
     # rate of the multiplies it actually issues (= what the matrix pipes see).
     FAMILY = {'stem6x6s2': 'st::stem_focus_conv_kernel', 'pw128': 'st::pw_conv_kernel', 'dc4x32': 'st::direct_conv3x3_kernel',
               'wino2x2': 'st::wino_conv3x3_kernel', 'wino2x2n': 'st::wino_conv3x3_kernel', 'skipped': None,
-              'front3x3s2': 'st::front_s2_csp_kernel', 'pwres': 'st::pw_resident_kernel'}
+              'front3x3s2': 'st::front_s2_csp_kernel', 'pwres': 'st::pw_resident_kernel',
+              'headpred': 'st::head_pred_kernel'}   # (a VALU reduction, listed with the conv ops it replaces)
     fam = {}
     for name, v in per_variant.items():
         f = FAMILY.get(name, 'st::conv_igemm_kernel')

@@ -18,7 +18,7 @@
 //   * PAFPN nearest x2 upsample                          -> replicated epilogue store
 //   * branch average (rgb + disp)/2                      -> epilogue of disp_stage1's final conv
 //   * head cls-tower conv0 + reg-tower conv0             -> one conv, split store
-//   * head conv_reg + conv_obj                           -> one conv
+//   * head conv_cls + conv_reg + conv_obj of all three levels -> one reduction launch (head_pred.hip)
 //   * stage1.0 (3x3/s2) + stage1.1 main|short + blocks.0.conv1 of both branches -> one launch (front_fused.hip)
 #include <algorithm>
 #include <cmath>
@@ -58,6 +58,17 @@ int stem_focus_conv_launch(const float* in, int N, int H, int W, int used_planes
                            hipStream_t stream);
 int spp_pool_launch(const float* x, int x_ld, int x_off, int N, int H, int W, int C, float* out,
                     int out_ld, int out_off, hipStream_t stream);
+struct HeadPredLevel {
+  const float *cls, *reg, *wc, *wr, *bc, *br;
+  float* out;
+  int cls_ld, cls_off, reg_ld, reg_off, M, blk0;
+};
+struct HeadPredArgs {
+  HeadPredLevel lv[3];
+  int Kpad, nc, nblocks;
+};
+bool head_pred_applicable(int feat, int nc);
+int head_pred_launch(HeadPredArgs a, int feat, hipStream_t stream);
 
 namespace {
 
@@ -120,7 +131,7 @@ struct TRef {  // a channel slice of an NHWC buffer
 };
 
 struct Op {
-  enum Type { FOCUS, CONV, SPP, STEM } type;
+  enum Type { FOCUS, CONV, SPP, STEM, PRED } type;
   // FOCUS / STEM: src input index (0 = img/left, 1 = disp, 2 = right), dst tensor, dst batch offset
   // (STEM = fused Focus + stem ConvModule, stem_focus_conv.hip; uses pc and out1)
   int focus_input = 0;
@@ -139,6 +150,9 @@ struct Op {
   bool chain_next = false;  // the NEXT op is a 1x1 conv on this op's out1 (CSP main_conv -> bottleneck conv1):
                             // when both run on the streaming kernel (variant 41), or both on the LDS-resident
                             // kernel (variant 46), they are launched as one
+  // PRED (head_pred.hip): per level the two tower outputs, the packed conv_cls / conv_reg|obj and the head rows
+  TRef pred_cls[3], pred_reg[3], pred_out[3];
+  int pred_pcc[3] = {-1, -1, -1}, pred_pcr[3] = {-1, -1, -1};
   bool front_next2 = false; // this 3x3/s2 conv and the NEXT TWO ops (CSP main|short, blocks.0.conv1) are one launch
                             // of front_fused.hip (variant 45) whenever the three descriptors qualify
 };
@@ -482,6 +496,12 @@ int StDetector::build() {
     lvl_off[l] = head_floats;
     head_floats += (size_t)N * F[l].H * F[l].W * 8;
   }
+  bool fused_pred = head_pred_applicable(feat, nc);
+#ifdef ST_ABLATION
+  if (getenv("ST_NO_FUSED_PRED")) fused_pred = false;
+#endif
+  Op pred;
+  pred.type = Op::PRED; pred.phase = cur_phase; pred.variant = 47;
   for (int l = 0; l < 3; ++l) {
     const std::string ls = std::to_string(l);
     TRef t0 = new_tensor(N, F[l].H, F[l].W, 2 * feat);  // [cls_feat0 | reg_feat0]
@@ -494,10 +514,20 @@ int StDetector::build() {
     TRef ho;
     ho.buf = BUF_HEAD; ho.N = N; ho.H = F[l].H; ho.W = F[l].W; ho.ld = 8; ho.base = lvl_off[l];
     const int pcc = packed_conv2d({hp + "multi_level_conv_cls." + ls}, feat, {nc});
-    op_conv(pcc, clsf, 1, ho.slice(0, nc), -1, TRef(), TRef(), TRef(), 1.f, /*act=*/0);
     const int pcr = packed_conv2d({hp + "multi_level_conv_reg." + ls, hp + "multi_level_conv_obj." + ls},
                                   feat, {4, 1});
-    op_conv(pcr, regf, 1, ho.slice(nc, 5), -1, TRef(), TRef(), TRef(), 1.f, /*act=*/0);
+    if (fused_pred) {   // all prediction convs of all levels: one launch after the towers
+      pred.pred_cls[l] = clsf; pred.pred_reg[l] = regf; pred.pred_out[l] = ho;
+      pred.pred_pcc[l] = pcc; pred.pred_pcr[l] = pcr;
+      pred.macs += (double)N * F[l].H * F[l].W * feat * (nc + 5);
+    } else {
+      op_conv(pcc, clsf, 1, ho.slice(0, nc), -1, TRef(), TRef(), TRef(), 1.f, /*act=*/0);
+      op_conv(pcr, regf, 1, ho.slice(nc, 5), -1, TRef(), TRef(), TRef(), 1.f, /*act=*/0);
+    }
+  }
+  if (fused_pred) {
+    macs += pred.macs;
+    ops.push_back(pred);
   }
 
   // packed weight arena layout
@@ -682,6 +712,22 @@ int launch_op(StDetector* det, Op& o, int img0, const float* const inputs[3], fl
       return spp_pool_launch(x, o.in.ld, o.in.off, o.in.N, o.in.H, o.in.W, o.in.C, out, o.out1.ld, o.out1.off,
                              stream);
     }
+    case Op::PRED: {
+      HeadPredArgs a{};
+      for (int l = 0; l < 3; ++l) {
+        const PackedConv &pcc = det->convs[o.pred_pcc[l]], &pcr = det->convs[o.pred_pcr[l]];
+        HeadPredLevel& L = a.lv[l];
+        L.cls = resolve(det, o.pred_cls[l], ws, head, img0); L.cls_ld = o.pred_cls[l].ld; L.cls_off = o.pred_cls[l].off;
+        L.reg = resolve(det, o.pred_reg[l], ws, head, img0); L.reg_ld = o.pred_reg[l].ld; L.reg_off = o.pred_reg[l].off;
+        L.wc = det->wgt_dev + pcc.wgt_off; L.bc = det->wgt_dev + pcc.bias_off;
+        L.wr = det->wgt_dev + pcr.wgt_off; L.br = det->wgt_dev + pcr.bias_off;
+        L.out = resolve(det, o.pred_out[l], ws, head, img0);
+        L.M = o.pred_out[l].N * o.pred_out[l].H * o.pred_out[l].W;
+        a.Kpad = round_up(pcc.cin, 32);
+        a.nc = pcc.cout;
+      }
+      return head_pred_launch(a, det->convs[o.pred_pcc[0]].cin, stream);
+    }
     case Op::CONV: {
       const PackedConv& pc = det->convs[o.pc];
       (void)pc;
@@ -844,7 +890,7 @@ extern "C" int st_detector_op_times(StDetector* det, int cap, float* ms, int* ki
       t += dt;
     }
     if (ms) ms[i] = t;
-    if (kind) kind[i] = det->ops[i].type == Op::FOCUS ? 0 : det->ops[i].type == Op::SPP ? 2 : 1;  // STEM counts as conv
+    if (kind) kind[i] = det->ops[i].type == Op::FOCUS ? 0 : det->ops[i].type == Op::SPP ? 2 : 1;  // STEM, PRED count as conv
     if (variant) variant[i] = det->ops[i].variant;
     if (macs) macs[i] = det->ops[i].macs;
     if (phase) phase[i] = det->ops[i].phase;
@@ -944,10 +990,10 @@ extern "C" int st_detector_autotune(StDetector* det, void* workspace_dev, size_t
 // id 40 = the fused Focus+stem kernel (stem_focus_conv.hip), reported with the conv ops
 // id 41 = the streaming 1x1 kernel for narrow layers (pointwise_conv.hip)
 extern "C" const char* st_conv_variant_name(int id) {
-  return id == 46 ? "pwres" : id == 45 ? "front3x3s2" : id == 40 ? "stem6x6s2" : id == 41 ? "pw128" : id == 42 ? "dc4x32" : id == 43 ? "wino2x2" : id == 44 ? "wino2x2n" : conv_variant_name(id);
+  return id == 47 ? "headpred" : id == 46 ? "pwres" : id == 45 ? "front3x3s2" : id == 40 ? "stem6x6s2" : id == 41 ? "pw128" : id == 42 ? "dc4x32" : id == 43 ? "wino2x2" : id == 44 ? "wino2x2n" : conv_variant_name(id);
 }
 extern "C" const char* st_conv_variant_signature(int id) {
-  return id == 46 ? "pw_resident" : id == 45 ? "front_s2_csp" : id == 40 ? "stem_focus_conv" : id == 41 ? "pw_conv" : id == 42 ? "direct_conv3x3" : id == 43 ? "wino_conv3x3" : id == 44 ? "wino_conv3x3 narrow"
+  return id == 47 ? "head_pred" : id == 46 ? "pw_resident" : id == 45 ? "front_s2_csp" : id == 40 ? "stem_focus_conv" : id == 41 ? "pw_conv" : id == 42 ? "direct_conv3x3" : id == 43 ? "wino_conv3x3" : id == 44 ? "wino_conv3x3 narrow"
                                                               : conv_variant_signature(id);
 }
 
@@ -988,6 +1034,10 @@ extern "C" int st_detector_op_desc(const StDetector* det, int i, char* buf, int 
              det->convs[o.pc].srcs[0].conv_prefix.c_str());
   } else if (o.type == Op::SPP) {
     snprintf(buf, (size_t)cap, "spp_pool N=%d H=%d W=%d C=%d", o.in.N, o.in.H, o.in.W, o.in.C);
+  } else if (o.type == Op::PRED) {
+    snprintf(buf, (size_t)cap, "head conv_cls + conv_reg + conv_obj, 3 levels (%dx%d, %dx%d, %dx%d) N=%d Cin=%d  %s",
+             o.pred_out[0].H, o.pred_out[0].W, o.pred_out[1].H, o.pred_out[1].W, o.pred_out[2].H, o.pred_out[2].W,
+             o.pred_out[0].N, det->convs[o.pred_pcc[0]].cin, det->convs[o.pred_pcc[0]].srcs[0].conv_prefix.c_str());
   } else {
     const PackedConv& pc = det->convs[o.pc];
     snprintf(buf, (size_t)cap, "conv k%d s%d N=%dx%d Hi=%d Wi=%d Cin=%d Cout=%d%s%s%s  %s", pc.k, o.stride, o.in.N,
