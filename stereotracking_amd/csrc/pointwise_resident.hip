@@ -151,8 +151,11 @@ __global__ __launch_bounds__(PR_THREADS, 1) void pw_resident_kernel(const PwrArg
     f32x4 v[CB];
 #pragma unroll
     for (int cb = 0; cb < CB; ++cb) {
+      v[cb] = acc[cb];
+      if (p.act) {   // uniform branch, not a per-value select
 #pragma unroll
-      for (int e = 0; e < 4; ++e) v[cb][e] = p.act ? pr_silu(acc[cb][e]) : acc[cb][e];
+        for (int e = 0; e < 4; ++e) v[cb][e] = pr_silu(v[cb][e]);
+      }
     }
     if (CH > 0) {   // chained conv on channels [0, 16 CH) (before any residual: CSP main_conv has none)
       f32x4 ac[CH > 0 ? CH : 1];
@@ -171,9 +174,11 @@ __global__ __launch_bounds__(PR_THREADS, 1) void pw_resident_kernel(const PwrArg
       }
 #pragma unroll
       for (int c3 = 0; c3 < CH; ++c3) {
-        f32x4 t;
+        f32x4 t = ac[c3];
+        if (p.act2) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) t[e] = p.act2 ? pr_silu(ac[c3][e]) : ac[c3][e];
+          for (int e = 0; e < 4; ++e) t[e] = pr_silu(t[e]);
+        }
         const unsigned o = st_ok ? (unsigned)((m * p.out3_ld + p.out3_off + c3 * 16 + 4 * kq) * 4) : 0x80000000u;
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, t), o3rsrc, o, 0, 0);
       }

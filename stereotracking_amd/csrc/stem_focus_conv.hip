@@ -155,9 +155,10 @@ __global__ __launch_bounds__(256, NB == 1 ? 2 : 1) void stem_focus_conv_kernel(c
     const int co = nb * 32 + 8 * g + 4 * half;
     f32x4 v;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const float x = prev[i][nb][4 * g + e] + bv[nb][g][e];
-      v[e] = p.act ? stem_silu(x) : x;
+    for (int e = 0; e < 4; ++e) v[e] = prev[i][nb][4 * g + e];   // bias included: the accumulator started from it
+    if (p.act) {   // uniform branch (a per-value select would cost a vector instruction per output)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = stem_silu(v[e]);
     }
 #if defined(__HIP_DEVICE_COMPILE__)
     if (VEC) {   // out_ld, out_off, Cout multiples of 4: one dwordx4 per group
@@ -201,7 +202,7 @@ __global__ __launch_bounds__(256, NB == 1 ? 2 : 1) void stem_focus_conv_kernel(c
 #pragma unroll
       for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][nb][r] = 0.f;
+        for (int r = 0; r < 16; ++r) acc[i][nb][r] = bv[nb][r >> 2][r & 3];   // start from the bias: no add per output
     float a[2][STEM_WB], w[2][NB];
 #pragma unroll
     for (int i = 0; i < STEM_WB; ++i) a[0][i] = win[aoff[i] + koff(0)];
