@@ -34,10 +34,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int FF_CIN = 32, FF_C2 = 64, FF_MID = 32;
-#ifndef FF_WAVES_PER_CU
-#define FF_WAVES_PER_CU 8
-#endif
-constexpr int FF_WAVES = FF_WAVES_PER_CU, FF_THREADS = 64 * FF_WAVES;
+constexpr int FF_WAVES = 8, FF_THREADS = 64 * FF_WAVES;   // measured: 8 waves 422 us, 12 waves 430 us, 16 waves 452 us
 constexpr int FF_W3_FLOATS = 9 * FF_C2 * FF_CIN;      // [tap][cout][32 ch], 16-byte quads of a row XOR-swizzled
 constexpr int FF_MS_FLOATS = 2 * FF_MID * FF_C2;      // [c2 4][c 4][lane][4]
 constexpr int FF_C1_FLOATS = FF_MID * FF_MID;         // [c3 2][c2 2][lane][4]
@@ -168,9 +165,6 @@ __global__ __launch_bounds__(FF_THREADS, 1) void front_s2_csp_kernel(const Front
   const __amdgpu_buffer_rsrc_t srsrc = __builtin_amdgcn_make_buffer_rsrc(p.out_short, 0, (int)p.short_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t trsrc = __builtin_amdgcn_make_buffer_rsrc(p.out_tmp, 0, (int)p.tmp_bytes, 0x00020000);
 
-#ifdef ST_ABLATION
-  if ((p.abl & 64) && ((0x96 >> wave) & 1)) __builtin_amdgcn_s_sleep(90);   // waves 1, 2, 4, 7: half a tile late
-#endif
   for (; tile < p.ntiles; tile += stride) {
     // where this tile's results go (before `locate` moves on to the next tile)
     const int tx = tile % p.tiles_x, orow = tile / p.tiles_x;
