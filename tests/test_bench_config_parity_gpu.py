@@ -1,10 +1,10 @@
 """GPU parity of BASELINE.json configs[1] EXACTLY as bench.py runs it: 8 synthetic 1280x720 stereo pairs per
 step, D=192, full two-branch YOLOX-s, 2 aggregation convs, 3 in-flight contexts, AUTOTUNED tile variants
-(streaming 1x1 + chain, direct 3x3, LDS-DMA tiles), bench.py's own weights and seeds.
+(Winograd, fused front, LDS-resident 1x1 + chain, LDS-DMA tiles), bench.py's own weights and seeds.
 
   (a) tuned vs untuned: all 8 pairs of the tuned in-flight run against an autotune=False serial run — every
       float within 1e-3 * max(1, |ref|), kept prior indices equal;
-  (b) END-TO-END against the oracle for pairs 0 and 1: the oracle consumes ITS OWN disparity (no GPU
+  (b) END-TO-END against the oracle for all 8 pairs: the oracle consumes ITS OWN disparity (no GPU
       intermediate enters the reference side) — disparity / head / boxes / scores / depth within
       1e-3 * max(1, |ref|) (north_star's tolerance), kept prior indices equal (reference call chain
       mmtrack/models/mot/ocsort_disparity.py:73-83 -> detectors/yolo_detector_disparity_v1.py:92-125);
@@ -34,6 +34,7 @@ pytestmark = pytest.mark.gpu
 
 H, W, D, AGG, B = 720, 1280, 192, 2, 8
 FLOAT_KEYS = ('boxes', 'scores', 'depth', 'scales', 'scaled_boxes')
+E2E_PAIRS = tuple(range(8))   # every pair of the batch is compared end to end against the oracle pipeline (~2 CPU s each)
 
 
 def test_benched_configuration_parity(cuda):
@@ -115,10 +116,10 @@ def test_benched_configuration_parity(cuda):
     rec['tuned_vs_untuned_max_rel_err'] = a
     rec['tuned_vs_untuned_kept'] = tu
 
-    # (b) end to end against the oracle, pairs 0 and 1
+    # (b) end to end against the oracle, every pair
     ora = make_oracle(sd)
     rec['e2e'] = {}
-    for n in (0, 1):
+    for n in E2E_PAIRS:
         r = oracle_pipeline(ora, sd, batch['img'][n:n + 1], batch['right'][n:n + 1], pipe.det.levels, (H, W), D,
                             pipe.temperature, AGG, pipe.score_thr, pipe.iou_thr, M)
         c = compare_to_oracle(out, n, r, pipe.det.levels)
@@ -141,7 +142,7 @@ def test_benched_configuration_parity(cuda):
     assert tu['images_with_equal_kept_sets'] >= B - 2, tu
     assert tu['boxes_with_different_pixel_window'] <= max(2, tu['boxes_compared'] // 100), tu
     assert tu['max_score_gap_at_swaps'] <= 5e-5, tu          # order swaps only between (near-)equal scores
-    for n in (0, 1):
+    for n in E2E_PAIRS:
         c = rec['e2e'][f'pair{n}']
         assert c['disp_max_rel_err'] <= 1e-3, f"pair {n}: disparity {c['disp_max_rel_err']:.3e} (rel) vs the oracle's own"
         assert c['head_max_rel_err'] <= 1e-3, f"pair {n}: head {c['head_max_rel_err']:.3e}"
