@@ -241,6 +241,12 @@ class OCSORT_Disparity(nn.Module):
             ent[1] = ver
         return ent[0]
 
+    def _side_stream(self, dev):
+        st = self._staging.get(('side_stream', dev))
+        if st is None:
+            st = self._staging[('side_stream', dev)] = torch.cuda.Stream(device=dev)
+        return st
+
     def _pinned(self, name, shape, dtype=torch.float32):
         """View of a cached page-locked staging buffer.  Allocating pinned memory per chunk (hipHostMalloc) stalls the
         host until the device is idle, which serialises the in-flight contexts; these buffers are allocated once and
@@ -331,11 +337,16 @@ class OCSORT_Disparity(nn.Module):
             a, b = padded(img, s, e), padded(second, s, e)
             holder = {}
 
+            slot = (ci // len(runner)) & 1   # staging buffers alternate: the context is resubmitted before this chunk is consumed
+
             def post(out, ctx):   # under the context's stream: pack + start the ONE device->host copy of this chunk
                 rec = runner.pipes[ctx].pack_detections(out, scaled='both', n_real=e - s)
-                host = self._pinned(('records', id(runner), ctx), rec.shape, rec.dtype)   # free again: the chunk that
-                host.copy_(rec, non_blocking=True)                                     # used it was consumed
-                holder.update(ctx=ctx, disp=out['disp_postp'], host=host)
+                host = self._pinned(('records', id(runner), ctx, slot), rec.shape, rec.dtype)
+                host.copy_(rec, non_blocking=True)
+                # a private copy of the disparity channel (30 MB at 8 x 736 x 1280): the depth of the TRACK boxes is read
+                # from it after the association, when the context already runs its next chunk
+                disp = out['disp_postp'][:, :1].clone(memory_format=torch.contiguous_format)
+                holder.update(ctx=ctx, disp=disp, host=host, slot=slot)
                 return out
             _, ev = runner.submit(a, right=b if stereo else None, disp_postp=None if stereo else b, post=post)
             self.timings['submit_s'] += time.perf_counter() - ts
@@ -365,6 +376,9 @@ class OCSORT_Disparity(nn.Module):
             self.timings['wait_s'] += time.perf_counter() - tw
             if ci == len(chunks) - 1:
                 t_tail0 = time.perf_counter()
+            nxt = ci + len(runner)
+            if nxt < len(chunks):      # refill this context FIRST: the device keeps `inflight` chunks while the host
+                jobs[nxt] = submit(nxt)   # associates this one (its results live in buffers of their own)
             rec = job['host']
             s, e = job['s'], job['e']
             tracks_of = []
@@ -387,17 +401,18 @@ class OCSORT_Disparity(nn.Module):
                                                          labels=labels, prior_idx=rows[:, 12].long())   # (:107-108)
                 tracks_of.append(tracks)
             self.timings['tracker_s'] += time.perf_counter() - t0
-            # reference :99-104: depth (and gt depth) of the UNSCALED track boxes - ONE batched launch per chunk,
-            # enqueued on the chunk's own stream (its disp_postp buffer is still intact there)
+            # reference :99-104: depth (and gt depth) of the UNSCALED track boxes - ONE batched launch per chunk, on a
+            # side stream (the chunk's forward pass has completed: `ev` above), reading the chunk's own disparity copy
             td = time.perf_counter()
             mt = max([len(t) for t in tracks_of] + [1])
-            tb = self._pinned(('track_boxes', id(runner), job['ctx']), (B, mt, 4)).zero_()
-            tc = self._pinned(('track_counts', id(runner), job['ctx']), (B,), torch.int32).zero_()
+            tb = self._pinned(('track_boxes', id(runner), job['ctx'], job['slot']), (B, mt, 4)).zero_()
+            tc = self._pinned(('track_counts', id(runner), job['ctx'], job['slot']), (B,), torch.int32).zero_()
             for i, t in enumerate(tracks_of):
                 tb[i, :len(t)] = t.bboxes
                 tc[i] = len(t)
-            stream = runner.streams[job['ctx']]
+            stream = self._side_stream(dev)
             with torch.cuda.stream(stream):
+                job['disp'].record_stream(stream)
                 tbd, tcd = tb.to(dev, non_blocking=True), tc.to(dev, non_blocking=True)
                 d = self._box_depth(job['disp'], tbd, tcd, self.baseline, self.focal_length)[0]
                 cols = [d]
@@ -409,9 +424,6 @@ class OCSORT_Disparity(nn.Module):
                 ev2.record(stream)
             pending.append((s, e, tracks_of, dh, ev2, (tbd, tcd)))
             self.timings['depth_s'] += time.perf_counter() - td
-            nxt = ci + len(runner)
-            if nxt < len(chunks):                          # reuse this context (stream order: after the depth launch)
-                jobs[nxt] = submit(nxt)
             while pending and pending[0][4].query():       # earlier chunks whose track depth has landed: complete
                 finalize(pending.pop(0))                   # them now, while the device works on the next chunks
         for entry in pending:
