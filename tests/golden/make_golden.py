@@ -15,6 +15,13 @@ ships no fixtures of its own, so these vectors pin the oracle, not the reference
                        kalman_filter.py:38-189) with the SHIPPED tracker config: ids, boxes, scores, depth, scales
   lapjv_ties.npz       <= 7x7 assignment problems with NON-UNIQUE optima: all optimal assignments enumerated by
                        brute force, the one oracle/lapjv.py (restatement of lap.lapjv) picks is pinned
+  config2_sequence.npz BASELINE configs[2] END TO END through the oracle, at its stated size: 24 frames of the synthetic
+                       1280x720 sequence (D=192, full YOLOX-s two-branch, 2 aggregation convs) -> oracle stereo module
+                       -> oracle detector on the oracle's OWN disparity -> C decode+NMS -> numpy extract_depth -> ORACLE
+                       tracker, once with the SHIPPED thresholds and once with stress thresholds (hundreds of
+                       tracks).  Per frame: kept prior indices (in order), scores, boxes, depth, scales; per
+                       tracker config: ids / boxes per frame.  The GPU test compares model.test_step against it, so
+                       oracle/tracker.py never has to run on the GPU box.
 Nothing here is produced by product code (stereotracking_amd/ supplies only the seeded synthetic INPUTS).
 Run:  python tests/golden/make_golden.py [name ...]   (deterministic; CI checks the files are reproduced)."""
 import os
@@ -205,9 +212,72 @@ def lapjv_ties():
                 x=np.asarray(chosen), num_optimal=np.asarray(n_opt, np.int32))
 
 
+STRESS_TRACKER = dict(SHIPPED_TRACKER, obj_score_thr=0.02, init_track_thr=0.05)
+"""Random-weight heads emit low scores: gates low enough that hundreds of detections per frame become tracks."""
+
+CONFIG2 = dict(T=24, H=720, W=1280, D=192, AGG=2, objects=6, seq_seed=3, weight_seed=0, prior_prob=0.01, logit_std=0.6,
+               temperature=32.0, score_thr=0.01, iou_thr=0.5, max_det=1000)
+
+
+def config2_frames(cfg=CONFIG2):
+    from stereotracking_amd.sequence import synthetic_sequence
+    return list(synthetic_sequence(cfg['T'], cfg['objects'], cfg['H'], cfg['W'], cfg['D'], seed=cfg['seq_seed']))
+
+
+def config2_state_dict(cfg=CONFIG2):
+    """Seeded weights of the configs[2] fixture in reference state_dict naming (detector.* keys without the prefix
+    + stereo.agg.*): the table comes from the ORACLE model, not from the product."""
+    ora = OracleDetector(0.33, 0.5, 1).eval()
+    table = [(k, tuple(v.shape)) for k, v in ora.state_dict().items() if not k.endswith('num_batches_tracked')]
+    Dl = cfg['D'] // 4
+    for l in range(cfg['AGG']):
+        table += [(f'stereo.agg.{l}.weight', (Dl, Dl, 3, 3)), (f'stereo.agg.{l}.bias', (Dl,))]
+    return synthetic_state_dict(table, seed=cfg['weight_seed'], prior_prob=cfg['prior_prob'],
+                                logit_std=cfg['logit_std'])
+
+
+def config2_sequence():
+    import time
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    from parity_utils import make_oracle, oracle_pipeline
+    from stereotracking_amd.synthetic import pad_to_divisor
+    cfg = CONFIG2
+    torch.set_num_threads(min(os.cpu_count() or 1, 8))
+    sd = config2_state_dict(cfg)
+    ora = make_oracle(sd)
+    H, W = cfg['H'], cfg['W']
+    levels, _ = levels_for((H + 31) // 32 * 32, W, 1)
+    out = {k: np.asarray(v) for k, v in cfg.items()}
+    dets = []
+    t0 = time.time()
+    for t, f in enumerate(config2_frames(cfg)):
+        img = torch.from_numpy(pad_to_divisor(f['left'].astype(np.float32), 32, 114.0))[None]
+        right = torch.from_numpy(pad_to_divisor(f['right'].astype(np.float32), 32, 114.0))[None]
+        r = oracle_pipeline(ora, sd, img, right, levels, (H, W), cfg['D'], cfg['temperature'], cfg['AGG'],
+                            cfg['score_thr'], cfg['iou_thr'], cfg['max_det'])
+        k = len(r['prior'])
+        assert r['count'] == k <= cfg['max_det']
+        out[f'prior{t}'] = r['prior'].astype(np.int32)
+        out[f'boxes{t}'] = r['boxes'].astype(np.float32)
+        out[f'scores{t}'] = r['scores'].astype(np.float32)
+        out[f'depth{t}'] = r['depth'].astype(np.float32)
+        out[f'scales{t}'] = r['scales'].astype(np.float32)
+        out[f'disp_sum{t}'] = np.float64(r['disp'].double().sum().item())
+        sb = r['scaled_boxes'].numpy().astype(np.float32)
+        for i in range(k):   # the tracker consumes the depth-SCALED boxes (ocsort_disparity.py:82-86)
+            dets.append([t, *sb[i], r['scores'][i], r['depth'][i], r['scales'][i]])
+        print(f'  frame {t}: kept {k}  ({time.time() - t0:.0f} s)', flush=True)
+    dets = np.asarray(dets, np.float32)
+    for name, tc in (('shipped', SHIPPED_TRACKER), ('stress', STRESS_TRACKER)):
+        out['tracks_' + name] = run_oracle_tracker(dets, cfg['T'], **tc)
+        print(f'  tracker[{name}]: {len(out["tracks_" + name])} track rows, '
+              f'{len(set(out["tracks_" + name][:, 1].tolist()))} ids')
+    return out
+
+
 if __name__ == '__main__':
     c_oracle.build()
-    for name, fn in (('detector_tiny', detector_tiny), ('decode_nms', decode_nms), ('box_depth', box_depth),
+    for name, fn in (('config2_sequence', config2_sequence), ('detector_tiny', detector_tiny), ('decode_nms', decode_nms), ('box_depth', box_depth),
                      ('costvolume', costvolume), ('tracker_sequence', tracker_sequence), ('lapjv_ties', lapjv_ties)):
         if len(sys.argv) > 1 and name not in sys.argv[1:]:
             continue

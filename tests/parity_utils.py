@@ -174,7 +174,10 @@ def explain_kept_difference(rows, levels, kept_a, kept_b, score_thr, iou_thr, ep
     pos = {int(p): k for k, p in enumerate(cand)}
     diff = sorted(set(int(v) for v in kept_a) ^ set(int(v) for v in kept_b))
     unexplained = [p for p in diff if p not in pos or not affected[pos[p]]]
+    # `affected / candidates` is the vacuity check of this proof: a closure that swallows most candidates explains
+    # anything, so callers assert affected_frac <= 0.10 next to `unexplained == []`.
     return dict(candidates=int(len(cand)), marginal_seeds=int(seed.sum()), affected=int(affected.sum()),
+                affected_frac=float(affected.sum()) / max(1, len(cand)),
                 min_score_margin=float(np.abs(scores - score_thr).min()),
                 min_iou_margin=float(np.abs(iou[iou > 0] - iou_thr).min()) if (iou > 0).any() else None,
                 differing_priors=diff, unexplained=unexplained)

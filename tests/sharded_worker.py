@@ -1,6 +1,6 @@
 """Worker of tests/test_multirank_gpu.py: one rank of a world-2 'gloo' rehearsal of BASELINE configs[3] (frames of one
 sequence sharded over the ranks, ONE all-gather of the frame records, every rank tracks all frames).  Ranks share
-cuda:0 here (the GPU box has one card); the collective goes through host memory.  Prints one JSON line per rank."""
+cuda:0 here (the GPU box has one card); the collective goes through host memory.  Each rank writes its result to <out_dir>/rank{r}_of{world}.json (argv[2])."""
 import json
 import os
 import sys
@@ -43,9 +43,16 @@ def main():
         orig = sdist.gather_detections
         sdist.gather_detections = lambda local, counts=None: orig(local.cpu(), counts)
     res = run_sharded_sequence(runner, frames, trk, _Model(), dev)
-    print(json.dumps(dict(rank=rank, world=world, ids=[r.instances_id.tolist() for r in res],
-                          nboxes=[len(r) for r in res],
-                          box_sum=[float(r.bboxes.double().sum()) for r in res])), flush=True)
+    rec = dict(rank=rank, world=world, ids=[r.instances_id.tolist() for r in res], nboxes=[len(r) for r in res],
+               box_sum=[float(r.bboxes.double().sum()) for r in res])
+    # One FILE per rank: both ranks share the launcher's stdout pipe, and a write above PIPE_BUF (4096 B) is not
+    # atomic, so two long JSON lines can interleave.  Only a short digest goes to stdout.
+    out_dir = sys.argv[2]
+    tmp = os.path.join(out_dir, f'rank{rank}_of{world}.json.tmp')
+    with open(tmp, 'w') as f:
+        json.dump(rec, f)
+    os.replace(tmp, tmp[:-4])
+    print(f'sharded_worker rank {rank}/{world}: {len(res)} frames, {sum(rec["nboxes"])} boxes', flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -21,8 +21,7 @@ def build_pair(widen, deepen, N, H, W, seed=0):
     return det, ora
 
 
-def rel_err(got, ref):
-    return ((got - ref).abs() / ref.abs().clamp(min=1.0)).max().item()
+from parity_utils import explain_kept_difference, rel_err  # noqa: E402
 
 
 @pytest.mark.parametrize('widen,N,H,W', [(0.375, 2, 96, 160), (0.5, 1, 192, 320), (0.5, 2, 64, 96),
@@ -94,9 +93,9 @@ def test_full_size_pipeline_parity_and_batch_invariance(cuda):
         # stage-wise, like every other parity test here: the detector oracle consumes the GPU's own disparity
         # (soft-argmin at temperature 32 amplifies fp32 rounding of the features; the head would inherit it)
         rows = head_to_rows(*ora(dict(img=batch['img'][:1], disp_postp=out['disp_postp'][:1].cpu())))
-    err_d = (out['disp_postp'][:1].cpu() - disp).abs().max().item()
-    print(f'full-size disparity max err {err_d:.3e} px (bound {1e-3 * D:.3f})')
-    assert err_d <= 1e-3 * D
+    err_d = rel_err(out['disp_postp'][:1].cpu(), disp)      # per element: |a - b| <= 1e-3 * max(1, |b|)
+    print(f'full-size disparity max rel err {err_d:.3e}')
+    assert err_d <= 1e-3
     assert (out['disp_postp'][:, :, H:] == 0).all()
     for got, ref in zip(pipe.det.head_levels(out['head']), rows):
         assert rel_err(got[:1, :, :6].cpu(), ref) <= 1e-3
@@ -116,11 +115,15 @@ def test_full_size_pipeline_parity_and_batch_invariance(cuda):
     for n in range(2):
         o = solo.run(img[n:n + 1], right[n:n + 1])
         torch.cuda.synchronize()
-        assert (o['disp_postp'][0] - out['disp_postp'][n]).abs().max().item() <= 1e-3 * D
-        k = int(out['counts'][n])
-        if int(o['counts'][0]) == k:   # a score within 1e-6 of the threshold may flip; otherwise identical picks
-            same = (o['prior_idx'][0, :min(k, 300)] == out['prior_idx'][n, :min(k, 300)]).float().mean().item()
-            assert same > 0.98
+        assert rel_err(o['disp_postp'][0].cpu(), out['disp_postp'][n].cpu()) <= 1e-3
+        # the two launch plans (N=1, N=2) may pick different tiles: kept SETS must agree up to decisions whose
+        # margin is inside the float noise of the path (explained by the reference run's own margins)
+        ka = o['prior_idx'][0, :int(o['counts'][0])].cpu().numpy()
+        kb = out['prior_idx'][n, :int(out['counts'][n])].cpu().numpy()
+        if set(ka.tolist()) != set(kb.tolist()):
+            rows_n = [r[n:n + 1, :, :6].cpu() for r in pipe.det.head_levels(out['head'])]
+            ex = explain_kept_difference(rows_n, pipe.det.levels, ka, kb, pipe.score_thr, pipe.iou_thr)
+            assert ex['unexplained'] == [] and ex['affected_frac'] <= 0.10, ex
 
 
 def test_config0_tiny_pair_against_cpu_oracle(cuda):
@@ -146,7 +149,7 @@ def test_config0_tiny_pair_against_cpu_oracle(cuda):
         disp = torch.from_numpy(ostereo.disparity(fl, fr, fl.shape[-1], D // 4, pipe.temperature, sd, 2,
                                                   valid_hw=(H, W))[2])
         rows = head_to_rows(*ora(dict(img=batch['img'], disp_postp=out['disp_postp'].cpu())))
-    assert (out['disp_postp'].cpu() - disp).abs().max().item() <= 1e-3 * D
+    assert rel_err(out['disp_postp'].cpu(), disp) <= 1e-3
     for got, ref in zip(pipe.det.head_levels(out['head']), rows):
         assert rel_err(got[..., :6].cpu(), ref) <= 1e-3
     ref = c_oracle.decode_nms(out['head'].cpu().numpy(), 1, pipe.det.levels, pipe.score_thr, pipe.iou_thr,
@@ -161,4 +164,4 @@ def test_config0_tiny_pair_against_cpu_oracle(cuda):
     d_got = out['depth'][0, :k].cpu().double().numpy()
     assert np.array_equal(np.isnan(d_got), np.isnan(d_ref)) and np.array_equal(d_got == -1, d_ref == -1)
     ok = ~np.isnan(d_ref) & (d_ref != -1)
-    assert np.abs(d_got[ok] - d_ref[ok]).max() <= 1e-3 * max(1.0, np.abs(d_ref[ok]).max())
+    assert rel_err(d_got[ok], d_ref[ok]) <= 1e-3

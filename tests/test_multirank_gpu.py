@@ -26,17 +26,37 @@ def _launch(nproc, script_args, env_extra=None, timeout=600):
            '--master-addr', '127.0.0.1', '--master-port', str(_free_port())] + script_args
     p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
-    return [json.loads(l) for l in p.stdout.splitlines() if l.startswith('{')]
+    return p.stdout
 
 
-def test_sharded_sequence_world2_equals_single_process(cuda):
+def _json_lines(stdout):
+    """Complete JSON objects printed on lines of their own (anything else on stdout is ignored)."""
+    out = []
+    for line in stdout.splitlines():
+        if line.startswith('{') and line.rstrip().endswith('}'):
+            try:
+                out.append(json.loads(line))
+            except json.JSONDecodeError:
+                pass
+    return out
+
+
+def _read_rank(out_dir, rank, world):
+    with open(os.path.join(out_dir, f'rank{rank}_of{world}.json')) as f:
+        return json.load(f)
+
+
+def test_sharded_sequence_world2_equals_single_process(cuda, tmp_path):
     T = 13   # ragged: 7 + 6 frames, i.e. 2 batches of 4 per rank with padding on both
     worker = os.path.join(ROOT, 'tests', 'sharded_worker.py')
-    single = subprocess.run([sys.executable, worker, str(T)], cwd=ROOT, capture_output=True, text=True, timeout=600)
+    out_dir = str(tmp_path)
+    single = subprocess.run([sys.executable, worker, str(T), out_dir], cwd=ROOT, capture_output=True, text=True,
+                            timeout=600)
     assert single.returncode == 0, single.stderr[-3000:]
-    ref = [json.loads(l) for l in single.stdout.splitlines() if l.startswith('{')][0]
+    ref = _read_rank(out_dir, 0, 1)
     assert ref['world'] == 1 and sum(ref['nboxes']) > T
-    outs = _launch(2, [worker, str(T)])
+    _launch(2, [worker, str(T), out_dir])
+    outs = [_read_rank(out_dir, r, 2) for r in (0, 1)]   # one file per rank: ranks never share a pipe for results
     assert sorted(o['rank'] for o in outs) == [0, 1]
     for o in outs:   # every rank tracked ALL frames from the gathered records: identical to the unsharded run
         assert o['ids'] == ref['ids'] and o['nboxes'] == ref['nboxes'] and o['box_sum'] == ref['box_sum']
@@ -46,8 +66,9 @@ def test_bench_multirank_path_world2(cuda):
     """bench.py --gpus 2 exactly as the driver launches it (torch.distributed.run, one rank per process), with the
     collective rehearsed over gloo: the barrier / max-over-ranks timing, the per-step all-gather of the frame records
     from the context streams and the record-vs-local-count check all run; rank 0 prints ONE JSON line."""
-    outs = _launch(2, [os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '4', '--warmup', '2', '--no-cpu-baseline',
-                       '--no-test-step', '--sustain-seconds', '0'], dict(ST_BENCH_BACKEND='gloo'))
+    outs = _json_lines(_launch(2, [os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '4', '--warmup', '2',
+                                   '--no-cpu-baseline', '--no-test-step', '--sustain-seconds', '0'],
+                               dict(ST_BENCH_BACKEND='gloo')))
     assert len(outs) == 1
     line = outs[0]
     assert line['n_gpus'] == 2 and line['scaling'] == 'weak' and line['value'] > 0
