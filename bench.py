@@ -448,7 +448,7 @@ def main():
                                max_disp=args.max_disp, max_det=args.max_det, agg_layers=args.agg_layers)
     pipe = runner.pipes[0]
     sd = synthetic_state_dict(runner.param_table(), seed=0)
-    runner.load_state_dict(sd, tuning_cache=os.environ.get('ST_TUNE_CACHE'))
+    runner.load_state_dict(sd)   # plan from pipeline.default_tuning_cache() (committed), measured when absent
     # every rank gets its own 8 pairs (weak scaling: frames shard across ranks)
     batch_cpu = synthetic_batch([rank * B + i for i in range(B)], 720, 1280, args.max_disp)
     img, right = batch_cpu['img'].to(dev), batch_cpu['right'].to(dev)

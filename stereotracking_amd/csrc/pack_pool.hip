@@ -1,4 +1,5 @@
 // Small bandwidth-bound helpers of the detector: Focus space-to-depth packing and SPP pooling.
+#include <cstdint>
 #include <algorithm>
 #include <cstdlib>
 
@@ -251,6 +252,58 @@ __global__ __launch_bounds__(256) void pack_raw_inputs_kernel(const unsigned cha
   }
 }
 
+
+// 4 pixels per thread (w, W multiples of 4, 4-/8-/16-byte aligned rows): one uchar4 / ushort4 load, float4 stores.
+// Per image of 3 x 720 x 1280: 2.8 MB read, 11.3 MB written - an HBM stream (bytes, not flops).
+__global__ __launch_bounds__(256) void pack_raw_inputs_vec4_kernel(const unsigned char* __restrict__ img,
+                                                                   const unsigned short* __restrict__ disp, int N,
+                                                                   int h, int w, int H, int W, float img_pad,
+                                                                   float* __restrict__ img_out,
+                                                                   float* __restrict__ disp_out,
+                                                                   float* __restrict__ mask_out) {
+  const int W4 = W >> 2;
+  const long long total = (long long)N * H * W4;
+  const size_t plane = (size_t)H * W;
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (long long)gridDim.x * blockDim.x) {
+    const int X = (int)(idx % W4) << 2;
+    const long long t = idx / W4;
+    const int Y = (int)(t % H);
+    const int n = (int)(t / H);
+    const bool inside = Y < h && X < w;   // w % 4 == 0: a group of 4 is inside or outside as a whole
+    if (img_out) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        float4 v = make_float4(img_pad, img_pad, img_pad, img_pad);
+        if (inside) {
+          const uchar4 q = *reinterpret_cast<const uchar4*>(img + (((size_t)n * 3 + c) * h + Y) * w + X);
+          v = make_float4((float)q.x, (float)q.y, (float)q.z, (float)q.w);
+        }
+        *reinterpret_cast<float4*>(img_out + ((size_t)n * 3 + c) * plane + (size_t)Y * W + X) = v;
+      }
+    }
+    if (disp_out) {
+      float4 d = make_float4(0.f, 0.f, 0.f, 0.f), m = d;
+      if (inside) {
+        const ushort4 q = *reinterpret_cast<const ushort4*>(disp + ((size_t)n * h + Y) * w + X);
+        const unsigned code[4] = {q.x, q.y, q.z, q.w};
+        float dv[4], mv[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          mv[k] = code[k] < 65535u ? 1.f : 0.f;
+          dv[k] = (code[k] == 65535u ? 0.f : (float)code[k]) / 16.0f;
+        }
+        d = make_float4(dv[0], dv[1], dv[2], dv[3]);
+        m = make_float4(mv[0], mv[1], mv[2], mv[3]);
+      }
+#pragma unroll
+      for (int c = 0; c < 3; ++c)
+        *reinterpret_cast<float4*>(disp_out + ((size_t)n * 3 + c) * plane + (size_t)Y * W + X) = d;
+      if (mask_out) *reinterpret_cast<float4*>(mask_out + (size_t)n * plane + (size_t)Y * W + X) = m;
+    }
+  }
+}
+
 }  // namespace st
 
 extern "C" int st_pack_raw_inputs(const unsigned char* img_u8_dev, const unsigned short* disp_u16_dev, int N, int h,
@@ -261,6 +314,17 @@ extern "C" int st_pack_raw_inputs(const unsigned char* img_u8_dev, const unsigne
   ST_REQUIRE((img_u8_dev && img_out_dev) || (disp_u16_dev && disp_postp_out_dev), "st_pack_raw_inputs: nothing to do");
   ST_REQUIRE(!img_out_dev || img_u8_dev, "st_pack_raw_inputs: img output without img input");
   ST_REQUIRE(!disp_postp_out_dev || disp_u16_dev, "st_pack_raw_inputs: disparity output without disparity input");
+  const auto al = [](const void* p, size_t a) { return p == nullptr || (reinterpret_cast<uintptr_t>(p) % a) == 0; };
+  if (w % 4 == 0 && W % 4 == 0 && al(img_u8_dev, 4) && al(disp_u16_dev, 8) && al(img_out_dev, 16) &&
+      al(disp_postp_out_dev, 16) && al(disp_mask_out_dev, 16)) {
+    const long long total4 = (long long)N * H * (W / 4);
+    const int blocks4 = (int)std::min<long long>((total4 + 255) / 256, 256 * 16);
+    hipLaunchKernelGGL(pack_raw_inputs_vec4_kernel, dim3(blocks4), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       img_u8_dev, disp_u16_dev, N, h, w, H, W, img_pad, img_out_dev, disp_postp_out_dev,
+                       disp_mask_out_dev);
+    ST_CHECK_HIP(hipGetLastError());
+    return ST_OK;
+  }
   const long long total = (long long)N * H * W;
   const int blocks = (int)std::min<long long>((total + 255) / 256, 256 * 16);
   hipLaunchKernelGGL(pack_raw_inputs_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), img_u8_dev,

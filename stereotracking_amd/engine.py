@@ -37,6 +37,7 @@ class HipDetector:
         self.lib = _lib.load()
         self.batch, self.height, self.width = int(batch), int(height), int(width)
         self.stereo = bool(stereo)
+        self.widen_factor, self.deepen_factor = float(widen_factor), float(deepen_factor)
         self.disp_replicated = self.stereo if disp_replicated is None else bool(disp_replicated)
         cfg = StDetectorConfig(C.sizeof(StDetectorConfig), float(widen_factor), float(deepen_factor),
                                int(num_classes), self.batch, self.height, self.width, float(bn_eps),

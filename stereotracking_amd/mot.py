@@ -89,11 +89,18 @@ class TrackDataPreprocessor_Disparity_V1(nn.Module):
                     # the padded batch, and the pad value written to the pad strips only
                     h, w = pad_shapes[0]
                     batch = torch.empty((len(imgs), T, Cc, H, W), dtype=torch.float32, device=dev)
-                    batch[..., :h, :w].copy_(torch.stack(imgs, dim=0))
-                    if h < H:
-                        batch[..., h:, :] = float(self.pad_value)
-                    if w < W:
-                        batch[..., :h, w:] = float(self.pad_value)
+                    if imgs[0].dtype == torch.uint8 and imgs[0].is_cuda and T == 1 and Cc == 3:
+                        # frames uploaded raw (uint8): cast + pad in ONE HIP pass (st_pack_raw_inputs)
+                        raw = torch.cat(imgs, dim=0)
+                        check(_lib.load().st_pack_raw_inputs(ptr(raw), None, len(imgs), h, w, H, W,
+                                                             float(self.pad_value), ptr(batch), None, None,
+                                                             current_stream()), 'st_pack_raw_inputs')
+                    else:
+                        batch[..., :h, :w].copy_(torch.stack(imgs, dim=0))
+                        if h < H:
+                            batch[..., h:, :] = float(self.pad_value)
+                        if w < W:
+                            batch[..., :h, w:] = float(self.pad_value)
                 else:
                     batch = torch.full((len(imgs), T, Cc, H, W), float(self.pad_value), dtype=torch.float32, device=dev)
                     for i, im in enumerate(imgs):

@@ -19,6 +19,15 @@ from .engine import HipDetector, _require_cuda
 from .stereo import StereoCostVolume
 
 
+def default_tuning_cache():
+    """The tuning cache every entry point shares (bench.py, the MOT shell, the parity tests): $ST_TUNE_CACHE, else the
+    committed configs/tuning/mi355x.json.  One committed plan per graph makes the kernel instances - and with them the
+    fp32 summation order, i.e. every float the path returns - the same in the parity tests and in the bench run."""
+    import os
+    return os.environ.get('ST_TUNE_CACHE') or os.path.join(
+        os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'configs', 'tuning', 'mi355x.json')
+
+
 class StereoDensePipeline:
     """Fixed-shape dense path for `batch` frames of `ori_shape` (H, W) pixels."""
 
@@ -54,15 +63,19 @@ class StereoDensePipeline:
 
     def load_state_dict(self, sd, prefix='', autotune=True, tuning_cache=None):
         """Upload weights; then pick conv tile variants by measurement, or restore them from
-        `tuning_cache` (a JSON file keyed by the graph signature) when it holds this graph."""
+        `tuning_cache` (a JSON file keyed by the graph signature; default: default_tuning_cache()) when it holds this
+        graph.  tuning_cache=False: always measure, never read or write a cache."""
         import json
         import os
+        if tuning_cache is None:
+            tuning_cache = default_tuning_cache()
         self.det.load_state_dict(sd, prefix)
         pre = prefix + 'stereo.'
         self.stereo_module.load_state_dict({k[len(pre):]: v for k, v in sd.items() if k.startswith(pre)})
         if not autotune:
             return
-        key = (f'b{self.batch}_{self.height}x{self.width}_s{int(self.stereo)}_a{self.agg_layers}'
+        key = (f'v{self.det.lib.st_version()}_b{self.batch}_{self.height}x{self.width}_w{self.det.widen_factor:g}'
+               f'_d{self.det.deepen_factor:g}_s{int(self.stereo)}_a{self.agg_layers}_D{self.D}'
                f'_ops{self.det.lib.st_detector_num_ops(self.det.handle)}')
         cache = {}
         if tuning_cache and os.path.exists(tuning_cache):
@@ -84,8 +97,11 @@ class StereoDensePipeline:
             cache[key] = self.det.get_tuning()
             if self.agg_layers:
                 cache[key + '_agg'] = self.stereo_module.variant
-            os.makedirs(os.path.dirname(os.path.abspath(tuning_cache)), exist_ok=True)
-            json.dump(cache, open(tuning_cache, 'w'))
+            try:
+                os.makedirs(os.path.dirname(os.path.abspath(tuning_cache)), exist_ok=True)
+                json.dump(cache, open(tuning_cache, 'w'), indent=0, sort_keys=True)
+            except OSError:
+                pass    # a read-only install keeps working: the plan was measured, it is just not remembered
 
     # ---- buffers -----------------------------------------------------------------------------------
     def _buffers(self, dev):

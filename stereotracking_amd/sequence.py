@@ -17,13 +17,31 @@ from .mot import scale_bbox
 from .structures import InstanceData, TrackDataSample
 
 
-def synthetic_sequence(num_frames=64, num_objects=6, height=720, width=1280, max_disp=192, seed=0):
+def _smooth_texture(tex, k=3):
+    """k x k box blur + contrast stretch of a uint8 (..., H, W) noise texture (as synthetic.synthetic_stereo_pair): white
+    noise has no structure at the stride-4 scale the stereo module correlates; an image-like texture does."""
+    if k <= 1:
+        return tex
+    t = tex.astype(np.float32)
+    pad = k // 2
+    tp = np.pad(t, [(0, 0)] * (t.ndim - 2) + [(pad, pad), (pad, pad)], mode='reflect')
+    acc = np.zeros_like(t)
+    H, W = t.shape[-2:]
+    for dy in range(k):
+        for dx in range(k):
+            acc += tp[..., dy:dy + H, dx:dx + W]
+    t = acc / (k * k)
+    t = (t - t.mean()) * (k * 0.9) + 127.5
+    return np.clip(np.rint(t), 0, 255).astype(np.uint8)
+
+
+def synthetic_sequence(num_frames=64, num_objects=6, height=720, width=1280, max_disp=192, seed=0, smooth=3):
     """`num_objects` rectangles (8-60 px) moving with constant velocity + noise
     over a textured background, per-frame disparity consistent with per-object depth 5-60 m
     (disp = 0.25 * 640 / Z).  Yields dicts with left/right uint8 (3,H,W), disp float32 (H,W), gt boxes."""
     rng = np.random.RandomState(seed)
-    bg = rng.randint(0, 256, size=(3, height, width + max_disp)).astype(np.uint8)
-    tex = rng.randint(0, 256, size=(num_objects, 3, 64, 64)).astype(np.uint8)
+    bg = _smooth_texture(rng.randint(0, 256, size=(3, height, width + max_disp)).astype(np.uint8), smooth)
+    tex = _smooth_texture(rng.randint(0, 256, size=(num_objects, 3, 64, 64)).astype(np.uint8), smooth)
     pos = rng.uniform([100, 80], [width - 100, height - 80], (num_objects, 2))
     vel = rng.uniform(-3, 3, (num_objects, 2))
     size = rng.randint(8, 61, (num_objects, 2))
@@ -51,7 +69,8 @@ def synthetic_sequence(num_frames=64, num_objects=6, height=720, width=1280, max
 
 
 def frames_to_batch(frames, device, use_right=True):
-    """List of frame dicts -> padded float tensors in the detector's input layout."""
+    """List of frame dicts -> padded float tensors in the detector's input layout, converted on the HOST and uploaded
+    as fp32 (15 MB per frame).  Kept for small tests; the sequence drivers upload raw bytes (RawFrameUploader)."""
     from .synthetic import pad_to_divisor
     img = np.stack([pad_to_divisor(f['left'].astype(np.float32), 32, 114.0) for f in frames])
     out = dict(img=torch.from_numpy(img).to(device))
@@ -64,9 +83,143 @@ def frames_to_batch(frames, device, use_right=True):
     return out
 
 
-def detect_shard(pipe, frames, device, check_overflow=True):
+def disparity_png_codes(disp):
+    """float32 disparity px -> the uint16 PNG code the dataset stores (code = 16 * px, 65535 = invalid; reference
+    mmtrack/datasets/transforms/loading_disparity.py:82,129-134), or None when 16 * px is not an integer <= 65534
+    (such a map cannot have come from a PNG and is uploaded as fp32)."""
+    c = disp.astype(np.float64) * 16.0
+    if not (np.all(c == np.rint(c)) and c.min() >= 0 and c.max() <= 65534):
+        return None
+    return c.astype(np.uint16)
+
+
+class HostSequence:
+    """A sequence resident in PAGE-LOCKED host memory as the bytes a dataset decodes: left / right uint8
+    (T,3,h,w) and, for the disparity-input configs, uint16 PNG codes (T,h,w).  Batches are uploaded straight
+    from slices of these tensors (no staging copy)."""
+
+    def __init__(self, frames, use_right=True):
+        frames = list(frames)
+        self.use_right = bool(use_right)
+        self.left = torch.from_numpy(np.stack([f['left'] for f in frames])).pin_memory()
+        self.right = self.codes = None
+        if use_right:
+            self.right = torch.from_numpy(np.stack([f['right'] for f in frames])).pin_memory()
+        else:
+            codes = [disparity_png_codes(f['disp']) for f in frames]
+            if any(c is None for c in codes):
+                raise ValueError('HostSequence: disparity maps are not PNG-representable (16 * px not integral)')
+            self.codes = torch.from_numpy(np.stack(codes).view(np.int16)).pin_memory()
+        self.gt = [f.get('gt') for f in frames]
+
+    def __len__(self):
+        return self.left.shape[0]
+
+
+class RawFrameUploader:
+    """Host frames -> device batches in the detector's input layout, crossing PCIe as RAW BYTES (uint8 pixels /
+    uint16 disparity codes: 4.7 MB per frame instead of 15.1 MB of fp32) and converted on the
+    device by st_pack_raw_inputs (cast, x3 channel repeat, /16, invalid -> 0, pad 114 / 0: reference
+    loading_disparity.py:82-134, transforms_disparity.py:234-249, data_preprocessor_disparity_v1.py:38-51).
+
+    Two page-locked staging slots and two device byte buffers alternate; the H2D copies run on a stream of their
+    own, ordered against the pack kernels by events, so the upload of batch i+1 overlaps the dense work of batch i
+    and the host never waits for the device unless it is two batches ahead."""
+
+    def __init__(self, batch, ori_hw, device, use_right=True, slots=2):
+        self.B, (self.h, self.w) = int(batch), (int(ori_hw[0]), int(ori_hw[1]))
+        self.H, self.W = (self.h + 31) // 32 * 32, (self.w + 31) // 32 * 32
+        self.dev, self.use_right = torch.device(device), bool(use_right)
+        self.copy_stream = torch.cuda.Stream(device=self.dev)
+        shape_img, shape_code = (self.B, 3, self.h, self.w), (self.B, self.h, self.w)
+        self.slots = []
+        for _ in range(slots):
+            sl = dict(pin_left=torch.empty(shape_img, dtype=torch.uint8).pin_memory(),
+                      dev_left=torch.empty(shape_img, dtype=torch.uint8, device=self.dev),
+                      uploaded=torch.cuda.Event(), consumed=torch.cuda.Event(), used=False)
+            if self.use_right:
+                sl.update(pin_right=torch.empty(shape_img, dtype=torch.uint8).pin_memory(),
+                          dev_right=torch.empty(shape_img, dtype=torch.uint8, device=self.dev))
+            else:
+                sl.update(pin_code=torch.empty(shape_code, dtype=torch.int16).pin_memory(),
+                          dev_code=torch.empty(shape_code, dtype=torch.int16, device=self.dev))
+            self.slots.append(sl)
+        self._k = 0
+        self.bytes_uploaded = 0
+
+    def _stage(self, sl, frames):
+        """list of frame dicts -> this slot's page-locked buffers (host memcpy)."""
+        n = len(frames)
+        for i in range(self.B):
+            f = frames[min(i, n - 1)]      # a short last batch repeats its last frame (results ignored)
+            sl['pin_left'][i].copy_(torch.from_numpy(f['left']))
+            if self.use_right:
+                sl['pin_right'][i].copy_(torch.from_numpy(f['right']))
+            else:
+                c = disparity_png_codes(f['disp'])
+                if c is None:
+                    raise ValueError('disparity map is not PNG-representable; use frames_to_batch')
+                sl['pin_code'][i].copy_(torch.from_numpy(c.view(np.int16)))
+        return sl['pin_left'], sl.get('pin_right'), sl.get('pin_code')
+
+    def upload(self, frames):
+        """frames: list of <= B frame dicts, or (HostSequence, start, stop).  -> dict(img[, right | disp_postp]) fp32
+        (B,3,H,W) device tensors, produced on the CURRENT stream (a fresh allocation per batch: safe to hand to an
+        in-flight context)."""
+        from ._lib import check, current_stream, load, ptr
+        sl = self.slots[self._k % len(self.slots)]
+        self._k += 1
+        if isinstance(frames, tuple):
+            seq, a, b = frames
+            idx = torch.arange(a, a + self.B).clamp_(max=b - 1)
+            if b - a == self.B:        # straight from the resident page-locked sequence
+                srcs = (seq.left[a:b], seq.right[a:b] if self.use_right else None,
+                        None if self.use_right else seq.codes[a:b])
+            else:                      # ragged last batch: gather (with the last frame repeated) into the slot
+                if sl['used']:
+                    sl['uploaded'].synchronize()
+                sl['pin_left'].copy_(seq.left[idx])
+                if self.use_right:
+                    sl['pin_right'].copy_(seq.right[idx])
+                else:
+                    sl['pin_code'].copy_(seq.codes[idx])
+                srcs = (sl['pin_left'], sl.get('pin_right'), sl.get('pin_code'))
+        else:
+            if sl['used']:
+                sl['uploaded'].synchronize()      # the H2D copy that last read this staging slot has finished
+            srcs = self._stage(sl, list(frames))
+        cur = torch.cuda.current_stream(self.dev)
+        with torch.cuda.stream(self.copy_stream):
+            if sl['used']:
+                self.copy_stream.wait_event(sl['consumed'])   # the pack kernel that last read the device bytes is done
+            for src, name in zip(srcs, ('dev_left', 'dev_right', 'dev_code')):
+                if src is not None:
+                    sl[name].copy_(src, non_blocking=True)
+                    self.bytes_uploaded += src.numel() * src.element_size()
+            sl['uploaded'].record(self.copy_stream)
+        cur.wait_event(sl['uploaded'])
+        lib = load()
+        out = dict(img=torch.empty(self.B, 3, self.H, self.W, dtype=torch.float32, device=self.dev))
+        check(lib.st_pack_raw_inputs(ptr(sl['dev_left']), None, self.B, self.h, self.w, self.H, self.W, 114.0,
+                                     ptr(out['img']), None, None, current_stream()), 'st_pack_raw_inputs')
+        if self.use_right:
+            out['right'] = torch.empty_like(out['img'])
+            check(lib.st_pack_raw_inputs(ptr(sl['dev_right']), None, self.B, self.h, self.w, self.H, self.W, 114.0,
+                                         ptr(out['right']), None, None, current_stream()), 'st_pack_raw_inputs')
+        else:
+            out['disp_postp'] = torch.empty_like(out['img'])
+            check(lib.st_pack_raw_inputs(None, ptr(sl['dev_code']), self.B, self.h, self.w, self.H, self.W, 114.0,
+                                         None, ptr(out['disp_postp']), None, current_stream()), 'st_pack_raw_inputs')
+        sl['consumed'].record(cur)
+        sl['used'] = True
+        return out
+
+
+def detect_shard(pipe, frames, device, check_overflow=True, uploader=None):
     """Dense path over this rank's frames, `pipe.batch` frames per launch plan.  `pipe` is a StereoDensePipeline
-    (strictly serial batches) or an InflightPipelines runner (consecutive batches overlap on its streams).
+    (strictly serial batches) or an InflightPipelines runner (consecutive batches overlap on its streams); `frames`
+    is a list of frame dicts (host numpy) or a HostSequence (page-locked, uploaded without a staging copy).  Frames
+    cross PCIe as raw bytes through a RawFrameUploader (`uploader`: reuse one across calls).
     -> (F_pad, max_det + 1, 8) frame records (header row + SCALED boxes, what the tracker consumes), counts
     (true counts; 0 for batch padding).  Raises DetectionOverflow if a frame kept more than max_det boxes
     (check_overflow=False defers that to unpack_frame, after a collective, so every rank raises together)."""
@@ -74,15 +227,22 @@ def detect_shard(pipe, frames, device, check_overflow=True):
     one = runner.pipes[0] if runner is not None else pipe
     B = one.batch
     bufs = []
+    if uploader is None:
+        uploader = RawFrameUploader(B, (one.ori_h, one.ori_w), device, use_right=one.stereo)
+    resident = isinstance(frames, HostSequence)
+    if not resident and not one.stereo and any(disparity_png_codes(f['disp']) is None for f in frames):
+        uploader = None        # disparity maps that no PNG could hold: fp32 upload (small tests only)
 
     def pack(out, n_real):
         return one.pack_detections(out, scaled=True, n_real=n_real)   # fresh tensor
 
     for i in range(0, len(frames), B):
-        chunk = list(frames[i:i + B])
-        n_real = len(chunk)
-        chunk = chunk + [chunk[-1]] * (B - n_real)  # pad the last batch with a repeated frame
-        batch = frames_to_batch(chunk, device, use_right=one.stereo)
+        n_real = min(B, len(frames) - i)
+        if uploader is not None:
+            batch = uploader.upload((frames, i, i + n_real) if resident else frames[i:i + n_real])
+        else:
+            chunk = list(frames[i:i + n_real])
+            batch = frames_to_batch(chunk + [chunk[-1]] * (B - n_real), device, use_right=one.stereo)
         if runner is not None:   # packed under the context's stream, before that context is reused
             det, _ = runner.submit(batch['img'], right=batch.get('right'), disp_postp=batch.get('disp_postp'),
                                    post=lambda out, ctx, n=n_real: pack(out, n))

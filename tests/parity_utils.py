@@ -194,3 +194,34 @@ def write_record(name, rec):
     os.makedirs(d, exist_ok=True)
     with open(os.path.join(d, name), 'w') as f:
         json.dump(rec, f, indent=1, sort_keys=True)
+
+
+def unscale_boxes_np(boxes, scales):
+    """scale_bbox(boxes, 1 / scales) (reference trackers/utils.py:58-73, as ocsort_disparity.py:95-97 applies it to
+    the tracks), float64 numpy."""
+    boxes, inv = np.asarray(boxes, np.float64), 1.0 / np.asarray(scales, np.float64)
+    cx, cy = (boxes[:, 0] + boxes[:, 2]) / 2, (boxes[:, 1] + boxes[:, 3]) / 2
+    w, h = (boxes[:, 2] - boxes[:, 0]) * inv, (boxes[:, 3] - boxes[:, 1]) * inv
+    return np.stack([cx - w / 2, cy - h / 2, cx + w / 2, cy + h / 2], 1)
+
+
+def match_track_rows(got, ref, tol=1e-3):
+    """Pair the track rows of one frame of two runs by their boxes (a track's box IS the box of the detection it was
+    matched to, and NMS leaves no two detections closer than IoU 0.5, so the pairing is unambiguous): mutual nearest
+    neighbours in L-inf whose distance is within `tol` * max(1, |coordinate|, box extent).
+    -> (pairs [(i_got, j_ref)], rows only in got, rows only in ref, largest relative error over the pairs)."""
+    got, ref = np.asarray(got, np.float64).reshape(-1, 4), np.asarray(ref, np.float64).reshape(-1, 4)
+    if len(got) == 0 or len(ref) == 0:
+        return [], list(range(len(got))), list(range(len(ref))), 0.0
+    d = np.abs(got[:, None, :] - ref[None, :, :])                      # (G, R, 4)
+    ext = np.maximum(ref[:, 2] - ref[:, 0], ref[:, 3] - ref[:, 1])
+    scale = np.maximum(np.maximum(np.abs(ref), 1.0), ext[:, None])    # (R, 4)
+    rel = (d / scale[None]).max(-1)                                    # (G, R)
+    jg, ig = rel.argmin(1), rel.argmin(0)
+    pairs, worst = [], 0.0
+    for i, j in enumerate(jg):
+        if ig[j] == i and rel[i, j] <= tol:
+            pairs.append((i, int(j)))
+            worst = max(worst, float(rel[i, j]))
+    pg, pr = {i for i, _ in pairs}, {j for _, j in pairs}
+    return pairs, [i for i in range(len(got)) if i not in pg], [j for j in range(len(ref)) if j not in pr], worst

@@ -192,13 +192,14 @@ def test_box_depth_large_box_and_w_gt_800(cuda):
     assert rel_err(sb[0], ref_sb.numpy()) <= 1e-3
 
 
-def test_pack_raw_inputs_matches_reference_pipeline(cuda):
+@pytest.mark.parametrize('h,w', [(50, 70), (48, 72), (64, 96)])   # scalar path, 4-pixel path, 4-pixel path without padding
+def test_pack_raw_inputs_matches_reference_pipeline(h, w, cuda):
     """uint8 image + uint16 disparity codes -> the tensors LoadDisparityFromFile._post_processing_v2
     (loading_disparity.py:82-86,129-134), Pad_Disparity (transforms_disparity.py:234-249) and the
     preprocessor (data_preprocessor_disparity_v1.py:38-51) produce; bit-exact."""
     from stereotracking_amd.mot import pack_raw_inputs
     rng = np.random.RandomState(5)
-    N, h, w = 2, 50, 70
+    N = 2
     img = rng.randint(0, 256, (N, 3, h, w)).astype(np.uint8)
     code = rng.randint(0, 48 * 16, (N, h, w)).astype(np.uint16)
     code[rng.uniform(size=code.shape) < 0.1] = 65535
