@@ -126,19 +126,20 @@ def conv_roofline(pipe, img, right, steps):
         t = (tot_ms[sel].sum() + ms_agg) / steps
         fl = 2.0 * (macs[sel].sum() + agg_macs * n_agg / steps)
         n_launch = int(sel.sum()) + n_agg // steps
+        n_events = n_launch      # every op of the plan is bracketed by its own event pair, fused-away ops included
         if VARIANT_TILES[v] == 'front3x3s2':
             n_launch //= 3      # one launch computes three ops of the plan (3x3/s2 + main|short + conv1)
-        per_variant[VARIANT_TILES[v]] = dict(launches=n_launch, ms_per_step=round(float(t), 4),
+        per_variant[VARIANT_TILES[v]] = dict(launches=n_launch, event_pairs=n_events, ms_per_step=round(float(t), 4),
                                              gflop_per_step=round(fl / 1e9, 3),
                                              tflops=round(fl / (t * 1e-3) / 1e12, 3) if t > 0 else 0.0)
     # Kernel families of the MFMA work.  `roofline` describes the DOMINANT one = the family with the largest summed
     # duration per step.  conv_igemm_kernel's tile instances are one kernel template (which instance a layer uses is
     # an autotune outcome that varies from run to run) and are aggregated; the Winograd, direct 3x3, streaming 1x1
     # fused-stem, fused-front and LDS-resident 1x1 kernels are families of their own (a chained 1x1 pair counts as two
-    # `launches` here: ops of the plan, the second with only the event overhead as duration).  `achieved` = ALGORITHMIC flops (2 x MACs of the direct
-    # convolution) / summed duration.  The Winograd kernel executes 2.25x fewer multiplies than
-    # that for the same convolution, so its algorithmic rate may exceed the MFMA peak: `mfma_executed_tflops` is the
-    # rate of the multiplies it actually issues (= what the matrix pipes see).
+    # `launches` here: ops of the plan, the second with only the event overhead as duration).  `tflops` / `frac` = flops the
+    # matrix pipes EXECUTE / summed duration (<= peak by construction); `algorithmic_tflops` = 2 x MACs of the direct
+    # convolution / the same duration: the Winograd kernel executes 2.25x fewer multiplies than that,
+    # so its algorithmic rate may exceed the MFMA peak (`algorithmic_speedup`).
     FAMILY = {'stem6x6s2': 'st::stem_focus_conv_kernel', 'pw128': 'st::pw_conv_kernel', 'dc4x32': 'st::direct_conv3x3_kernel',
               'wino2x2': 'st::wino_conv3x3_kernel', 'wino2x2n': 'st::wino_conv3x3_kernel', 'skipped': None,
               'front3x3s2': 'st::front_s2_csp_kernel', 'pwres': 'st::pw_resident_kernel',
@@ -148,27 +149,42 @@ def conv_roofline(pipe, img, right, steps):
         f = FAMILY.get(name, 'st::conv_igemm_kernel')
         if f is None:
             continue
-        e = fam.setdefault(f, dict(launches=0, ms_per_step=0.0, gflop_per_step=0.0, instances=[]))
+        e = fam.setdefault(f, dict(launches=0, event_pairs=0, ms_per_step=0.0, gflop_per_step=0.0, instances=[]))
         e['launches'] += v['launches']
+        e['event_pairs'] += v['event_pairs']
         e['ms_per_step'] += v['ms_per_step']
         e['gflop_per_step'] += v['gflop_per_step']
         e['instances'].append(name)
+    # Durations: raw HIP-event times carry the event-pair overhead (two barrier packets, measured above on this stream:
+    # `event_pair_overhead_us`); rocprofv3's kernel durations do not.  The overhead is subtracted per launch so that
+    # `achieved` / `avg_launch_us` reproduce from profiles/r03_kernel_stats_inflight1.csv (the raw figures are kept
+    # next to them).  `frac` is a fraction of the INSTRUCTION peak: flops the matrix pipes execute / time / 157.3 - for
+    # the Winograd family that is the direct-convolution count / 2.25 (F(2x2,3x3) issues 16 of every 36 multiplies),
+    # which goes into `algorithmic_speedup`, never into `frac`.
+    WINO = 'st::wino_conv3x3_kernel'
     for f, e in fam.items():
-        e['tflops'] = round(e['gflop_per_step'] / e['ms_per_step'], 3) if e['ms_per_step'] > 0 else 0.0
+        speed = 2.25 if f == WINO else 1.0
+        raw = e['ms_per_step']
+        e['ms_per_step_raw_events'] = round(raw, 4)
+        e['ms_per_step'] = max(raw - e['event_pairs'] * null_ms, 1e-6)
+        e['algorithmic_tflops'] = round(e['gflop_per_step'] / e['ms_per_step'], 3)
+        e['algorithmic_speedup'] = speed
+        e['tflops'] = round(e['gflop_per_step'] / speed / e['ms_per_step'], 3)       # executed by the matrix pipes
         e['frac'] = round(e['tflops'] / PEAK_FP32_MFMA_TFLOPS, 4)
         e['ms_per_step'] = round(e['ms_per_step'], 4)
         e['gflop_per_step'] = round(e['gflop_per_step'], 3)
-        if f == 'st::wino_conv3x3_kernel':
-            e['mfma_executed_tflops'] = round(e['tflops'] / 2.25, 3)
-            e['mfma_executed_frac'] = round(e['tflops'] / 2.25 / PEAK_FP32_MFMA_TFLOPS, 4)
+        e['executed_gflop_per_step'] = round(e['gflop_per_step'] / speed, 3)
     dom = max(fam, key=lambda k: fam[k]['ms_per_step'])
     D = fam[dom]
-    conv_ms = float((tot_ms[kind == 1].sum() + sum(a[1] for a in agg.values())) / steps)
+    n_conv_launches = sum(e['event_pairs'] for e in fam.values())
+    conv_ms = float((tot_ms[kind == 1].sum() + sum(a[1] for a in agg.values())) / steps) - n_conv_launches * null_ms
     conv_fl = 2.0 * float(macs[kind == 1].sum() + agg_macs * sum(a[0] for a in agg.values()) / steps)
-    # HBM bytes per launch of the dominant family from the committed rocprofv3 PMC passes of this command (FETCH_SIZE
-    # x2 gfx950 correction + WRITE_SIZE, separate passes; tools/pmc_summary.py) - NOT measured inside this run
+    conv_exec = sum(e['executed_gflop_per_step'] for e in fam.values()) * 1e9
+    # HBM bytes per launch of the dominant family from this round's rocprofv3 PMC passes of this command (FETCH_SIZE x2
+    # gfx950 correction + WRITE_SIZE, separate passes; tools/profile_round.sh writes profiles/r03_hbm_traffic.json from
+    # the SAME commit's library).  null when that file is absent: never a number from another round.
     traffic, traffic_src = None, None
-    tpath = os.path.join(ROOT, 'profiles', 'r02_hbm_traffic.json')
+    tpath = os.path.join(ROOT, 'profiles', 'r03_hbm_traffic.json')
     if os.path.exists(tpath):
         tj = json.load(open(tpath))
         tot_b, cov = 0.0, 0
@@ -179,27 +195,30 @@ def conv_roofline(pipe, img, right, steps):
                 cov += n
         if cov:
             traffic = int(tot_b / cov)
-            traffic_src = ('profiles/r02_hbm_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command '
-                           '(separate runs, not measured inside this one), launch-weighted over %s*' % dom)
+            traffic_src = ('profiles/r03_hbm_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command '
+                           '(separate runs of tools/profile_round.sh), launch-weighted over %s*' % dom)
     roof = dict(bound='mfma', kernel=dom + ('<...> (all tile instances)' if dom == 'st::conv_igemm_kernel' else ''),
                 achieved=D['tflops'], peak=PEAK_FP32_MFMA_TFLOPS, unit='TFLOP/s', frac=D['frac'],
                 traffic=traffic, traffic_source=traffic_src,
-                flop_per_launch=round(D['gflop_per_step'] * 1e9 / max(D['launches'], 1)),
+                algorithmic_tflops=D['algorithmic_tflops'], algorithmic_speedup=D['algorithmic_speedup'],
+                flop_per_launch=round(D['executed_gflop_per_step'] * 1e9 / max(D['launches'], 1)),
+                algorithmic_flop_per_launch=round(D['gflop_per_step'] * 1e9 / max(D['launches'], 1)),
                 avg_launch_us=round(D['ms_per_step'] * 1e3 / max(D['launches'], 1), 2),
+                avg_launch_us_raw_events=round(D['ms_per_step_raw_events'] * 1e3 / max(D['launches'], 1), 2),
                 launches_per_step=D['launches'], event_pair_overhead_us=round(null_ms * 1e3, 2),
-                event_overhead_subtracted=False,
-                definition='achieved = algorithmic flops of the direct convolution / summed HIP-event duration of the '
-                           'family\'s launches in a serialized pass',
+                event_overhead_subtracted=True,
+                definition='achieved = flops EXECUTED by the matrix pipes (direct-convolution count / algorithmic_speedup) '
+                           '/ summed kernel duration of the family in a serialized pass (HIP events on the launch '
+                           'stream minus the measured event-pair overhead; agrees with the rocprofv3 kernel-trace '
+                           'durations in profiles/r03_kernel_stats_inflight1.csv); frac = achieved / peak <= 1',
                 families=fam,
                 all_mfma_kernels=dict(ms_per_step=round(conv_ms, 4),
-                                      tflops=round(conv_fl / (conv_ms * 1e-3) / 1e12, 3),
-                                      frac=round(conv_fl / (conv_ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4)),
+                                      algorithmic_tflops=round(conv_fl / (conv_ms * 1e-3) / 1e12, 3),
+                                      tflops=round(conv_exec / (conv_ms * 1e-3) / 1e12, 3),
+                                      frac=round(conv_exec / (conv_ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4)),
                 per_variant=per_variant,
                 other_kernels_ms_per_step={k: round(v / steps, 4) for k, v in other.items()},
                 focus_spp_ms_per_step=round(float(tot_ms[kind != 1].sum() / steps), 4))
-    if 'mfma_executed_tflops' in D:
-        roof['mfma_executed_tflops'] = D['mfma_executed_tflops']
-        roof['mfma_executed_frac'] = D['mfma_executed_frac']
     # secondary roofline (SURVEY.md §8d "cost volume: HBM-bound scan", materialised form at 1/4 resolution):
     # algorithmic bytes of one costvolume launch = both feature maps read once + the volume written once
     Cf = pipe.det.tap('stage1_rgb').shape[-1]
@@ -250,7 +269,7 @@ def costvolume_fullres(lib, reps=5):
         return dict(error=repr(e))
 
 
-def cpu_baseline(sd, batch_cpu, max_disp, seconds, agg_layers):
+def cpu_baseline(sd, batch_cpu, max_disp, seconds, agg_layers, max_det=1000):
     """The CPU oracle (kind 'port': this repo's restatement of the reference path; the reference itself
     cannot be imported) timed on the host cores over whole stereo pairs."""
     import numpy as np
@@ -282,8 +301,8 @@ def cpu_baseline(sd, batch_cpu, max_disp, seconds, agg_layers):
             off += hw * 8
             flat.append(pad.reshape(-1))
         head = torch.cat(flat).numpy()
-        boxes, scores, labels, prior, counts = c_oracle.decode_nms(head, 1, levels, 0.01, 0.5, 300, (ori_h, ori_w))
-        k = min(int(counts[0]), 300)
+        boxes, scores, labels, prior, counts = c_oracle.decode_nms(head, 1, levels, 0.01, 0.5, max_det, (ori_h, ori_w))
+        k = min(int(counts[0]), max_det)      # the same capacity as the GPU's detection buffer: no box dropped
         odepth.bbox_postp_depth(torch.from_numpy(boxes[0, :k]), disp)
         return k
 
@@ -520,6 +539,13 @@ def main():
         Hf, Wf = pipe.height // pipe.feat_stride, pipe.width // pipe.feat_stride
         roof['gflop_per_pair_conv'] = round(
             2.0 * (pipe.det.macs + pipe.agg_layers * pipe.stereo_module.agg_macs(B, Hf, Wf)) / B / 1e9, 3)
+        # the whole detector against the fp32 MFMA roof = 66.96 GFLOP (direct-convolution count) per
+        # pair x pairs/s / 157.3 TFLOP/s, from the TIMED region's throughput (all kernels, 3 contexts in flight)
+        roof['pipeline_achieved_tflops'] = round(66.96e9 * line['value'] / world / 1e12, 3)
+        roof['pipeline_frac'] = round(66.96e9 * line['value'] / world / (PEAK_FP32_MFMA_TFLOPS * 1e12), 4)
+        roof['pipeline_definition'] = ('SURVEY.md 8(d): 66.96 GFLOP of direct convolution per pair x pairs/s per GPU / '
+                                       '157.3 TFLOP/s (Winograd layers counted at their direct-convolution flops: an '
+                                       'algorithmic rate, may exceed what the pipes execute)')
         roof['measured'] = ('separate serialized pass on one context after the timed region: with inflight > 1 the '
                             'timed region overlaps kernels of consecutive batches, which inflates per-launch durations '
                             '(compare profiles/*_inflight1 for the serialized rocprof summary)')
@@ -532,7 +558,7 @@ def main():
                 line['test_step']['long_call']['vs_pipeline'] = round(line['test_step']['long_call']['value'] / line['value'], 4)
         line['tracker_cpu'] = tracker_cost()
         if world == 1 and not args.no_cpu_baseline:
-            line['cpu_baseline'] = cpu_baseline(sd, batch_cpu, args.max_disp, args.cpu_seconds, args.agg_layers)
+            line['cpu_baseline'] = cpu_baseline(sd, batch_cpu, args.max_disp, args.cpu_seconds, args.agg_layers, args.max_det)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

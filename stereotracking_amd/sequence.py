@@ -145,21 +145,29 @@ class RawFrameUploader:
                           dev_code=torch.empty(shape_code, dtype=torch.int16, device=self.dev))
             self.slots.append(sl)
         self._k = 0
+        self._pool = None
         self.bytes_uploaded = 0
 
     def _stage(self, sl, frames):
-        """list of frame dicts -> this slot's page-locked buffers (host memcpy)."""
+        """list of frame dicts -> this slot's page-locked buffers.  The 2.8 MB per-frame copies run on a few host
+        threads (memcpy releases the GIL): one thread moves ~5 GB/s, i.e. 9 ms per 8-pair batch against 4.7 ms of
+        dense work."""
         n = len(frames)
+        jobs = []
         for i in range(self.B):
             f = frames[min(i, n - 1)]      # a short last batch repeats its last frame (results ignored)
-            sl['pin_left'][i].copy_(torch.from_numpy(f['left']))
+            jobs.append((sl['pin_left'][i], f['left']))
             if self.use_right:
-                sl['pin_right'][i].copy_(torch.from_numpy(f['right']))
+                jobs.append((sl['pin_right'][i], f['right']))
             else:
                 c = disparity_png_codes(f['disp'])
                 if c is None:
                     raise ValueError('disparity map is not PNG-representable; use frames_to_batch')
-                sl['pin_code'][i].copy_(torch.from_numpy(c.view(np.int16)))
+                jobs.append((sl['pin_code'][i], c.view(np.int16)))
+        if self._pool is None:
+            from concurrent.futures import ThreadPoolExecutor
+            self._pool = ThreadPoolExecutor(max_workers=4)
+        list(self._pool.map(lambda j: j[0].copy_(torch.from_numpy(j[1])), jobs))
         return sl['pin_left'], sl.get('pin_right'), sl.get('pin_code')
 
     def upload(self, frames):

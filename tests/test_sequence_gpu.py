@@ -140,7 +140,7 @@ def test_config2_full_size_64_frame_sequence(cuda):
     two-branch detector + 2 aggregation convs, detector + disparity feeding the (CPU) association, on one GPU.
     Batched execution (8 frames per launch plan on 3 in-flight contexts) gives bit-identical detections and the same
     track ids / boxes as the strictly sequential frame-by-frame run (batch 1, one context); the measured rates go
-    into gpurun_out/r02_config2.json (copied to profiles/)."""
+    into gpurun_out/r03_config2.json (copied to profiles/)."""
     import json
     import os
     import time
@@ -156,12 +156,20 @@ def test_config2_full_size_64_frame_sequence(cuda):
     # random weights give low scores: gates low enough that tracks are started and matched (as tests/test_shell_gpu.py)
     cfg = dict(obj_score_thr=0.02, init_track_thr=0.05, weight_iou_with_det_scores=False, match_iou_thr=0.1,
                num_tentatives=3, vel_consist_weight=0.2, vel_delta_t=3, num_frames_retain=30)
-    detect_shard(runner, frames[:8], cuda)                       # warm-up (first-launch costs)
+    from stereotracking_amd.sequence import HostSequence, RawFrameUploader
+    up = RawFrameUploader(8, (H, W), cuda, use_right=True)
+    detect_shard(runner, frames[:8], cuda, uploader=up)          # warm-up (first-launch costs)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    db, cb = detect_shard(runner, frames, cuda)
+    db, cb = detect_shard(runner, frames, cuda, uploader=up)     # frames = host numpy: staged through 2 pinned slots
     torch.cuda.synchronize()
     t_dense = time.perf_counter() - t0
+    resident = HostSequence(frames, use_right=True)              # the decoded bytes resident in page-locked memory
+    t0 = time.perf_counter()
+    dr, cr = detect_shard(runner, resident, cuda, uploader=up)
+    torch.cuda.synchronize()
+    t_res = time.perf_counter() - t0
+    assert torch.equal(dr.nan_to_num(-7.0), db.nan_to_num(-7.0)) and torch.equal(cr, cb)
     t0 = time.perf_counter()
     rb = track_gathered(db, cb, T, OCSORTTracker_Disparity(**cfg), _Model())
     t_track = time.perf_counter() - t0
@@ -180,10 +188,14 @@ def test_config2_full_size_64_frame_sequence(cuda):
     assert n_trk > T, 'the scenario must exercise the association step'
     rec = dict(config='configs[2]: 64-frame synthetic 1280x720 sequence, D=192, full YOLOX-s, 1 GPU',
                frames=T, dense_seconds=round(t_dense, 4), dense_frames_per_s=round(T / t_dense, 1),
-               includes='host->device upload of the float frames (frames_to_batch) + dense path, 8 frames per plan on 3 contexts',
+               includes='host numpy frames -> 2 pinned staging slots -> uint8 H2D on a copy stream -> st_pack_raw_inputs -> dense '
+                        'path, 8 frames per plan on 3 contexts',
+               dense_frames_per_s_from_pinned_u8=round(T / t_res, 1),
+               includes_pinned='the same from a HostSequence (uint8 frames resident in page-locked memory: no staging copy)',
+               uploaded_bytes_per_frame=int(up.bytes_uploaded / (2 * T + 8)),
                tracker_seconds=round(t_track, 4), tracker_ms_per_frame=round(t_track / T * 1e3, 4),
                tracks_returned=n_trk, detections_per_frame_mean=round(float(c1.float().mean()), 1),
                end_to_end_frames_per_s=round(T / (t_dense + t_track), 1))
     os.makedirs('gpurun_out', exist_ok=True)
-    json.dump(rec, open('gpurun_out/r02_config2.json', 'w'), indent=1)
+    json.dump(rec, open('gpurun_out/r03_config2.json', 'w'), indent=1)
     print(rec)
