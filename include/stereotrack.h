@@ -283,7 +283,7 @@ size_t st_decode_nms_workspace_bytes(const StDecodeDesc* d);
  * the bit-exact identity of a kept box), out_count[n] = number kept (may exceed
  * max_det: then only the first max_det are stored - the reference applies NO cap under
  * yolox_style=True, so callers must treat out_count[n] > max_det as an overflow and re-run with a
- * larger buffer or raise; rows past min(count, max_det) are left untouched). */
+ * larger buffer or raise; rows past min(count, max_det) are written as zero, prior index -1). */
 int st_decode_nms(const StDecodeDesc* d, const float* head_out_dev, void* workspace_dev,
                   size_t workspace_bytes, st_stream_t stream, float* out_boxes_dev,
                   float* out_scores_dev, int64_t* out_labels_dev, int32_t* out_prior_idx_dev,
@@ -324,6 +324,17 @@ int st_box_depth(const float* disp_dev, size_t img_pitch, int N, int H, int W,
                  const float* boxes_dev, const int32_t* counts_dev, int max_det, float baseline,
                  float focal, void* workspace_dev, size_t workspace_bytes, st_stream_t stream,
                  float* out_depth_dev, float* out_scale_dev, float* out_scaled_boxes_dev);
+
+/* Frame records: the fixed-size, self-describing unit of the detection all-gather and of the ONE
+ * device->host copy per chunk of the MOT shell: out (N, max_det + 1, cols) fp32, row 0 = [true count (may exceed
+ * max_det = overflow), max_det, valid-frame flag, 0...], rows 1.. = x1,y1,x2,y2,score,label,depth,scale.
+ * mode 0: unscaled boxes (what reference mmtrack/models/mot/ocsort_disparity.py:107-108 returns as pred_det_instances),
+ * mode 1: the depth-scaled boxes the tracker consumes (:82-86), cols = 8; mode 2: unscaled box first, scaled box and
+ * kept prior index appended, cols = 13.  Frames >= n_real are batch padding (header all zero).  One launch. */
+int st_pack_records(const float* boxes_dev, const float* scores_dev, const int64_t* labels_dev, const float* depth_dev,
+                    const float* scales_dev, const float* scaled_boxes_dev, const int32_t* prior_idx_dev,
+                    const int32_t* counts_dev, int N, int max_det, int mode, int n_real, float* out_records_dev,
+                    st_stream_t stream);
 /* rows k >= min(counts[n], max_det) of the three outputs are written as 0 (never stale). */
 
 /* ------------------------------------------------------------------------

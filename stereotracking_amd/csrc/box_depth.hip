@@ -21,8 +21,8 @@
 // depths are positive, so the unsigned order equals the float order); the two segment bounds are
 // selected together (two histograms per pass); the trimmed mean is accumulated in fp64 and rounded
 // once (numpy uses fp32 pairwise summation: equal to ~1e-6 relative, inside the 1e-3 float
-// tolerance of the path).  Windows of up to 12288 pixels (every realistic drone box) are cached in
-// LDS by the counting pass, so the 9 following passes never touch memory again.
+// tolerance of the path).  Windows of up to 4096 pixels (every realistic drone box) are cached in
+// LDS by the counting pass, so the following passes never touch memory again.
 #include <algorithm>
 
 #include "st_common.h"
@@ -31,7 +31,13 @@ namespace st {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int BD_CACHE = 12288;  // floats of LDS window cache (48 KiB)
+// One SMALL workgroup per box: drone boxes are tens of pixels wide (8-60 px objects, 4-80 px boxes of
+// the synthetic head), so a box is ~15 elements per lane for BD_THREADS lanes and the kernel's time is the ~20
+// workgroup barriers of the 6 passes, not the data.  512-thread workgroups (round 2) kept 8 waves waiting at every
+// barrier and only 2 boxes per CU in flight: 192 us for ~3000 boxes.  128 threads and a 16 KiB window cache put 6
+// boxes on a CU at once; windows above BD_CACHE pixels stream from L2 in every pass (rare, still exact).
+constexpr int BD_THREADS = 128;
+constexpr int BD_CACHE = 4096;   // floats of LDS window cache (16 KiB)
 
 __device__ __forceinline__ int py_slice_index(int i, int len) {
   if (i < 0) {
@@ -120,8 +126,8 @@ __device__ void select_ranks(const Window& w, const int* ranks, unsigned (*hist)
     __syncthreads();
     // one wave per rank: 64-lane prefix sum over the 256 bins (4 bins per lane), the lane whose bins
     // straddle the rank reports (bin, count below it)
-    const int wv = threadIdx.x >> 6, ln = threadIdx.x & 63;
-    if (wv < BD_NR) {
+    const int wv0 = threadIdx.x >> 6, ln = threadIdx.x & 63, nwv = blockDim.x >> 6;
+    for (int wv = wv0; wv < BD_NR; wv += nwv) {   // the ranks are dealt over the waves of the workgroup
       int rq = 0;
       unsigned pq = 0;
 #pragma unroll
@@ -179,7 +185,7 @@ __device__ float corner_mean(const float* disp, int H, int W, int r0, int r1, in
   return s / (float)cnt;
 }
 
-__global__ __launch_bounds__(512) void box_depth_kernel(const float* __restrict__ disp_all, size_t img_pitch, int H,
+__global__ __launch_bounds__(BD_THREADS) void box_depth_kernel(const float* __restrict__ disp_all, size_t img_pitch, int H,
                                                         int W, const float* __restrict__ boxes,
                                                         const int* __restrict__ counts, int max_det, float bf,
                                                         int is_depth, float* __restrict__ out_depth,
@@ -189,8 +195,8 @@ __global__ __launch_bounds__(512) void box_depth_kernel(const float* __restrict_
   __shared__ unsigned hist[BD_NR][256];
   __shared__ unsigned sh[2 * BD_NR];
   __shared__ int s_len;
-  __shared__ double s_red[512];
-  __shared__ int s_cnt[4][512];
+  __shared__ double s_red[BD_THREADS / 64];
+  __shared__ int s_cnt[4][BD_THREADS / 64];
   const int n = blockIdx.y, k = blockIdx.x;
   const int cnt_n = min(counts[n], max_det);
   if (k >= cnt_n) {  // block-uniform: rows past the count are defined (zero), never stale
@@ -293,18 +299,27 @@ __global__ __launch_bounds__(512) void box_depth_kernel(const float* __restrict_
           if (d > va && d < vb) sum += (double)d;
         }
       });
-      s_red[threadIdx.x] = sum;
-      s_cnt[0][threadIdx.x] = lt_a; s_cnt[1][threadIdx.x] = eq_a;
-      s_cnt[2][threadIdx.x] = lt_b; s_cnt[3][threadIdx.x] = eq_b;
-      __syncthreads();
-      for (int s = 256; s > 0; s >>= 1) {
-        if ((int)threadIdx.x < s) {
-          s_red[threadIdx.x] += s_red[threadIdx.x + s];
+      // wave reduction by shuffles, then one LDS slot per wave (fp64 sum: the order is fixed, so deterministic)
 #pragma unroll
-          for (int q = 0; q < 4; ++q) s_cnt[q][threadIdx.x] += s_cnt[q][threadIdx.x + s];
-        }
-        __syncthreads();
+      for (int off = 32; off > 0; off >>= 1) {
+        sum += __shfl_xor(sum, off);
+        lt_a += __shfl_xor(lt_a, off); eq_a += __shfl_xor(eq_a, off);
+        lt_b += __shfl_xor(lt_b, off); eq_b += __shfl_xor(eq_b, off);
       }
+      const int wvr = threadIdx.x >> 6;
+      if ((threadIdx.x & 63) == 0) {
+        s_red[wvr] = sum;
+        s_cnt[0][wvr] = lt_a; s_cnt[1][wvr] = eq_a; s_cnt[2][wvr] = lt_b; s_cnt[3][wvr] = eq_b;
+      }
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        for (int v = 1; v < (int)(blockDim.x >> 6); ++v) {
+          s_red[0] += s_red[v];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) s_cnt[q][0] += s_cnt[q][v];
+        }
+      }
+      __syncthreads();
       const int n_lt_a = s_cnt[0][0], n_eq_a = s_cnt[1][0], n_lt_b = s_cnt[2][0], n_eq_b = s_cnt[3][0];
       double tot = s_red[0];
       const int ca = min(n_lt_a + n_eq_a, b) - max(n_lt_a, a);
@@ -331,7 +346,67 @@ __global__ __launch_bounds__(512) void box_depth_kernel(const float* __restrict_
   }
 }
 
+// Frame records for the all-gather / the one D2H copy per chunk: (N, M + 1, cols) fp32.  Row 0 = header [true count,
+// M, valid-frame flag, 0 ...]; rows 1..M = x1,y1,x2,y2 (mode 1: the depth-scaled box), score, label, depth, scale
+// [mode 2: + scaled box (4) + kept prior index].  One launch instead of ~10 cat / fill / cast launches.
+__global__ __launch_bounds__(256) void pack_records_kernel(const float* __restrict__ boxes,
+                                                           const float* __restrict__ scores,
+                                                           const long long* __restrict__ labels,
+                                                           const float* __restrict__ depth,
+                                                           const float* __restrict__ scales,
+                                                           const float* __restrict__ sboxes,
+                                                           const int* __restrict__ prior,
+                                                           const int* __restrict__ counts, int N, int M, int mode,
+                                                           int n_real, float* __restrict__ out) {
+  const int cols = mode == 2 ? 13 : 8;
+  const long long total = (long long)N * (M + 1);
+  for (long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x; r < total;
+       r += (long long)gridDim.x * blockDim.x) {
+    const int n = (int)(r / (M + 1)), k = (int)(r % (M + 1));
+    float* o = out + r * cols;
+    if (k == 0) {
+      const bool real = n < n_real;
+      o[0] = real ? (float)counts[n] : 0.f;
+      o[1] = real ? (float)M : 0.f;
+      o[2] = real ? 1.f : 0.f;
+      for (int c = 3; c < cols; ++c) o[c] = 0.f;
+      continue;
+    }
+    const size_t i = (size_t)n * M + (k - 1);
+    const f32x4 b = *reinterpret_cast<const f32x4*>(boxes + i * 4);
+    const f32x4 sb = *reinterpret_cast<const f32x4*>(sboxes + i * 4);
+    const f32x4 first = mode == 1 ? sb : b;
+    o[0] = first[0]; o[1] = first[1]; o[2] = first[2]; o[3] = first[3];
+    o[4] = scores[i];
+    o[5] = (float)labels[i];
+    o[6] = depth[i];
+    o[7] = scales[i];
+    if (mode == 2) {
+      o[8] = sb[0]; o[9] = sb[1]; o[10] = sb[2]; o[11] = sb[3];
+      o[12] = (float)prior[i];   // prior index < 2^24: exact in fp32
+    }
+  }
+}
+
 }  // namespace st
+
+extern "C" int st_pack_records(const float* boxes_dev, const float* scores_dev, const int64_t* labels_dev,
+                               const float* depth_dev, const float* scales_dev, const float* scaled_boxes_dev,
+                               const int32_t* prior_idx_dev, const int32_t* counts_dev, int N, int max_det, int mode,
+                               int n_real, float* out_records_dev, st_stream_t stream_) {
+  using namespace st;
+  ST_REQUIRE(boxes_dev && scores_dev && labels_dev && depth_dev && scales_dev && scaled_boxes_dev && counts_dev &&
+                 out_records_dev, "st_pack_records: null pointer");
+  ST_REQUIRE(mode >= 0 && mode <= 2 && (mode != 2 || prior_idx_dev), "st_pack_records: bad mode");
+  ST_REQUIRE(N > 0 && max_det > 0 && n_real >= 0, "st_pack_records: bad geometry");
+  const long long total = (long long)N * (max_det + 1);
+  const int blocks = (int)std::min<long long>((total + 255) / 256, 2048);
+  hipLaunchKernelGGL(pack_records_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream_), boxes_dev,
+                     scores_dev, reinterpret_cast<const long long*>(labels_dev), depth_dev, scales_dev,
+                     scaled_boxes_dev, prior_idx_dev, counts_dev, N, max_det, mode, n_real, out_records_dev);
+  ST_CHECK_HIP(hipGetLastError());
+  return ST_OK;
+}
 
 extern "C" size_t st_box_depth_workspace_bytes(int, int, int, int) { return 0; }
 
@@ -348,7 +423,7 @@ extern "C" int st_box_depth(const float* disp_dev, size_t img_pitch, int N, int 
   // ocsort_disparity.py:120-122); bf = baseline * focal as a Python float product rounded to fp32
   const int is_depth = baseline < 0.f;
   const float bf = (float)((double)baseline * (double)focal);
-  hipLaunchKernelGGL(box_depth_kernel, dim3(max_det, N), dim3(512), 0, static_cast<hipStream_t>(stream_), disp_dev,
+  hipLaunchKernelGGL(box_depth_kernel, dim3(max_det, N), dim3(BD_THREADS), 0, static_cast<hipStream_t>(stream_), disp_dev,
                      img_pitch, H, W, boxes_dev, counts_dev, max_det, bf, is_depth, out_depth_dev, out_scale_dev,
                      out_scaled_boxes_dev);
   ST_CHECK_HIP(hipGetLastError());

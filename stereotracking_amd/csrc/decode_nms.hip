@@ -268,6 +268,16 @@ __global__ __launch_bounds__(64) void nms_reduce_kernel(DecodeArgs a, float* out
     __syncthreads();
   }
   if (lane == 0) out_count[n] = outcount;
+  // rows past the count are DEFINED by this kernel (zero boxes / scores / labels, prior index -1): the caller's
+  // output buffers are persistent and need no clearing launch per batch
+  const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+  for (int pos = min(outcount, a.max_det) + lane; pos < a.max_det; pos += 64) {
+    const size_t oo = (size_t)n * a.max_det + pos;
+    *reinterpret_cast<f32x4*>(out_boxes + oo * 4) = z4;
+    out_scores[oo] = 0.f;
+    out_labels[oo] = 0;
+    out_prior[oo] = -1;
+  }
 }
 
 struct DecodeLayout {

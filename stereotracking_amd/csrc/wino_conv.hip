@@ -57,6 +57,7 @@ struct WinoArgs {
   float post_scale;
   int act;
   int tbx, tby, ncb, nkc;
+  int g_last;   // channel groups of 8 that exist in the LAST K-chunk (4 unless Cin % 32 != 0)
   unsigned in_bytes, out_bytes, res_bytes, wino_bytes;
   int abl;   // tools-only (ST_ABLATION): 1 = weight fragments loaded once, 2 = window DMA once, 3 = both (wrong results)
 };
@@ -114,7 +115,9 @@ __device__ __forceinline__ f32x4 wn_sub_mfma(f32x4 a, f32x4 b) {
 // CBN = cout blocks of 32 a workgroup computes; LCBN = cout blocks per group in the weight LAYOUT (>= CBN).  LCBN = 2 with
 // CBN = 1 (tile variant 44) runs a 64-cout layout with 32-cout workgroups: twice the workgroups, for the small maps
 // (23x40, 46x80) whose grid otherwise fills less than one round of the chip.
-template <int CBN, int LCBN, bool RES>
+// KTAIL: Cin % 32 != 0 (the 48-level aggregation convs): the last K-chunk runs only the channel groups that exist
+// (g_last of 4) instead of multiplying zero-padded channels - a quarter of the layer's MFMAs at Cin = 48.
+template <int CBN, int LCBN, bool RES, bool KTAIL>
 __global__ __launch_bounds__(256, 2) void wino_conv3x3_kernel(const WinoArgs p) {
   constexpr int WN_CB = 32 * CBN;                       // couts per workgroup
   constexpr int WN_FRAG_FLOATS = LCBN * 64 * 4;         // one (kc, g, b) step in memory: LCBN cout blocks x 64 lanes x 4
@@ -220,8 +223,10 @@ __global__ __launch_bounds__(256, 2) void wino_conv3x3_kernel(const WinoArgs p) 
     if (kc + 1 < p.nkc) dma_window(kc + 1, buf ^ 1);   // lands during this chunk's 128 MFMAs
 #endif
     const float* win = smem + buf * WN_WIN_FLOATS;
+    const int gn = (KTAIL && kc == p.nkc - 1) ? p.g_last : 4;   // wave-uniform
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
+      if (KTAIL && g >= gn) continue;
       // raw patch -> V[a][0..3] for this lane's 4 channels (8g + 4h .. + 3)
       f32x4 d[8];
 #ifdef ST_ABLATION
@@ -403,11 +408,11 @@ bool wino_conv_applicable(const StConvDesc& d) {
   return true;
 }
 
-template <int CBN, int LCBN, bool RES>
+template <int CBN, int LCBN, bool RES, bool KTAIL = false>
 static int wino_launch_instance(const WinoArgs& a, unsigned blocks, hipStream_t stream) {
   constexpr int lds = wn_lds_floats(CBN) * (int)sizeof(float);
   static int lds_set = 0;
-  auto kern = wino_conv3x3_kernel<CBN, LCBN, RES>;
+  auto kern = wino_conv3x3_kernel<CBN, LCBN, RES, KTAIL>;
   ST_ENSURE_DYNAMIC_LDS(kern, lds, lds_set);
   hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), lds, stream, a);
   return ST_OK;
@@ -436,6 +441,8 @@ int wino_conv_launch(const StConvDesc& d, hipStream_t stream, bool narrow) {
   a.out_bytes = (unsigned)(M * d.out1_ld * 4);
   a.res_bytes = d.res_dev ? (unsigned)(M * d.res_ld * 4) : 0u;
   a.wino_bytes = (unsigned)(wino_packed_floats(d.Cout, d.Cin) * 4);
+  a.g_last = 4 - (a.nkc * 32 - d.Cin) / 8;          // whole groups of 8 padded channels are skipped
+  const bool ktail = a.g_last < 4;
   a.abl = 0;
 #ifdef ST_ABLATION
   if (const char* e = getenv("ST_WN_ABL")) a.abl = atoi(e);
@@ -443,7 +450,9 @@ int wino_conv_launch(const StConvDesc& d, hipStream_t stream, bool narrow) {
   const long long blocks = (long long)d.N * a.tbx * a.tby * a.ncb;
   ST_REQUIRE(blocks < (1ll << 31), "winograd conv: grid too large");
   int rc;
-  if (cbn == 2) rc = d.res_dev ? wino_launch_instance<2, 2, true>(a, (unsigned)blocks, stream)
+  if (ktail && cbn == 2 && !d.res_dev) rc = wino_launch_instance<2, 2, false, true>(a, (unsigned)blocks, stream);
+  else if (ktail && cbn == 1 && lcbn == 1 && !d.res_dev) rc = wino_launch_instance<1, 1, false, true>(a, (unsigned)blocks, stream);
+  else if (cbn == 2) rc = d.res_dev ? wino_launch_instance<2, 2, true>(a, (unsigned)blocks, stream)
                                : wino_launch_instance<2, 2, false>(a, (unsigned)blocks, stream);
   else if (lcbn == 2) rc = d.res_dev ? wino_launch_instance<1, 2, true>(a, (unsigned)blocks, stream)
                                      : wino_launch_instance<1, 2, false>(a, (unsigned)blocks, stream);

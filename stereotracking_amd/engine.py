@@ -192,11 +192,13 @@ class HipDetector:
         return d
 
     def decode_nms(self, head_out, score_thr=0.01, iou_thr=0.5, max_det=1000, ori_shape=None,
-                   scale_factor=(1.0, 1.0), pad_param=None, nms_mask_rows=0):
+                   scale_factor=(1.0, 1.0), pad_param=None, nms_mask_rows=0, out=None):
         """-> boxes (N,max_det,4), scores (N,max_det), labels (N,max_det) int64,
         prior_idx (N,max_det) int32, counts (N,) int32 — all on device, no host sync.  counts[n] is the
         TRUE number kept; counts[n] > max_det means the buffer overflowed (the reference applies no cap
-        under yolox_style=True) and the caller must raise or re-run with a larger max_det."""
+        under yolox_style=True) and the caller must raise or re-run with a larger max_det.  Rows past the count are
+        written by the kernel (zero, prior index -1).  `out`: the five tensors to write into (persistent buffers of a
+        pipeline context: no allocation, no clearing launch); default: fresh tensors."""
         _require_cuda(head_out, 'head_out')
         ori_shape = ori_shape or (self.height, self.width)
         d = self.decode_desc(score_thr, iou_thr, max_det, ori_shape, scale_factor, pad_param, nms_mask_rows)
@@ -207,15 +209,21 @@ class HipDetector:
         if self._dec_ws is None or self._dec_ws.numel() < nbytes or self._dec_ws.device != dev:
             self._dec_ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
         N = self.batch
-        boxes = torch.zeros(N, max_det, 4, dtype=torch.float32, device=dev)
-        scores = torch.zeros(N, max_det, dtype=torch.float32, device=dev)
-        labels = torch.zeros(N, max_det, dtype=torch.int64, device=dev)
-        prior = torch.full((N, max_det), -1, dtype=torch.int32, device=dev)
-        counts = torch.zeros(N, dtype=torch.int32, device=dev)
+        if out is None:
+            out = self.decode_buffers(max_det, dev)
+        boxes, scores, labels, prior, counts = out
         check(self.lib.st_decode_nms(C.byref(d), ptr(head_out), ptr(self._dec_ws), self._dec_ws.numel(),
                                      current_stream(), ptr(boxes), ptr(scores), ptr(labels), ptr(prior),
                                      ptr(counts)), 'st_decode_nms')
         return boxes, scores, labels, prior, counts
+
+    def decode_buffers(self, max_det, dev):
+        N = self.batch
+        return (torch.empty(N, max_det, 4, dtype=torch.float32, device=dev),
+                torch.empty(N, max_det, dtype=torch.float32, device=dev),
+                torch.empty(N, max_det, dtype=torch.int64, device=dev),
+                torch.empty(N, max_det, dtype=torch.int32, device=dev),
+                torch.empty(N, dtype=torch.int32, device=dev))
 
 
 def state_dict_from_table(table, tensors):

@@ -112,9 +112,11 @@ class StereoDensePipeline:
             b['head'] = torch.empty(self.det.head_floats, **f32)
             b['disp_lr'] = torch.empty(N, H // self.feat_stride, W // self.feat_stride, **f32)
             b['disp_postp'] = torch.empty(N, 3, H, W, **f32)
-            b['depth'] = torch.zeros(N, M, **f32)       # rows past the count are written as 0 by st_box_depth
-            b['scales'] = torch.zeros(N, M, **f32)
-            b['scaled_boxes'] = torch.zeros(N, M, 4, **f32)
+            b['depth'] = torch.empty(N, M, **f32)       # rows past the count are written as 0 by st_box_depth
+            b['scales'] = torch.empty(N, M, **f32)
+            b['scaled_boxes'] = torch.empty(N, M, 4, **f32)
+            b['decode'] = self.det.decode_buffers(M, dev)   # persistent: st_decode_nms defines every row itself
+            b['overflow'] = torch.empty(N, dtype=torch.bool, device=dev)
             self._bufs = b
         return self._bufs
 
@@ -138,7 +140,7 @@ class StereoDensePipeline:
 
     def run(self, img, right=None, disp_postp=None):
         """img (N,3,H,W) fp32 CUDA; stereo: right (N,3,H,W); mono: disp_postp (N,3,H,W).
-        Returns a dict of device tensors (no host sync): boxes (N,M,4) unscaled xyxy, scores, labels,
+        Returns a dict of device tensors (no host sync; the context's PERSISTENT buffers, overwritten by its next run): boxes (N,M,4) unscaled xyxy, scores, labels,
         prior_idx, counts (TRUE number kept per frame), overflow (N,) bool = counts > M, depth, scales,
         scaled_boxes, disp_postp, head.  Rows past min(counts, M) are zero (prior_idx -1)."""
         _require_cuda(img, 'img')
@@ -153,10 +155,11 @@ class StereoDensePipeline:
                 raise ValueError('mono pipeline needs disp_postp')
             self.det.forward(img, disp_postp, b['head'])
         boxes, scores, labels, prior, counts = self.det.decode_nms(
-            b['head'], self.score_thr, self.iou_thr, self.max_det, (self.ori_h, self.ori_w))
+            b['head'], self.score_thr, self.iou_thr, self.max_det, (self.ori_h, self.ori_w), out=b['decode'])
         depth, scales, sboxes = self.box_depth(disp_postp, boxes, counts)
+        torch.gt(counts, self.max_det, out=b['overflow'])
         return dict(boxes=boxes, scores=scores, labels=labels, prior_idx=prior, counts=counts,
-                    overflow=counts > self.max_det, depth=depth, scales=scales, scaled_boxes=sboxes,
+                    overflow=b['overflow'], depth=depth, scales=scales, scaled_boxes=sboxes,
                     disp_postp=disp_postp, head=b['head'])
 
     @staticmethod
@@ -167,20 +170,14 @@ class StereoDensePipeline:
         scaled='both': 13 columns, the unscaled box first, then the scaled box and the kept prior index appended -
         what the MOT shell copies to the host in ONE transfer per batch).  A fresh tensor: safe to keep after the context's buffers are reused.
         Frames >= n_real are batch padding."""
-        boxes = out['scaled_boxes'] if scaled is True else out['boxes']
-        cols = [boxes, out['scores'][..., None], out['labels'][..., None].float(), out['depth'][..., None],
-                out['scales'][..., None]]
-        if scaled == 'both':
-            cols += [out['scaled_boxes'], out['prior_idx'][..., None].float()]   # prior index < 2^24: exact in fp32
-        rows = torch.cat(cols, dim=-1)
-        N, M = rows.shape[0], rows.shape[1]
-        head = rows.new_zeros(N, 1, rows.shape[2])
-        head[:, 0, 0] = out['counts'].float()
-        head[:, 0, 1] = float(M)
-        head[:, 0, 2] = 1.0
-        if n_real is not None and n_real < N:
-            head[n_real:] = 0.0
-        return torch.cat([head, rows], dim=1)
+        mode = 2 if scaled == 'both' else (1 if scaled is True else 0)
+        N, M = out['boxes'].shape[0], out['boxes'].shape[1]
+        rec = torch.empty(N, M + 1, 13 if mode == 2 else 8, dtype=torch.float32, device=out['boxes'].device)
+        check(_lib.load().st_pack_records(ptr(out['boxes']), ptr(out['scores']), ptr(out['labels']), ptr(out['depth']),
+                                          ptr(out['scales']), ptr(out['scaled_boxes']), ptr(out['prior_idx']),
+                                          ptr(out['counts']), N, M, mode, N if n_real is None else int(n_real),
+                                          ptr(rec), current_stream()), 'st_pack_records')
+        return rec
 
 
 class InflightPipelines:
