@@ -471,13 +471,18 @@ def main():
     # every rank gets its own 8 pairs (weak scaling: frames shard across ranks)
     batch_cpu = synthetic_batch([rank * B + i for i in range(B)], 720, 1280, args.max_disp)
     img, right = batch_cpu['img'].to(dev), batch_cpu['right'].to(dev)
+    from stereotracking_amd.dist import DetectionGatherer
     gathered = [torch.empty(world * B, pipe.max_det + 1, 8, device=cdev) for _ in runner.pipes] if world > 1 else None
+    # ONE communication stream for every all-gather of this rank: collectives are issued in host program order (step
+    # i on every rank), behind an event of the producing context's stream - never from inside a context stream
+    gatherer = DetectionGatherer(dev)
 
     def post(out, ctx):   # runs under the context's stream
         dets = pipe.pack_detections(out)   # self-describing frame records: header row (true count) + max_det rows
         if world > 1:  # ONE collective per shard of frames: the fixed-size records (8 x 32 KB / rank)
-            dist.all_gather_into_tensor(gathered[ctx], dets if backend == 'nccl' else dets.cpu())
-        out['records'] = gathered[ctx] if world > 1 else dets
+            out['records'], out['records_ready'] = gatherer.gather(dets, gathered[ctx])
+        else:
+            out['records'] = dets
         return out
 
     def step():

@@ -76,7 +76,9 @@ typedef struct StConvDesc {
   float post_scale;
   int act; /* 0 = identity, 1 = SiLU */
   /* optional: the same weights in Winograd F(2x2,3x3) form (st_wino_pack_weights of wgt, fragment order); enables
-   * kernel instance 43 for 3x3 / stride-1 layers with Cin % 32 == 0 and Cout % 64 == 0.  NULL = not available. */
+   * kernel instances 43 / 44 for 3x3 / stride-1 / pad-1 layers with Cin % 4 == 0 (>= 16; a Cin that is not a multiple
+   * of 32 runs a short last K-chunk) and Cout a multiple of 32 or 33..64 (one zero-padded block of 64).  NULL = not
+   * available. */
   const float* wgt_wino_dev;
 } StConvDesc;
 
@@ -96,9 +98,6 @@ int st_conv2d_nhwc_variant(const StConvDesc* d, st_stream_t stream, int variant)
 size_t st_wino_packed_floats(int Cout, int Cin);
 int st_wino_pack_weights(const float* packed_wgt_host, int Cout, int Cin, float* out_host);
 
-/* Pack one Conv2d weight [Cout][Cin][KH][KW] (+ optional BN, folded in fp64)
- * into the kernel layout above.  Host function; out buffers are host memory
- * of st_conv_packed_floats(...) / roundup(Cout,32) floats. */
 /* Fused pair of 1x1 convolutions for the narrow high-resolution CSP layers: `b` (Cin = 32, Cout <= 32) consumes
  * output channels [0, 32) of `a` (Cin 32 or 64, 32 < Cout <= 64, no residual) - the CSPLayer main_conv ->
  * DarknetBottleneck conv1 pair (mmdet CSPLayer, built at csp_darknet_disparity_v1.py:113-153).  a's outputs are
@@ -116,6 +115,9 @@ size_t st_front_frag_floats(int Cout, int Cin);
 int st_front_pack_frags(const float* packed_wgt_host, int Cout, int Cin, float* out_host);
 int st_conv3x3s2_csp_front(const StConvDesc* a, const StConvDesc* ms, const StConvDesc* c1, const float* frag_ms_dev,
                            const float* frag_c1_dev, st_stream_t stream);
+/* Pack one Conv2d weight [Cout][Cin][KH][KW] (+ optional BN, folded in fp64)
+ * into the kernel layout above.  Host function; out buffers are host memory
+ * of st_conv_packed_floats(...) / roundup(Cout,32) floats. */
 size_t st_conv_packed_floats(int Cout, int Cin, int KH, int KW);
 int st_conv_pack_weights(const float* w, const float* conv_bias, /* may be NULL */
                          const float* bn_gamma, const float* bn_beta,
@@ -375,6 +377,14 @@ int st_tracker_destroy(StTracker* t);
 int st_tracker_reset(StTracker* t);
 int st_tracker_track(StTracker* t, int frame_id, const float* dets, int n, float* out_rows,
                      int64_t* out_ids, int cap, int* out_n);
+/* The same over a CHUNK of frame records (st_pack_records mode 2: (F, rows_per_frame, cols >= 12) fp32 in host memory,
+ * e.g. the page-locked buffer the chunk's ONE device->host copy landed in): for every valid frame f the detections
+ * (depth-scaled box, score, label, depth, scale) feed st_tracker_track with frame_ids[f]; out_rows (F, cap, 8) /
+ * out_ids (F, cap) receive pred_track_instances with the box UNSCALED again (scale_bbox(b, 1 / scale), reference
+ * mmtrack/models/mot/ocsort_disparity.py:88-97); out_counts[f] = rows written, -1 for batch-padding frames.  A frame
+ * whose record says count > capacity returns ST_ERR_WORKSPACE (the DetectionOverflow of the Python side). */
+int st_tracker_track_records(StTracker* t, const int* frame_ids, const float* records, int F, int rows_per_frame,
+                             int cols, float* out_rows, int64_t* out_ids, int cap, int* out_counts);
 /* state inspection (tests, checkpointing): live tracks in creation order */
 int st_tracker_num_tracks(const StTracker* t);
 long long st_tracker_next_id(const StTracker* t);

@@ -113,6 +113,7 @@ _PROTOS = {
     'st_tracker_destroy': (_i, [_vp]),
     'st_tracker_reset': (_i, [_vp]),
     'st_tracker_track': (_i, [_vp, _i, _vp, _i, _vp, _vp, _i, C.POINTER(_i)]),
+    'st_tracker_track_records': (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _i, _vp]),
     'st_tracker_num_tracks': (_i, [_vp]),
     'st_tracker_next_id': (C.c_longlong, [_vp]),
     'st_tracker_get_track': (_i, [_vp, _i, _vp, _vp, _vp, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i)]),

@@ -58,8 +58,6 @@ struct FrontArgs {
   int ntiles;              // N * Ho * tiles_x
   int slots_per_xcd;       // wave slots (workgroups x 8) of one XCD; gridDim.x is a multiple of 8
   unsigned in_bytes, wgt_bytes, main_bytes, short_bytes, tmp_bytes;
-  int abl;   // tools-only (ST_ABLATION) timing experiments, wrong results: 1 no pixel loads, 4 no chained GEMMs,
-             // 16 no stores, 32 no LDS weight reads
 };
 
 __device__ __forceinline__ float ff_silu(float v) { return v * __builtin_amdgcn_rcpf(1.0f + __expf(-v)); }
@@ -186,12 +184,6 @@ __global__ __launch_bounds__(FF_THREADS, 1) void front_s2_csp_kernel(const Front
 #pragma unroll
     for (int k = 0; k < 18; ++k) {
       const int tap = k >> 1, g = k & 1;
-#ifdef ST_ABLATION
-      if (p.abl & 32) {
-#pragma unroll
-        for (int cb = 0; cb < 4; ++cb) wf[(k + 1) & 1][cb] = wf[k & 1][cb] + f32x4{1.f, 1.f, 1.f, 1.f};
-      } else
-#endif
       if (k + 1 < 18) {
 #pragma unroll
         for (int cb = 0; cb < 4; ++cb)
@@ -204,22 +196,10 @@ __global__ __launch_bounds__(FF_THREADS, 1) void front_s2_csp_kernel(const Front
 #pragma unroll
         for (int cb = 0; cb < 4; ++cb)
           acc[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[k & 1][cb][s], xf[s], acc[cb], 0, 0, 0);
-#ifdef ST_ABLATION
-      if (!(p.abl & 1))
-#endif
       X[k] = xload(tap, g);   // the next tile's fragment, a whole tile of MFMAs ahead of its use
       __builtin_amdgcn_sched_barrier(0);
     }
 
-#ifdef ST_ABLATION
-    if (p.abl & 4) {
-      float v = 0.f;
-#pragma unroll
-      for (int cb = 0; cb < 4; ++cb) v += acc[cb][0] + acc[cb][1] + acc[cb][2] + acc[cb][3];
-      if (v == 12345.678f) p.out_main[tid] = v;
-      continue;
-    }
-#endif
     // ---- stage A epilogue in registers: lane holds couts cb*16 + 4kq + e of its pixel = the B operand of the 1x1 GEMM
     f32x4 va[4];
 #pragma unroll
@@ -248,11 +228,7 @@ __global__ __launch_bounds__(FF_THREADS, 1) void front_s2_csp_kernel(const Front
 #pragma unroll
       for (int e = 0; e < 4; ++e) vm[c2][e] = ff_silu(am[c2][e]);
     }
-#ifdef ST_ABLATION
-    const bool no_store = p.abl & 16;
-#else
     constexpr bool no_store = false;
-#endif
     // stores: 16 bytes per (pixel, 4 couts); range-checked descriptors, no branches
     if (!no_store) {
 #pragma unroll
@@ -357,10 +333,6 @@ int front_fused_launch(const StConvDesc& da, const StConvDesc& dms, const StConv
   a.main_bytes = (unsigned)(Mo * dms.out1_ld * 4);
   a.short_bytes = (unsigned)(Mo * dms.out2_ld * 4);
   a.tmp_bytes = (unsigned)(Mo * dc1.out1_ld * 4);
-  a.abl = 0;
-#ifdef ST_ABLATION
-  if (const char* e = getenv("ST_FF_ABL")) a.abl = atoi(e);
-#endif
   // one persistent workgroup per CU (a multiple of 8 so that every XCD gets the same number), fewer for small inputs
   static int cus = 0;
   if (cus == 0) {

@@ -411,6 +411,51 @@ extern "C" int st_tracker_track(StTracker* t, int frame_id, const float* dets, i
   return t->track(frame_id, dets, n, out_rows, out_ids, cap, out_n);
 }
 
+extern "C" int st_tracker_track_records(StTracker* t, const int* frame_ids, const float* records, int F,
+                                        int rows_per_frame, int cols, float* out_rows, int64_t* out_ids, int cap,
+                                        int* out_counts) {
+  using namespace st;
+  if (!t || !frame_ids || !records || !out_counts)
+    return set_error(ST_ERR_INVALID, "st_tracker_track_records: null argument");
+  ST_REQUIRE(F >= 0 && rows_per_frame >= 1 && cols >= 12 && cap >= 0 && (cap == 0 || (out_rows && out_ids)),
+             "st_tracker_track_records: bad buffers (cols %d: the records must carry the scaled box, mode 2)", cols);
+  std::vector<float> dets;
+  for (int f = 0; f < F; ++f) {
+    const float* rec = records + (size_t)f * rows_per_frame * cols;
+    if (rec[2] == 0.0f) {   // batch padding: not a frame
+      out_counts[f] = -1;
+      continue;
+    }
+    const int k = (int)rec[0], capacity = (int)rec[1];
+    ST_REQUIRE(capacity == rows_per_frame - 1, "st_tracker_track_records: frame %d: record capacity %d != %d rows", f,
+               capacity, rows_per_frame - 1);
+    if (k > capacity)
+      return set_error(ST_ERR_WORKSPACE, "frame %d: %d detections kept but the detection buffer has %d rows",
+                       frame_ids[f], k, capacity);
+    dets.resize((size_t)k * 8);
+    for (int i = 0; i < k; ++i) {
+      const float* r = rec + (size_t)(1 + i) * cols;
+      float* d = dets.data() + (size_t)i * 8;
+      d[0] = r[8]; d[1] = r[9]; d[2] = r[10]; d[3] = r[11];   // the depth-SCALED box (ocsort_disparity.py:82-86)
+      d[4] = r[4]; d[5] = r[5]; d[6] = r[6]; d[7] = r[7];
+    }
+    float* o = out_rows + (size_t)f * cap * 8;
+    int n = 0;
+    ST_CHECK(t->track(frame_ids[f], dets.data(), k, o, out_ids + (size_t)f * cap, cap, &n));
+    // scale_bbox(track_bboxes, 1 / scales) (ocsort_disparity.py:95-97, trackers/utils.py:58-73) as the same fp32
+    // single operations torch evaluates (this file is built with -ffp-contract=off)
+    for (int i = 0; i < n; ++i) {
+      float* r = o + (size_t)i * 8;
+      const float inv = 1.0f / r[7];
+      const float cx = (r[0] + r[2]) / 2.0f, cy = (r[1] + r[3]) / 2.0f;
+      const float w = (r[2] - r[0]) * inv, h = (r[3] - r[1]) * inv;
+      r[0] = cx - w / 2.0f; r[1] = cy - h / 2.0f; r[2] = cx + w / 2.0f; r[3] = cy + h / 2.0f;
+    }
+    out_counts[f] = n;
+  }
+  return ST_OK;
+}
+
 extern "C" int st_tracker_num_tracks(const StTracker* t) { return t ? (int)t->tracks.size() : 0; }
 extern "C" long long st_tracker_next_id(const StTracker* t) { return t ? t->num_tracks : 0; }
 

@@ -59,7 +59,6 @@ struct WinoArgs {
   int tbx, tby, ncb, nkc;
   int g_last;   // channel groups of 8 that exist in the LAST K-chunk (4 unless Cin % 32 != 0)
   unsigned in_bytes, out_bytes, res_bytes, wino_bytes;
-  int abl;   // tools-only (ST_ABLATION): 1 = weight fragments loaded once, 2 = window DMA once, 3 = both (wrong results)
 };
 
 __device__ __forceinline__ float wn_silu(float v) { return v * __builtin_amdgcn_rcpf(1.0f + __expf(-v)); }
@@ -191,9 +190,6 @@ __global__ __launch_bounds__(256, 2) void wino_conv3x3_kernel(const WinoArgs p) 
                                     lane * 4) * 4u;
   const int last_step = p.nkc * 16 - 1;
   auto load_frag = [&](int step, f32x4 (&f)[CBN]) {   // step = (kc * 4 + g) * 4 + b; the prefetch past the last step
-#ifdef ST_ABLATION                                     // re-reads the last one (never used)
-    if ((p.abl & 1) && step > 1) return;
-#endif
     // the step displacement is wave-uniform: it rides in the scalar offset, no vector add per load
     const int soff = (step < last_step ? step : last_step) * (WN_FRAG_FLOATS * 4);
 #pragma unroll
@@ -217,11 +213,7 @@ __global__ __launch_bounds__(256, 2) void wino_conv3x3_kernel(const WinoArgs p) 
 
   for (int kc = 0; kc < p.nkc; ++kc) {
     const int buf = kc & 1;
-#ifdef ST_ABLATION
-    if (kc + 1 < p.nkc && !(p.abl & 2)) dma_window(kc + 1, buf ^ 1);
-#else
     if (kc + 1 < p.nkc) dma_window(kc + 1, buf ^ 1);   // lands during this chunk's 128 MFMAs
-#endif
     const float* win = smem + buf * WN_WIN_FLOATS;
     const int gn = (KTAIL && kc == p.nkc - 1) ? p.g_last : 4;   // wave-uniform
 #pragma unroll
@@ -229,12 +221,6 @@ __global__ __launch_bounds__(256, 2) void wino_conv3x3_kernel(const WinoArgs p) 
       if (KTAIL && g >= gn) continue;
       // raw patch -> V[a][0..3] for this lane's 4 channels (8g + 4h .. + 3)
       f32x4 d[8];
-#ifdef ST_ABLATION
-      if (p.abl & 8) {
-#pragma unroll
-        for (int k = 0; k < 8; ++k) d[k] = f32x4{1.f, 2.f, 3.f, (float)(k + g)};
-      } else
-#endif
 #pragma unroll
       for (int k = 0; k < 8; ++k)
         d[k] = *reinterpret_cast<const f32x4*>(win + qoff[k] + (((2 * g + h) ^ qsw[k]) << 2));
@@ -261,19 +247,6 @@ __global__ __launch_bounds__(256, 2) void wino_conv3x3_kernel(const WinoArgs p) 
     __syncthreads();
   }
 
-#ifdef ST_ABLATION
-  if (p.abl & 4) {   // no epilogue: one store per lane keeps the accumulators alive
-    float v = 0.f;
-#pragma unroll
-    for (int b = 0; b < 4; ++b)
-#pragma unroll
-      for (int nb = 0; nb < CBN; ++nb)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) v += acc[b][nb][r];
-    if (v == 12345.678f) p.out[tid] = v;
-    return;
-  }
-#endif
   // ---- output transform.  Row reduction over b in registers: R[0] = M0 + M1 + M2, R[1] = M1 - M2 - M3
   float* Rb = smem;   // [a][j][tile][co]: every wave is past its last window read (barrier above)
   // The packed adds below are written as instructions, which the compiler's hazard recogniser does not see as VALU
@@ -443,10 +416,6 @@ int wino_conv_launch(const StConvDesc& d, hipStream_t stream, bool narrow) {
   a.wino_bytes = (unsigned)(wino_packed_floats(d.Cout, d.Cin) * 4);
   a.g_last = 4 - (a.nkc * 32 - d.Cin) / 8;          // whole groups of 8 padded channels are skipped
   const bool ktail = a.g_last < 4;
-  a.abl = 0;
-#ifdef ST_ABLATION
-  if (const char* e = getenv("ST_WN_ABL")) a.abl = atoi(e);
-#endif
   const long long blocks = (long long)d.N * a.tbx * a.tby * a.ncb;
   ST_REQUIRE(blocks < (1ll << 31), "winograd conv: grid too large");
   int rc;

@@ -55,6 +55,54 @@ def gather_detections(local, counts=None):
     return out, cout
 
 
+class DetectionGatherer:
+    """Every detection all-gather of a process goes through ONE object and ONE communication stream.
+
+    The pipeline contexts run on HIP streams of their own and finish in data-dependent order, but a collective must be
+    issued in the SAME order on every rank.  The order here is structural: `gather()` is called from the host in
+    program order (step i of every rank, whatever context it ran on), the collective is enqueued on the single
+    communication stream behind an event recorded on the producing stream, and a sequence number is kept so that
+    tests can assert that all ranks issued the same number of collectives.  RCCL then sees one in-order queue per
+    rank, independent of how the contexts interleave on the device.  Payload: the fixed-size frame records
+    ((max_det + 1) x 8 fp32 per frame, 256 KB per 8-frame shard) - latency-bound over xGMI, so one collective per
+    shard, never per frame.  'gloo' (CPU rehearsal) gathers through host memory."""
+
+    def __init__(self, device=None):
+        self.device = torch.device(device) if device is not None else None
+        self.stream = None
+        self.seq = 0
+        _, self.world = world()
+        self.on_device = self.world > 1 and dist.get_backend() == 'nccl'
+
+    def gather(self, records, out=None):
+        """records: this rank's (F, M + 1, C) frame records, produced on the CURRENT stream.
+        -> (gathered (world * F, M + 1, C), event or None).  world 1: (records, None)."""
+        self.seq += 1
+        if self.world == 1:
+            return records, None
+        if not self.on_device:                 # gloo rehearsal: host memory, synchronous
+            host = records.cpu()
+            if out is None:
+                out = torch.empty((self.world * host.shape[0],) + tuple(host.shape[1:]), dtype=host.dtype)
+            dist.all_gather_into_tensor(out, host.contiguous())
+            return out, None
+        dev = records.device
+        if self.stream is None:
+            self.stream = torch.cuda.Stream(device=dev)
+        if out is None:
+            out = torch.empty((self.world * records.shape[0],) + tuple(records.shape[1:]), dtype=records.dtype,
+                              device=dev)
+        ready = torch.cuda.Event()
+        ready.record(torch.cuda.current_stream(dev))
+        self.stream.wait_event(ready)
+        records.record_stream(self.stream)
+        with torch.cuda.stream(self.stream):
+            dist.all_gather_into_tensor(out, records.contiguous())
+            done = torch.cuda.Event()
+            done.record(self.stream)
+        return out, done
+
+
 class DetectionOverflow(RuntimeError):
     """A frame kept more boxes than the fixed-size detection buffer holds.  The reference applies no cap
     (yolox_style=True), so dropping the surplus would change the tracker's input: fail loudly instead."""

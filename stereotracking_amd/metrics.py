@@ -146,8 +146,41 @@ class MOTDroneMetrics:
                 for t in rows:
                     f.write('%d,%d,%d,%d,%d,%d,%d,%d,%.5f\n' % tuple(t[:9]))
 
-    def evaluate(self):
-        """Per-video and combined (count-summed, like TrackEval's COMBINED_SEQ) scores."""
+    def gather(self):
+        """Multi-rank evaluation, the reference's way (mot_drone_metrics.py:336-358: barrier, all_gather_object of the
+        per-video `seq_info`, rank 0 evaluates, broadcast_object_list of the result): ranks hold DISJOINT whole videos
+        (video_sampler.py:62-70 / dist.shard_videos), so the per-video row lists are merged by key.  Afterwards every
+        rank holds every video's rows.  No-op without an initialised process group."""
+        import torch.distributed as dist
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+            return self
+        dist.barrier()                                   # wait for all processes to complete prediction (:336)
+        parts = [None] * dist.get_world_size()
+        dist.all_gather_object(parts, dict(pred=dict(self.pred), gt=dict(self.gt)))   # KBs of pickled rows (:340)
+        pred, gt = defaultdict(list), defaultdict(list)
+        for part in parts:                               # rank order = video order of shard_videos
+            for v, rows in part['pred'].items():
+                if v in pred:
+                    raise RuntimeError(f'video {v!r} was evaluated on more than one rank: videos shard whole')
+                pred[v] = rows
+            for v, rows in part['gt'].items():
+                gt[v] = rows
+        self.pred, self.gt = pred, gt
+        return self
+
+    def evaluate(self, distributed=True):
+        """Per-video and combined (count-summed, like TrackEval's COMBINED_SEQ) scores.  With a process group (and
+        `distributed`): gather first, rank 0 computes, every rank returns the broadcast result (:344-358)."""
+        import torch.distributed as dist
+        multi = distributed and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+        if multi:
+            self.gather()
+            box = [self._evaluate_local() if dist.get_rank() == 0 else None]
+            dist.broadcast_object_list(box, src=0)
+            return box[0]
+        return self._evaluate_local()
+
+    def _evaluate_local(self):
         per_video = {v: clear_identity(self.gt.get(v, []), self.pred.get(v, []), self.iou_thr)
                      for v in sorted(set(self.gt) | set(self.pred))}
         tot = defaultdict(float)

@@ -148,6 +148,51 @@ def pack_raw_inputs(img_u8=None, disp_u16=None, pad_size_divisor=32, img_pad=114
     return out
 
 
+CSV_HEADER = ['frame', 'id', 'label', 'tl_x', 'tl_y', 'br_x', 'br_y', 'depth', 'gt_depth', 'score']
+
+
+def append_prediction_results(file_path, results):
+    """The CSV side effect of the reference's predict (mmtrack/utils/collect_results.py:1-44: one row per track,
+    `frame,id,label,tl_x,tl_y,br_x,br_y,depth,gt_depth,score`, header written when the file is empty), for EVERY
+    sample of a batched call (the reference handles results[0] because it never batches)."""
+    import csv
+    import os
+    if not file_path.endswith('.csv'):
+        raise ValueError('The saving format is not supported.')
+    with open(file_path, 'a') as f:
+        writer = csv.writer(f)
+        f.seek(0, os.SEEK_END)
+        if f.tell() == 0:
+            writer.writerow(CSV_HEADER)
+        for sample in results:
+            trk = sample.pred_track_instances
+            frame_id = sample.metainfo.get('frame_id')
+            boxes = trk.get('bboxes').cpu().numpy()
+            ids = trk.get('instances_id').cpu().numpy()
+            labels = trk.get('labels').cpu().numpy()
+            scores = trk.get('scores').cpu().numpy()
+            depth, gt_depth = trk.get('depth'), trk.get('gt_depth')
+            for iid, label, box, d, gd, sc in zip(ids, labels, boxes, depth, gt_depth, scores):
+                writer.writerow([frame_id, iid, label, *box, d, gd, sc])
+
+
+def save_prediction_results(file_path):
+    """Decorator form, as the reference applies it to OCSORT_Disparity.predict (collect_results.py:1-44): an existing
+    file is deleted when the decorator is applied."""
+    import os
+
+    def decorator(predict_func):
+        if os.path.exists(file_path):
+            os.remove(file_path)
+
+        def wrapper(*args, **kwargs):
+            results = predict_func(*args, **kwargs)
+            append_prediction_results(file_path, results)
+            return results
+        return wrapper
+    return decorator
+
+
 def scale_bbox(bboxes, scales):
     """Scale boxes about their centres (reference mmtrack/models/trackers/utils.py:58-73)."""
     cx, cy = (bboxes[:, 0] + bboxes[:, 2]) / 2, (bboxes[:, 1] + bboxes[:, 3]) / 2
@@ -171,7 +216,7 @@ class OCSORT_Disparity(nn.Module):
 
     def __init__(self, detector=None, tracker=None, motion=None, data_preprocessor=None, init_cfg=None,
                  baseline=0.25, focal_length=640, stereo=None, dense_batch=8, inflight=3, max_det=1000,
-                 results_device='cpu', autotune=True, tuning_cache=None):
+                 results_device='cpu', autotune=True, tuning_cache=None, results_csv=None):
         super().__init__()
         self.data_preprocessor = MODELS.build(data_preprocessor) if data_preprocessor is not None else None
         self.detector = MODELS.build(detector) if detector is not None else None
@@ -186,6 +231,13 @@ class OCSORT_Disparity(nn.Module):
             raise ValueError("results_device must be 'cpu' or 'input'")
         self.results_device = results_device
         self.autotune, self.tuning_cache = bool(autotune), tuning_cache
+        # the reference decorates predict with save_prediction_results('results.csv') unconditionally
+        # (ocsort_disparity.py:49); here the side effect is opt-in: results_csv='results.csv' reproduces it
+        self.results_csv = results_csv
+        if results_csv is not None:
+            import os
+            if os.path.exists(results_csv):
+                os.remove(results_csv)
         self.lib = _lib.load()
         self._dense = {}          # (batch, ori_h, ori_w, stereo) -> [InflightPipelines, weights version]
         self._staging = {}        # name -> pinned host buffer (grow-only): no pinned allocation on the per-chunk path
@@ -390,7 +442,32 @@ class OCSORT_Disparity(nn.Module):
             s, e = job['s'], job['e']
             tracks_of = []
             t0 = time.perf_counter()
-            for n in range(s, e):
+            if getattr(self.tracker, 'backend', None) == 'native' and not kwargs:
+                # the whole chunk in ONE native call (st_tracker_track_records reads the page-locked record buffer the
+                # D2H copy landed in: detections in, unscaled track rows out); per frame only views are taken
+                fids = [int(data_samples[n].metainfo.get('frame_id', -1)) for n in range(s, e)]
+                chunk = rec[:e - s].clone()            # the staging buffer is reused by a later chunk
+                trows, tids, tcnt = self.tracker.track_records(fids, chunk)
+                trows, tids = torch.from_numpy(trows), torch.from_numpy(tids)
+                det_labels, det_prior = chunk[:, 1:, 5].long(), chunk[:, 1:, 12].long()
+                trk_labels = trows[:, :, 5].long()
+                counts_h = chunk[:, 0, 0].long().tolist()
+                for i, n in enumerate(range(s, e)):
+                    k, m = counts_h[i], int(tcnt[i])
+                    rows, tr = chunk[i, 1:1 + k], trows[i, :m]
+                    data_samples[n].pred_det_instances = InstanceData(bboxes=rows[:, 0:4], scores=rows[:, 4],
+                                                                      labels=det_labels[i, :k],
+                                                                      prior_idx=det_prior[i, :k])   # (:107-108)
+                    tracks = InstanceData()
+                    tracks['bboxes'] = tr[:, 0:4]                     # already unscaled (:95-97)
+                    tracks['labels'] = trk_labels[i, :m]
+                    tracks['scores'] = tr[:, 4]
+                    tracks['scales'] = tr[:, 7]
+                    tracks['depth'] = tr[:, 6]
+                    tracks.instances_id = tids[i, :m]
+                    tracks_of.append(tracks)
+            else:
+              for n in range(s, e):
                 r = rec[n - s]
                 k, cap = int(r[0, 0]), int(r[0, 1])
                 if k > cap:
@@ -441,4 +518,6 @@ class OCSORT_Disparity(nn.Module):
         self.timings['tail_s'] += time.perf_counter() - t_tail0
         self.timings['frames'] += N
         self.timings['host_s'] += time.perf_counter() - t_host0
+        if self.results_csv is not None:
+            append_prediction_results(self.results_csv, outs)
         return outs

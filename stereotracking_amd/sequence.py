@@ -299,8 +299,39 @@ def run_sharded_sequence(pipe, frames, tracker, model, device):
     pad = per_rank - dets.shape[0]
     if pad:
         dets = torch.cat([dets, dets.new_zeros(pad, pipe.max_det + 1, 8)])
-    all_dets = sdist.gather_detections(dets)   # ONE collective: the records carry their own counts
+    # ONE collective (the records carry their own counts), on the process's communication stream
+    all_dets, done = sdist.DetectionGatherer(device).gather(dets)
+    if done is not None:
+        torch.cuda.current_stream(all_dets.device).wait_event(done)
     _, world = sdist.world()
     # drop the per-rank padding: rank r holds frames [r*chunk, r*chunk + chunk) in its first `chunk` slots
     idx = torch.cat([torch.arange(r * per_rank, r * per_rank + chunk) for r in range(world)])[:T]
     return track_gathered(all_dets[idx.to(all_dets.device)], None, T, tracker, model)
+
+
+def run_video_replicas(pipe, videos, make_tracker, model, device, metrics=None, gts=None):
+    """The reference's multi-GPU mode (mmtrack/datasets/samplers/video_sampler.py:25-70): WHOLE videos are dealt to
+    the ranks in contiguous blocks (dist.shard_videos = np.array_split over the video list), every rank runs its videos
+    sequentially with a fresh tracker per video and there is NO communication in the loop; only the evaluation gathers
+    (MOTDroneMetrics.evaluate -> all_gather_object, mot_drone_metrics.py:336-358).  `videos`: dict name -> list of
+    frame dicts (or HostSequence); `gts`: optional dict name -> per-frame lists of gt instance dicts.
+    -> (dict name -> per-frame track InstanceData for THIS rank's videos, scores dict or None)."""
+    names = sorted(videos)
+    mine = [names[i] for i in sdist.shard_videos(len(names))]
+    uploader = None
+    results = {}
+    for name in mine:
+        frames = videos[name]
+        one = pipe.pipes[0] if hasattr(pipe, 'submit') else pipe
+        if uploader is None:
+            uploader = RawFrameUploader(one.batch, (one.ori_h, one.ori_w), device, use_right=one.stereo)
+        dets, counts = detect_shard(pipe, frames, device, uploader=uploader)
+        tracks = track_gathered(dets, counts, len(frames), make_tracker(), model)   # frame_id 0 resets the tracker
+        results[name] = tracks
+        if metrics is not None:
+            for t, trk in enumerate(tracks):
+                sample = TrackDataSample(dict(frame_id=t))
+                sample.pred_track_instances = trk
+                metrics.process(name, sample, gts[name][t] if gts is not None else None)
+    scores = metrics.evaluate() if metrics is not None else None     # collective: every rank calls it
+    return results, scores

@@ -168,6 +168,30 @@ class OCSORTTracker_Disparity:
                             last_frame=lf.value))
         return out
 
+    def track_records(self, frame_ids, records):
+        """A CHUNK of frames in one native call (st_tracker_track_records): `records` = host float32 (F, M + 1, 13)
+        frame records (pipeline.pack_detections(scaled='both')), `frame_ids` = F ints.
+        -> (rows (F, M, 8) float32 [unscaled box, score, label, depth, scale], ids (F, M) int64, counts (F,) int32;
+        -1 = padding frame).  Native backend only."""
+        if self.backend != 'native':
+            raise RuntimeError("track_records needs backend='native'")
+        F, R, Cc = records.shape
+        rec = np.ascontiguousarray(records, dtype=np.float32) if isinstance(records, np.ndarray) else records.numpy()
+        fid = np.ascontiguousarray(frame_ids, dtype=np.int32)
+        rows = np.empty((F, R - 1, 8), np.float32)
+        ids = np.empty((F, R - 1), np.int64)
+        counts = np.empty(F, np.int32)
+        rc = _lib.load().st_tracker_track_records(self._handle(), fid.ctypes.data_as(C.c_void_p),
+                                                  rec.ctypes.data_as(C.c_void_p), F, R, Cc,
+                                                  rows.ctypes.data_as(C.c_void_p), ids.ctypes.data_as(C.c_void_p),
+                                                  R - 1, counts.ctypes.data_as(C.c_void_p))
+        if rc == -4:   # ST_ERR_WORKSPACE: a frame kept more boxes than the record holds
+            from .dist import DetectionOverflow
+            raise DetectionOverflow(_lib.load().st_last_error().decode() + '; build the model with a larger max_det')
+        _lib.check(rc, 'st_tracker_track_records')
+        self.num_tracks = int(_lib.load().st_tracker_next_id(self._native))
+        return rows, ids, counts
+
     def _track_native(self, data_sample):
         det = data_sample.pred_det_instances
         dev = det.bboxes.device

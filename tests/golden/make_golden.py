@@ -22,6 +22,9 @@ ships no fixtures of its own, so these vectors pin the oracle, not the reference
                        tracks).  Per frame: kept prior indices (in order), scores, boxes, depth, scales; per
                        tracker config: ids / boxes per frame.  The GPU test compares model.test_step against it, so
                        oracle/tracker.py never has to run on the GPU box.
+  shell_sequence.npz   the 6-frame 80x160 scenario of tests/test_shell_gpu.py (disparity given as input, tiny detector):
+                       oracle detector -> C decode+NMS -> numpy extract_depth -> ORACLE tracker; kept priors, track ids
+                       and unscaled track boxes per frame
 Nothing here is produced by product code (stereotracking_amd/ supplies only the seeded synthetic INPUTS).
 Run:  python tests/golden/make_golden.py [name ...]   (deterministic; CI checks the files are reproduced)."""
 import os
@@ -275,9 +278,49 @@ def config2_sequence():
     return out
 
 
+SHELL_TRACKER = dict(SHIPPED_TRACKER, init_track_thr=0.03, obj_score_thr=0.02)
+
+
+def shell_sequence():
+    """tests/test_shell_gpu.py::test_mot_shell_matches_oracle_composition's reference side, generated HERE so that
+    oracle/tracker.py never runs on the GPU box: 6 frames (pairs of identical frames) of 80x160 with the disparity as
+    an INPUT (the reference's own configuration), widen 0.375, confident synthetic head."""
+    torch.set_num_threads(1)
+    ora = OracleDetector(0.33, 0.375, 1).eval()
+    table = [(k, tuple(v.shape)) for k, v in ora.state_dict().items() if not k.endswith('num_batches_tracked')]
+    sd = synthetic_state_dict(table, seed=5, prior_prob=0.2, logit_std=2.5)
+    ora.load_state_dict(sd, strict=False)
+    ori = (80, 160)
+    levels, _ = levels_for(96, 160, 1)
+    out, dets = dict(num_frames=6), []
+    for t in range(6):
+        fr = synthetic_batch([40 + (t // 2)], ori[0], ori[1], 32)
+        # what the model sees: the preprocessor pads the un-padded uint8 frame with 0 (the dataset pipeline would
+        # have padded with 114 before; the test feeds un-padded frames)
+        img = torch.nn.functional.pad(fr['img'][0:1, :, :ori[0]].to(torch.uint8).float(), [0, 0, 0, 16])
+        disp = fr['disp_postp'][0:1]
+        with torch.no_grad():
+            rows = head_to_rows(*ora(dict(img=img, disp_postp=disp)))
+        flat = []
+        for r in rows:
+            buf = torch.zeros(1, r.shape[1], 8)
+            buf[..., :6] = r
+            flat.append(buf.reshape(-1))
+        b, sc, _, p, c = c_oracle.decode_nms(torch.cat(flat).numpy(), 1, levels, 0.01, 0.5, 1000, ori)
+        k = int(c[0])
+        d, scl, sb = odepth.bbox_postp_depth(torch.from_numpy(b[0, :k]), disp)
+        out[f'prior{t}'], out[f'boxes{t}'], out[f'scores{t}'] = p[0, :k], b[0, :k], sc[0, :k]
+        for i in range(k):
+            dets.append([t, *sb[i].tolist(), sc[0, i], float(d[i]), float(scl[i])])
+    tr = run_oracle_tracker(np.asarray(dets, np.float32), 6, **SHELL_TRACKER)
+    out['tracks'] = tr
+    assert len(tr) > 0
+    return out
+
+
 if __name__ == '__main__':
     c_oracle.build()
-    for name, fn in (('config2_sequence', config2_sequence), ('detector_tiny', detector_tiny), ('decode_nms', decode_nms), ('box_depth', box_depth),
+    for name, fn in (('shell_sequence', shell_sequence), ('config2_sequence', config2_sequence), ('detector_tiny', detector_tiny), ('decode_nms', decode_nms), ('box_depth', box_depth),
                      ('costvolume', costvolume), ('tracker_sequence', tracker_sequence), ('lapjv_ties', lapjv_ties)):
         if len(sys.argv) > 1 and name not in sys.argv[1:]:
             continue

@@ -1,6 +1,6 @@
 """Worker of tests/test_multirank_gpu.py: one rank of a world-2 'gloo' rehearsal of BASELINE configs[3] (frames of one
 sequence sharded over the ranks, ONE all-gather of the frame records, every rank tracks all frames).  Ranks share
-cuda:0 here (the GPU box has one card); the collective goes through host memory.  Each rank writes its result to <out_dir>/rank{r}_of{world}.json (argv[2])."""
+cuda:0 here (the GPU box has one card); under 'gloo' DetectionGatherer moves the records through host memory.  Each rank writes its result to <out_dir>/rank{r}_of{world}.json (argv[2])."""
 import json
 import os
 import sys
@@ -36,12 +36,6 @@ def main():
                                   match_iou_thr=0.1, num_tentatives=3, vel_consist_weight=0.2, vel_delta_t=3,
                                   num_frames_retain=30)
 
-    class _Gloo:   # the records are gathered through host memory under gloo
-        pass
-    import stereotracking_amd.dist as sdist
-    if world > 1:
-        orig = sdist.gather_detections
-        sdist.gather_detections = lambda local, counts=None: orig(local.cpu(), counts)
     res = run_sharded_sequence(runner, frames, trk, _Model(), dev)
     rec = dict(rank=rank, world=world, ids=[r.instances_id.tolist() for r in res], nboxes=[len(r) for r in res],
                box_sum=[float(r.bboxes.double().sum()) for r in res])

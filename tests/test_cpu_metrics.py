@@ -72,3 +72,90 @@ def test_drone_metrics_depth_filter_and_files(tmp_path):
     assert pred_lines[0] == '1,0,10.000,10.000,20.000,20.000,0.900,-1,-1,-1' and len(pred_lines) == 3
     gt_lines = open(os.path.join(tmp_path, 'gt', 'seq0.txt')).read().strip().split('\n')
     assert gt_lines[0] == '1,5,10,10,20,20,1,1,1.00000' and len(gt_lines) == 3
+
+
+# ---- multi-rank evaluation: whole videos per rank, gather only at the end (reference mot_drone_metrics.py:336-358) ----
+def _fill(metrics, video, seed):
+    """A small deterministic video: 3 objects, an id switch and a miss, so the scores are not trivial."""
+    rng = np.random.RandomState(seed)
+    for t in range(6):
+        boxes = torch.tensor([[10. + 3 * t, 10, 40 + 3 * t, 40], [200., 100 + 2 * t, 240, 140 + 2 * t],
+                              [400., 50, 430, 80]]) + float(rng.randint(0, 3))
+        ids = torch.tensor([0, 1, 2 if t < 3 else 7])          # object 2 changes its id at t = 3
+        keep = [0, 1, 2] if t != 4 else [0, 2]                 # object 1 missed at t = 4
+        s = TrackDataSample(dict(frame_id=t))
+        s.pred_track_instances = InstanceData(bboxes=boxes[keep], scores=torch.full((len(keep),), 0.9),
+                                              labels=torch.zeros(len(keep), dtype=torch.long),
+                                              depth=torch.full((len(keep),), 20.0), instances_id=ids[keep])
+        gt = [dict(instance_id=k, bbox=boxes[k].tolist(), location=[0, 0, 20.0]) for k in range(3)]
+        metrics.process(video, s, gt)
+
+
+def _metrics_worker(rank, world, port, q):
+    import torch.distributed as dist
+    from stereotracking_amd import dist as sdist
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    names = [f'seq{i}' for i in range(5)]
+    m = MOTDroneMetrics(depth_thr=80)
+    for i in sdist.shard_videos(len(names)):         # this rank's contiguous block of whole videos
+        _fill(m, names[i], seed=i)
+    res = m.evaluate()                                # barrier + all_gather_object + rank-0 evaluate + broadcast
+    q.put((rank, res['combined'], sorted(res['per_video']), sorted(m.pred)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_metrics_gather_world2_gloo_equals_single_process():
+    import multiprocessing as mp
+    import socket
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_metrics_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    ref = MOTDroneMetrics(depth_thr=80)
+    for i in range(5):
+        _fill(ref, f'seq{i}', seed=i)
+    want = ref.evaluate()
+    assert want['combined']['IDSW'] == 5 and want['combined']['FN'] == 5       # one of each per video
+    for rank, combined, videos, held in got:
+        assert combined == want['combined']                    # ONE set of scores, identical on every rank
+        assert videos == sorted(want['per_video']) and held == videos   # after the gather every rank holds all rows
+
+
+def test_prediction_results_csv_side_effect(tmp_path):
+    """reference mmtrack/utils/collect_results.py:1-44: header once, one row per track, file removed on decoration."""
+    from stereotracking_amd.mot import CSV_HEADER, append_prediction_results, save_prediction_results
+    path = str(tmp_path / 'results.csv')
+    open(path, 'w').write('stale')
+
+    def sample(t):
+        s = TrackDataSample(dict(frame_id=t))
+        s.pred_track_instances = InstanceData(bboxes=torch.tensor([[1., 2, 3, 4], [5., 6, 7, 8]]),
+                                              scores=torch.tensor([0.5, 0.25]), labels=torch.zeros(2, dtype=torch.long),
+                                              depth=torch.tensor([10.0, -1.0]), gt_depth=torch.tensor([10.0, -1.0]),
+                                              instances_id=torch.tensor([3, 4]))
+        return s
+
+    @save_prediction_results(path)
+    def predict(n0, n):
+        return [sample(t) for t in range(n0, n0 + n)]
+
+    assert not os.path.exists(path)                   # deleted when the decorator was applied
+    predict(0, 2)
+    predict(2, 1)
+    lines = open(path).read().strip().split('\n')
+    assert lines[0].split(',') == CSV_HEADER and len(lines) == 1 + 3 * 2
+    assert lines[1].split(',')[:7] == ['0', '3', '0', '1.0', '2.0', '3.0', '4.0']
+    assert lines[-1].split(',')[0] == '2'
+    import pytest
+    with pytest.raises(ValueError):
+        append_prediction_results(str(tmp_path / 'x.txt'), [])

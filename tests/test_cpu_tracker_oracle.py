@@ -204,3 +204,57 @@ def test_empty_and_first_frame_semantics():
     assert ref[ref[:, 0] == 0][:, 1].tolist() == [0.0]                  # only the 0.9 box starts a track
     assert len(ref[ref[:, 0] == 1]) == 0
     assert sorted(ref[ref[:, 0] == 2][:, 1].tolist()) == [0.0, 1.0]     # re-found + a new track at score 0.35
+
+
+def test_chunked_native_tracking_equals_frame_by_frame():
+    """st_tracker_track_records (a chunk of frame records in ONE native call, what OCSORT_Disparity.predict uses)
+    against the per-frame track() + scale_bbox(boxes, 1 / scales) of the same tracker: ids equal, every float
+    bit-equal (the un-scaling is the same fp32 single operations torch evaluates), padding frames skipped, an
+    overflowing record raises."""
+    from stereotracking_amd.dist import DetectionOverflow
+    from stereotracking_amd.mot import scale_bbox
+    T, M = 24, 12
+    det = detection_stream(51, T, duplicates=True)
+
+    class _Model:
+        motion = KalmanFilter()
+
+    one = OCSORTTracker_Disparity(**SHIPPED_TRACKER)
+    chunked = OCSORTTracker_Disparity(**SHIPPED_TRACKER)
+    rec = np.zeros((T + 2, M + 1, 13), np.float32)          # 2 trailing padding frames (header all zero)
+    rng = np.random.RandomState(3)
+    for t in range(T):
+        d = det[det[:, 0] == t]
+        k = len(d)
+        rec[t, 0, :3] = (k, M, 1)
+        rec[t, 1:1 + k, 8:12] = d[:, 1:5]                    # the depth-scaled box the tracker consumes
+        rec[t, 1:1 + k, 0:4] = rng.rand(k, 4)                # unscaled box of the detection: not used by the tracker
+        rec[t, 1:1 + k, 4], rec[t, 1:1 + k, 6], rec[t, 1:1 + k, 7] = d[:, 5], d[:, 6], d[:, 7]
+        rec[t, 1:1 + k, 12] = np.arange(k)
+    fids = list(range(T)) + [-1, -1]
+    n_rows = 0
+    for lo, hi in ((0, 8), (8, 16), (16, T + 2)):            # three chunks, as predict() walks a video
+        rows, ids, counts = chunked.track_records(fids[lo:hi], rec[lo:hi])
+        for i, t in enumerate(range(lo, hi)):
+            if t >= T:
+                assert counts[i] == -1
+                continue
+            d = det[det[:, 0] == t]
+            s = TrackDataSample(dict(frame_id=t))
+            s.pred_det_instances = InstanceData(bboxes=torch.from_numpy(d[:, 1:5].copy()),
+                                                scores=torch.from_numpy(d[:, 5].copy()),
+                                                labels=torch.zeros(len(d), dtype=torch.long),
+                                                scales=torch.from_numpy(d[:, 7].copy()),
+                                                depth=torch.from_numpy(d[:, 6].copy()))
+            ref = one.track(_Model(), None, None, s)
+            m = int(counts[i])
+            assert ids[i, :m].tolist() == ref.instances_id.tolist()
+            want = scale_bbox(ref.bboxes, 1 / ref.scales).numpy()
+            assert np.array_equal(rows[i, :m, 0:4].view(np.uint32), want.view(np.uint32))
+            assert np.array_equal(rows[i, :m, 4], ref.scores.numpy()) and np.array_equal(rows[i, :m, 6], ref.depth.numpy())
+            assert np.array_equal(rows[i, :m, 7], ref.scales.numpy())
+            n_rows += m
+    assert n_rows > 3 * T
+    rec[0, 0, 0] = M + 5                                      # a frame that kept more boxes than the record holds
+    with pytest.raises(DetectionOverflow, match='max_det'):
+        chunked.track_records(fids[:8], rec[:8])
