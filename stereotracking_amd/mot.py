@@ -12,6 +12,7 @@ order — the dense path runs batched, the tracker consumes the frames sequentia
 """
 import ctypes as C
 
+import numpy as np
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -446,12 +447,15 @@ class OCSORT_Disparity(nn.Module):
                 # the whole chunk in ONE native call (st_tracker_track_records reads the page-locked record buffer the
                 # D2H copy landed in: detections in, unscaled track rows out); per frame only views are taken
                 fids = [int(data_samples[n].metainfo.get('frame_id', -1)) for n in range(s, e)]
-                chunk = rec[:e - s].clone()            # the staging buffer is reused by a later chunk
-                trows, tids, tcnt = self.tracker.track_records(fids, chunk)
-                trows, tids = torch.from_numpy(trows), torch.from_numpy(tids)
-                det_labels, det_prior = chunk[:, 1:, 5].long(), chunk[:, 1:, 12].long()
-                trk_labels = trows[:, :, 5].long()
-                counts_h = chunk[:, 0, 0].long().tolist()
+                # (numpy copies: a torch CPU op above ~32 K elements wakes the whole intra-op thread pool - tens of
+                # milliseconds on a 256-core host whose process owns a 16-core share - for a 400 KB memcpy)
+                chunk_np = rec[:e - s].numpy().copy()  # the staging buffer is reused by a later chunk
+                trows, tids, tcnt = self.tracker.track_records(fids, chunk_np)
+                det_labels = torch.from_numpy(chunk_np[:, 1:, 5].astype(np.int64))
+                det_prior = torch.from_numpy(chunk_np[:, 1:, 12].astype(np.int64))
+                trk_labels = torch.from_numpy(trows[:, :, 5].astype(np.int64))
+                counts_h = chunk_np[:, 0, 0].astype(np.int64).tolist()
+                chunk, trows, tids = torch.from_numpy(chunk_np), torch.from_numpy(trows), torch.from_numpy(tids)
                 for i, n in enumerate(range(s, e)):
                     k, m = counts_h[i], int(tcnt[i])
                     rows, tr = chunk[i, 1:1 + k], trows[i, :m]

@@ -124,7 +124,10 @@ class OCSORTTracker_Disparity:
     def __del__(self):
         h = getattr(self, '_native', None)
         if h is not None:
-            _lib.load().st_tracker_destroy(h)
+            try:
+                _lib.load().st_tracker_destroy(h)
+            except Exception:      # interpreter shutdown: module globals are already gone
+                pass
             self._native = None
 
     @property
