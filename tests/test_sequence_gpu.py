@@ -186,8 +186,27 @@ def test_config2_full_size_64_frame_sequence(cuda):
         assert rb[t].instances_id.tolist() == r1[t].instances_id.tolist(), f'frame {t}: track ids differ'
         n_trk += len(rb[t])
     assert n_trk > T, 'the scenario must exercise the association step'
+    # throughput of the SAME driver on the plan bench.py runs (the committed / measured tuning; the parity part above
+    # pins the heuristic plan because batch 8 and batch 1 must pick the same kernel instances to be bit-identical)
+    del solo
+    tuned = InflightPipelines(3, 8, (H, W), 0.5, 0.33, 1, **kw)
+    tuned.load_state_dict(sd)
+    detect_shard(tuned, resident, cuda, uploader=up)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    dt_, ct_ = detect_shard(tuned, resident, cuda, uploader=up)
+    torch.cuda.synchronize()
+    t_tuned_res = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    detect_shard(tuned, frames, cuda, uploader=up)
+    torch.cuda.synchronize()
+    t_tuned_list = time.perf_counter() - t0
+    assert ct_[:T].tolist() == c1[:T].tolist() or int((ct_[:T] - c1[:T]).abs().max()) <= 2   # another plan: float noise only
     rec = dict(config='configs[2]: 64-frame synthetic 1280x720 sequence, D=192, full YOLOX-s, 1 GPU',
+               dense_frames_per_s_tuned_plan_from_pinned_u8=round(T / t_tuned_res, 1),
+               dense_frames_per_s_tuned_plan_from_host_numpy=round(T / t_tuned_list, 1),
                frames=T, dense_seconds=round(t_dense, 4), dense_frames_per_s=round(T / t_dense, 1),
+               plan_of_the_parity_part='heuristic (autotune=False)',
                includes='host numpy frames -> 2 pinned staging slots -> uint8 H2D on a copy stream -> st_pack_raw_inputs -> dense '
                         'path, 8 frames per plan on 3 contexts',
                dense_frames_per_s_from_pinned_u8=round(T / t_res, 1),
