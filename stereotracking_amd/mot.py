@@ -67,7 +67,10 @@ class TrackDataPreprocessor_Disparity_V1(nn.Module):
             return self._device
         return torch.device('cuda', torch.cuda.current_device()) if torch.cuda.is_available() else torch.device('cpu')
 
-    def forward(self, data, training=False):
+    def forward(self, data, training=False, lazy_raw=False):
+        """lazy_raw (used by OCSORT_Disparity.test_step): keys whose frames are equal-sized uint8 (1,3,h,w) CUDA
+        tensors, with no normalisation / channel swap configured, come back as RawFrames (converted chunk by chunk
+        inside the pipelined dense path) instead of one (N,1,3,H,W) fp32 tensor; the metainfo is set as usual."""
         inputs, samples = data['inputs'], data.get('data_samples')
         dev = self.device
         out = {}
@@ -75,6 +78,17 @@ class TrackDataPreprocessor_Disparity_V1(nn.Module):
             imgs = [im.to(dev, non_blocking=self.non_blocking) for im in imgs]
             pad_shapes = [tuple(im.shape[-2:]) for im in imgs]
             plain = not (self.channel_conversion and imgs[0].size(1) == 3) and not self._enable_normalize
+            if (lazy_raw and plain and imgs[0].is_cuda and len(set(pad_shapes)) == 1 and
+                    all(im.dtype == torch.uint8 and tuple(im.shape[:2]) == (1, 3) for im in imgs)):
+                d = self.pad_size_divisor
+                h, w = pad_shapes[0]
+                H, W = ((h + d - 1) // d * d, (w + d - 1) // d * d) if d > 1 else (h, w)
+                out[key] = RawFrames(imgs, (H, W), self.pad_value)
+                if samples is not None:
+                    prefix = key[:-3]
+                    for sm, ps in zip(samples, pad_shapes):
+                        sm.set_metainfo({f'{prefix}batch_input_shape': (H, W), f'{prefix}pad_shape': ps})
+                continue
             if plain and len({tuple(im.shape[:2]) for im in imgs}) == 1:
                 # cast + pad + stack as ONE pass per frame: the (N,T,C,H,W) fp32 result is allocated once, filled with
                 # the pad value, and every frame is converted straight into its slot (same values as
@@ -120,6 +134,38 @@ class TrackDataPreprocessor_Disparity_V1(nn.Module):
                 for s, ps in zip(samples, pad_shapes):
                     s.set_metainfo({f'{prefix}batch_input_shape': shape, f'{prefix}pad_shape': ps})
         return dict(inputs=out, data_samples=samples)
+
+
+class RawFrames:
+    """N equal-sized uint8 CUDA frames (1,3,h,w) of one input key, NOT yet converted: what test_step hands to
+    predict() for frames uploaded raw.  predict() converts a chunk at a time (torch.cat of the chunk's frames +
+    st_pack_raw_inputs: cast + pad in one HIP pass) inside the pipelined submit, so the conversion
+    of chunk i+3 overlaps the dense work of chunks i..i+2 and no (N,1,3,H,W) fp32 copy of the whole call exists.
+    Values are exactly those of TrackDataPreprocessor_Disparity_V1.forward (reference
+    data_preprocessor_disparity_v1.py:21-84 + utils/misc.py:13-64)."""
+
+    def __init__(self, frames, pad_hw, pad_value):
+        self.frames, self.pad_hw, self.pad_value = frames, (int(pad_hw[0]), int(pad_hw[1])), float(pad_value)
+        self.hw = tuple(frames[0].shape[-2:])
+        self.device = frames[0].device
+
+    def __len__(self):
+        return len(self.frames)
+
+    def chunk(self, s, e, B):
+        """frames [s, e) (+ the last one repeated up to B) -> (B,3,H,W) fp32, padded with pad_value."""
+        fr = self.frames[s:e]
+        fr = fr + [fr[-1]] * (B - len(fr))
+        raw = torch.cat(fr, dim=0)
+        (h, w), (H, W) = self.hw, self.pad_hw
+        out = torch.empty(B, 3, H, W, dtype=torch.float32, device=self.device)
+        check(_lib.load().st_pack_raw_inputs(ptr(raw), None, B, h, w, H, W, self.pad_value, ptr(out), None, None,
+                                             current_stream()), 'st_pack_raw_inputs')
+        return out
+
+    def dense(self):
+        """The (N,1,3,H,W) fp32 tensor the preprocessor would have produced (for callers that want it)."""
+        return self.chunk(0, len(self.frames), len(self.frames))[:, None]
 
 
 def pack_raw_inputs(img_u8=None, disp_u16=None, pad_size_divisor=32, img_pad=114.0):
@@ -252,7 +298,10 @@ class OCSORT_Disparity(nn.Module):
     def test_step(self, data):
         import time
         t0 = time.perf_counter()
-        data = self.data_preprocessor(data, False)
+        try:
+            data = self.data_preprocessor(data, False, lazy_raw=True)
+        except TypeError:      # a preprocessor without the lazy option (e.g. mmengine's own class)
+            data = self.data_preprocessor(data, False)
         self.timings['pre_s'] += time.perf_counter() - t0
         return self.forward(data['inputs'], data['data_samples'], mode='predict')
 
@@ -359,23 +408,33 @@ class OCSORT_Disparity(nn.Module):
         from .dist import DetectionOverflow
         img, disp_postp = inputs['img'], inputs.get('disp_postp')
         depth_postp = inputs.get('depth_postp', None)
-        assert img.dim() == 5, 'The img must be 5D Tensor (N, T, C, H, W).'
-        assert img.size(1) == 1, 'one key frame per sample (T = 1)'
-        N = img.size(0)
+
+        def unwrap(t, name):      # (N,1,C,H,W) tensor -> (N,C,H,W); RawFrames stay lazy (converted per chunk)
+            if t is None or isinstance(t, RawFrames):
+                return t
+            assert t.dim() == 5, f'The {name} must be 5D Tensor (N, T, C, H, W).'
+            assert t.size(1) == 1, 'one key frame per sample (T = 1)'
+            return t[:, 0]
+        img = unwrap(img, 'img')
+        N = len(img)
         assert len(data_samples) == N
-        img = img[:, 0]
-        if not img.is_cuda:
+        if not (img.device.type == 'cuda'):
             raise RuntimeError('OCSORT_Disparity runs on the HIP path only: inputs must be CUDA tensors')
         stereo = disp_postp is None
         if stereo:
             if self.stereo is None or inputs.get('right') is None:
                 raise KeyError("inputs need 'disp_postp', or 'right' with a stereo module configured")
-            second = inputs['right'][:, 0]
+            second = unwrap(inputs['right'], 'right')
         else:
-            second = disp_postp[:, 0]
-        gt = depth_postp[:, 0] if depth_postp is not None else None
+            second = unwrap(disp_postp, 'disp_postp')
+            if isinstance(second, RawFrames):
+                second = second.dense()[:, 0]      # a uint8 disparity is unusual: convert it eagerly
+        gt = unwrap(depth_postp, 'depth_postp')
+        if isinstance(gt, RawFrames):
+            gt = gt.dense()[:, 0]
         metas = [s.metainfo for s in data_samples]
-        ori = tuple(int(v) for v in metas[0].get('ori_shape', img.shape[-2:])[:2])
+        pad_hw = img.pad_hw if isinstance(img, RawFrames) else tuple(img.shape[-2:])
+        ori = tuple(int(v) for v in metas[0].get('ori_shape', pad_hw)[:2])
         for m in metas[1:]:
             if tuple(int(v) for v in m.get('ori_shape', ori)[:2]) != ori:
                 raise NotImplementedError('one batched launch plan needs a uniform ori_shape')
@@ -386,6 +445,8 @@ class OCSORT_Disparity(nn.Module):
         t_host0 = time.perf_counter()
 
         def padded(t, s, e):
+            if isinstance(t, RawFrames):
+                return t.chunk(s, e, B)
             t = t[s:e].float().contiguous()
             if e - s < B:      # last chunk: repeat its last frame (results of the padding are ignored)
                 t = torch.cat([t, t[-1:].expand(B - (e - s), *t.shape[1:])])

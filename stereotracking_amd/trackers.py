@@ -181,8 +181,8 @@ class OCSORTTracker_Disparity:
         F, R, Cc = records.shape
         rec = np.ascontiguousarray(records, dtype=np.float32) if isinstance(records, np.ndarray) else records.numpy()
         fid = np.ascontiguousarray(frame_ids, dtype=np.int32)
-        rows = np.empty((F, R - 1, 8), np.float32)
-        ids = np.empty((F, R - 1), np.int64)
+        rows = np.zeros((F, R - 1, 8), np.float32)     # rows past a frame's count stay zero (they are sliced off)
+        ids = np.zeros((F, R - 1), np.int64)
         counts = np.empty(F, np.int32)
         rc = _lib.load().st_tracker_track_records(self._handle(), fid.ctypes.data_as(C.c_void_p),
                                                   rec.ctypes.data_as(C.c_void_p), F, R, Cc,

@@ -20,7 +20,7 @@ reference run's own margins, parity_utils.explain_kept_difference) that it hangs
 allows two kept boxes to swap places in the score order only when their reference scores differ by < 5e-5; the
 counts of differing priors / swapped positions and the margins go into the record.
 
-The measured figures are written to gpurun_out/r02_e2e_parity.json (copied to profiles/)."""
+The measured figures are written to gpurun_out/r03_e2e_parity.json (copied to profiles/)."""
 import numpy as np
 import pytest
 import torch
@@ -91,6 +91,7 @@ def test_benched_configuration_parity(cuda):
             tu['differing_priors'][f'image{n}'] = dict(priors=e['differing_priors'], min_iou_margin=e['min_iou_margin'],
                                                        min_score_margin=e['min_score_margin'])
             tu['unexplained'] += e['unexplained']
+            tu['max_affected_frac'] = max(tu.get('max_affected_frac', 0.0), e['affected_frac'])
         ia, ib = align_kept(pa, pb)
         ia, ib = torch.from_numpy(ia).to(cuda), torch.from_numpy(ib).to(cuda)
         # extract_depth truncates the box to integer pixels (ocsort_disparity.py:141): a coordinate within float noise
@@ -129,7 +130,7 @@ def test_benched_configuration_parity(cuda):
             c['explain'] = explain_kept_difference(r['rows'], pipe.det.levels, out['prior_idx'][n, :int(counts[n])].cpu().numpy(),
                                                    r['prior'], pipe.score_thr, pipe.iou_thr)
         rec['e2e'][f'pair{n}'] = c
-    write_record('r02_e2e_parity.json', rec)
+    write_record('r03_e2e_parity.json', rec)
     print(rec)
 
     # ---- the bars ---------------------------------------------------------------------------------------
@@ -139,6 +140,7 @@ def test_benched_configuration_parity(cuda):
     for key, e in a.items():
         assert e <= 1e-3, f'tuned vs untuned {key}: {e:.3e}'
     assert not tu['unexplained'], f'tuned vs untuned: kept indices differ beyond marginal decisions: {tu}'
+    assert tu.get('max_affected_frac', 0.0) <= 0.10, f'the marginal-decision closure covers too many candidates to explain anything: {tu}'
     assert tu['images_with_equal_kept_sets'] >= B - 2, tu
     assert tu['boxes_with_different_pixel_window'] <= max(2, tu['boxes_compared'] // 100), tu
     assert tu['max_score_gap_at_swaps'] <= 5e-5, tu          # order swaps only between (near-)equal scores
@@ -151,4 +153,5 @@ def test_benched_configuration_parity(cuda):
         assert c['max_score_gap_at_swaps'] <= 5e-5, c
         if not c['kept_sets_equal']:
             assert not c['explain']['unexplained'], f'pair {n}: kept indices differ beyond marginal decisions: {c}'
+            assert c['explain']['affected_frac'] <= 0.10, f'pair {n}: vacuous explanation (closure too large): {c["explain"]}'
             assert c['kept_set_sym_diff'] <= max(2, c['count_oracle'] // 100), c

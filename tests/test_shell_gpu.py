@@ -217,3 +217,39 @@ def test_batched_predict_equals_sequential_and_stereo_module(cuda):
     model.detector._run(data, ori)
     torch.cuda.synchronize()
     assert rel_err(data['disp_postp'].cpu().numpy(), ref) <= 1e-3
+
+
+def test_frames_without_detections_and_ragged_calls(cuda):
+    """Edge cases of the shell: a score threshold nothing passes (every frame keeps 0 boxes: empty detection and track
+    containers, no crash in the chunked association / depth launches), a call whose frame count is not a multiple
+    of the dense batch, and a one-frame call - through the raw uint8 path (RawFrames) of test_step."""
+    from stereotracking_amd import mot  # noqa: F401
+    from stereotracking_amd.config import Config
+    from stereotracking_amd.registry import MODELS
+    from stereotracking_amd.structures import TrackDataSample
+    cfg = Config.fromfile(CFG_STEREO)
+    for part in ('backbone', 'neck'):
+        cfg.model.detector[part]['widen_factor'] = 0.375
+    cfg.model.detector.bbox_head.head_module['widen_factor'] = 0.375
+    cfg.model.stereo['max_disp'] = 32
+    cfg.model.detector.test_cfg['score_thr'] = 0.9999
+    model = MODELS.build(dict(cfg.model, autotune=False, dense_batch=4, inflight=2))
+    table = list(model.detector._table) + [('stereo.' + n, shp) for n, shp in model.stereo.param_table()]
+    sd = synthetic_state_dict(table, seed=5)
+    model.detector.load_state_dict(sd, strict=False)
+    model.stereo.load_state_dict({k[len('stereo.'):]: v for k, v in sd.items() if k.startswith('stereo.')})
+    ori = (80, 160)
+    fr = synthetic_batch(list(range(60, 67)), ori[0], ori[1], 32)     # 7 frames: chunks of 4 + 3
+    left = [fr['img'][i:i + 1, :, :ori[0]].to(torch.uint8).to(cuda) for i in range(7)]
+    right = [fr['right'][i:i + 1, :, :ori[0]].to(torch.uint8).to(cuda) for i in range(7)]
+    for lo, hi in ((0, 7), (0, 1)):
+        samples = [TrackDataSample(dict(frame_id=t, ori_shape=ori, scale_factor=(1.0, 1.0))) for t in range(lo, hi)]
+        outs = model.test_step(dict(inputs=dict(img=left[lo:hi], right=right[lo:hi]), data_samples=samples))
+        torch.cuda.synchronize()
+        assert len(outs) == hi - lo
+        for o in outs:
+            assert len(o.pred_det_instances) == 0 and len(o.pred_track_instances) == 0
+            assert tuple(o.pred_det_instances.bboxes.shape) == (0, 4)
+            assert set(o.pred_track_instances.keys()) >= {'bboxes', 'labels', 'scores', 'scales', 'depth', 'gt_depth',
+                                                          'instances_id'}
+            assert o.metainfo['batch_input_shape'] == (96, 160) and o.metainfo['pad_shape'] == ori
