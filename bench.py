@@ -209,8 +209,10 @@ def conv_roofline(pipe, img, right, steps):
                 event_overhead_subtracted=True,
                 definition='achieved = flops EXECUTED by the matrix pipes (direct-convolution count / algorithmic_speedup) '
                            '/ summed kernel duration of the family in a serialized pass (HIP events on the launch '
-                           'stream minus the measured event-pair overhead; agrees with the rocprofv3 kernel-trace '
-                           'durations in profiles/r03_kernel_stats_inflight1.csv); frac = achieved / peak <= 1',
+                           'stream minus the measured event-pair overhead; an event-bracketed launch also carries its '
+                           'dispatch latency, so these durations read ~4 % above the rocprofv3 kernel-trace durations '
+                           'of the same launches in profiles/r03_kernel_stats_inflight1.csv: `achieved` is a lower '
+                           'bound); frac = achieved / peak <= 1',
                 families=fam,
                 all_mfma_kernels=dict(ms_per_step=round(conv_ms, 4),
                                       algorithmic_tflops=round(conv_fl / (conv_ms * 1e-3) / 1e12, 3),

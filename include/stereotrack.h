@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define ST_VERSION 100
+#define ST_VERSION 300
 
 enum {
   ST_OK = 0,

@@ -3,10 +3,11 @@
 # MFMA-pipe utilisation and HBM traffic per kernel.  Outputs under gpurun_out/prof_$1; summaries are then copied to
 # profiles/ by hand.  rocprofv3 gets the program itself after `--` (no wrapper), counters in their own passes.
 set -e
-TAG=${1:-r02}
+TAG=${1:-r03}
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
-export ST_TUNE_CACHE=$PWD/$OUT/tune_cache.json
+# the plan every entry point shares: the committed configs/tuning/mi355x.json (measured here when absent)
+export ST_TUNE_CACHE=$PWD/configs/tuning/mi355x.json
 COMMON="--steps 20 --warmup 5 --no-cpu-baseline --no-test-step --sustain-seconds 0"
 python bench.py $COMMON > $OUT/bench_plain.json 2> $OUT/bench_plain.err          # also fills the tuning cache
 cd /tmp && export TMPDIR=/tmp
@@ -22,6 +23,7 @@ find $OUT -name "*_kernel_stats.csv" | head
 python tools/pmc_mfma.py $(find $OUT/pmc_mfma -name "*counter_collection.csv" | head -1) $OUT/mfma_busy.json > $OUT/mfma_busy.txt
 python tools/pmc_summary.py $(find $OUT/pmc_fetch -name "*counter_collection.csv" | head -1) $(find $OUT/pmc_write -name "*counter_collection.csv" | head -1) $OUT/hbm_traffic.json > $OUT/hbm_traffic.txt
 python tools/op_profile.py --out $OUT/op_table.txt > /dev/null
+cp configs/tuning/mi355x.json $OUT/tune_cache.json
 # keep the merged-back payload small: the raw traces are not needed
 find $OUT -name "*_kernel_trace.csv" -delete; find $OUT -name "*counter_collection.csv" -delete; find $OUT -name "*.db" -delete
 du -sh $OUT
