@@ -165,10 +165,12 @@ def test_config2_full_size_64_frame_sequence(cuda):
     torch.cuda.synchronize()
     t_dense = time.perf_counter() - t0
     resident = HostSequence(frames, use_right=True)              # the decoded bytes resident in page-locked memory
+    bytes0 = up.bytes_uploaded
     t0 = time.perf_counter()
     dr, cr = detect_shard(runner, resident, cuda, uploader=up)
     torch.cuda.synchronize()
     t_res = time.perf_counter() - t0
+    bytes_per_frame = (up.bytes_uploaded - bytes0) // T
     assert torch.equal(dr.nan_to_num(-7.0), db.nan_to_num(-7.0)) and torch.equal(cr, cb)
     t0 = time.perf_counter()
     rb = track_gathered(db, cb, T, OCSORTTracker_Disparity(**cfg), _Model())
@@ -211,7 +213,7 @@ def test_config2_full_size_64_frame_sequence(cuda):
                         'path, 8 frames per plan on 3 contexts',
                dense_frames_per_s_from_pinned_u8=round(T / t_res, 1),
                includes_pinned='the same from a HostSequence (uint8 frames resident in page-locked memory: no staging copy)',
-               uploaded_bytes_per_frame=int(up.bytes_uploaded / (2 * T + 8)),
+               uploaded_bytes_per_frame=int(bytes_per_frame),   # 2 x 3 x 720 x 1280 uint8 (fp32 frames: 22.1 MB)
                tracker_seconds=round(t_track, 4), tracker_ms_per_frame=round(t_track / T * 1e3, 4),
                tracks_returned=n_trk, detections_per_frame_mean=round(float(c1.float().mean()), 1),
                end_to_end_frames_per_s=round(T / (t_dense + t_track), 1))
