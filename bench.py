@@ -434,6 +434,54 @@ def tracker_cost(seconds=1.0):
                 workload='64-frame synthetic detection stream (6 objects, 10 % dropped detections, 8-frame occlusion)')
 
 
+def batched_association_line(dev, B=1024, T=32, M=16):
+    """the association step of B independent 6-object sequences per step on the device (one wave per
+    sequence, csrc/batched_assoc.hip) next to the native host tracker on one of them."""
+    import numpy as np
+    from stereotracking_amd.batched_assoc import BatchedGpuTracker
+    from stereotracking_amd.synthetic import synthetic_detection_stream
+    from stereotracking_amd.trackers import OCSORTTracker_Disparity
+    try:
+        cfg = dict(obj_score_thr=0.3, init_track_thr=0.7, weight_iou_with_det_scores=False, match_iou_thr=0.1,
+                   num_tentatives=3, vel_consist_weight=0.2, vel_delta_t=3, num_frames_retain=30)
+        base = []
+        for s in range(16):
+            det = synthetic_detection_stream(200 + s, T=T, K=6)
+            d, c = np.zeros((T, M, 8), np.float32), np.zeros(T, np.int32)
+            for t in range(T):
+                r = det[det[:, 0] == t]
+                k = len(r)
+                d[t, :k, 0:4], d[t, :k, 4], d[t, :k, 6], d[t, :k, 7], c[t] = r[:, 1:5], r[:, 5], r[:, 6], r[:, 7], k
+            base.append((d, c))
+        rec = np.zeros((T, M + 1, 13), np.float32)
+        rec[:, 0, 0], rec[:, 0, 1], rec[:, 0, 2] = base[0][1], M, 1
+        rec[:, 1:, 8:12], rec[:, 1:, 4:8] = base[0][0][:, :, 0:4], base[0][0][:, :, 4:8]
+        host = OCSORTTracker_Disparity(**cfg)
+        n, t0 = 0, time.perf_counter()
+        while time.perf_counter() - t0 < 0.3:
+            host.track_records(list(range(T)), rec)
+            n += T
+        host_us = (time.perf_counter() - t0) / n * 1e6
+        dets = torch.from_numpy(np.stack([base[b % 16][0] for b in range(B)], 1)).to(dev)
+        counts = torch.from_numpy(np.stack([base[b % 16][1] for b in range(B)], 1)).to(dev)
+        fids = [torch.full((B,), t, dtype=torch.int32, device=dev) for t in range(T)]
+        g = BatchedGpuTracker(B, max_tracks=32, max_dets=M, device=dev, **cfg)
+        for _ in range(2):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for t in range(T):
+                g.step(fids[t], dets[t], counts[t], check_status=False)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+        return dict(sequences_per_step=B, ms_per_step=round(dt / T * 1e3, 4),
+                    us_per_sequence_frame=round(dt / T / B * 1e6, 4), host_native_us_per_sequence_frame=round(host_us, 3),
+                    overflow=bool(int(g.status.max()) != 0),
+                    workload=f'{B} independent 6-object sequences x {T} frames, shipped tracker thresholds; ids equal '
+                             'to the host tracker (tests/test_batched_assoc_gpu.py)')
+    except Exception as e:   # a secondary line must never cost the headline
+        return dict(error=repr(e))
+
+
 def main():
     args = parse()
     rank = int(os.environ.get('RANK', 0))
@@ -564,6 +612,8 @@ def main():
             if line['test_step'].get('long_call'):
                 line['test_step']['long_call']['vs_pipeline'] = round(line['test_step']['long_call']['value'] / line['value'], 4)
         line['tracker_cpu'] = tracker_cost()
+        if world == 1:
+            line['batched_gpu_association'] = batched_association_line(dev)
         if world == 1 and not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline(sd, batch_cpu, args.max_disp, args.cpu_seconds, args.agg_layers, args.max_det)
         print(json.dumps(line), flush=True)

@@ -391,6 +391,29 @@ long long st_tracker_next_id(const StTracker* t);
 int st_tracker_get_track(const StTracker* t, int index, int64_t* id, double* mean8, double* cov64,
                          int* tentative, int* tracked, int* last_frame);
 
+
+/* ------------------------------------------------------------------------
+ * 9. Batched GPU association: the SAME association step (section 8) for `batch` independent
+ *    sequences advanced in lockstep on the device, one wave per sequence and frame; state stays in device memory
+ *    between steps.  Results (ids, rows, order) equal st_tracker_track's on the same detections.  For many short
+ *    sequences per step (multi-camera serving); for one video the host routine is the faster one.
+ *    dets (batch, max_dets, 8) = rows of frame records (depth-scaled box, score, label, depth, scale), counts[b] = rows
+ *    of sequence b in this step (-1: sequence b has no frame in this step), frame_ids[b] (0 resets sequence b).
+ *    state / scratch: caller-owned device buffers of st_batched_tracker_{state,scratch}_bytes (state zero-filled
+ *    before the first step).  out_rows (batch, max_dets, 8), out_ids (batch, max_dets), out_counts (batch),
+ *    status (batch): 0 ok, 1 = more than max_tracks live tracks, 2 = counts[b] > max_dets (that sequence's
+ *    output count is 0; the caller checks status).  Enqueued on `stream`, no host sync.
+ * ---------------------------------------------------------------------- */
+typedef struct StBatchedTracker StBatchedTracker;
+int st_batched_tracker_create(const StTrackerConfig* cfg, int batch, int max_tracks, int max_dets,
+                              StBatchedTracker** out);
+int st_batched_tracker_destroy(StBatchedTracker* t);
+size_t st_batched_tracker_state_bytes(const StBatchedTracker* t);
+size_t st_batched_tracker_scratch_bytes(const StBatchedTracker* t);
+int st_batched_tracker_step(StBatchedTracker* t, const int32_t* frame_ids_dev, const float* dets_dev,
+                            const int32_t* counts_dev, void* state_dev, void* scratch_dev, float* out_rows_dev,
+                            int64_t* out_ids_dev, int32_t* out_counts_dev, int32_t* status_dev, st_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

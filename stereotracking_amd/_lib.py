@@ -117,6 +117,11 @@ _PROTOS = {
     'st_tracker_num_tracks': (_i, [_vp]),
     'st_tracker_next_id': (C.c_longlong, [_vp]),
     'st_tracker_get_track': (_i, [_vp, _i, _vp, _vp, _vp, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i)]),
+    'st_batched_tracker_create': (_i, [C.POINTER(StTrackerConfig), _i, _i, _i, C.POINTER(_vp)]),
+    'st_batched_tracker_destroy': (_i, [_vp]),
+    'st_batched_tracker_state_bytes': (_sz, [_vp]),
+    'st_batched_tracker_scratch_bytes': (_sz, [_vp]),
+    'st_batched_tracker_step': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     'st_decode_nms': (_i, [C.POINTER(StDecodeDesc), _vp, _vp, _sz, _vp, _vp, _vp, _vp, _vp, _vp]),
     'st_costvolume_softargmin': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _f, _vp, _vp, _vp]),
     'st_softargmin': (_i, [_vp, _i, _i, _i, _i, _f, _vp, _vp]),

@@ -15,7 +15,7 @@ def pytest_configure(config):
 # Collection order of the GPU run (the driver uses `-x`): oracle-parity files first, multi-process rehearsals LAST, so
 # that a harness failure in a subprocess launcher can never again hide the parity tests behind it (round 2:
 # GPUTEST_r02 stopped at test_multirank_gpu and 27 parity tests did not run).
-_ORDER = ['test_decode_nms_gpu', 'test_stereo_depth_gpu', 'test_conv_gpu', 'test_detector_gpu',
+_ORDER = ['test_decode_nms_gpu', 'test_stereo_depth_gpu', 'test_conv_gpu', 'test_detector_gpu', 'test_batched_assoc_gpu',
           'test_bench_config_parity_gpu', 'test_shell_gpu', 'test_sequence_gpu']
 _LAST = ['test_multirank_gpu']
 

@@ -1,0 +1,133 @@
+"""GPU: batched association (csrc/batched_assoc.hip) against the native host tracker
+(csrc/ocsort_tracker.cpp: st_tracker_track, itself held equal to the oracle restatement of reference
+mmtrack/models/trackers/ocsort_tracker_disparity.py:345-618 by tests/test_cpu_tracker_oracle.py): B independent
+sequences advanced in lockstep on the device must return, for every sequence and frame, the SAME ids in the same order
+and bit-identical rows; sequences of different lengths (padding slots), exact duplicates (assignment ties), an
+occlusion (observation-centric recovery + online smoothing), a dense sequence (hundreds of detections, the shipped
+and the stress thresholds) and the capacity checks are covered."""
+import numpy as np
+import pytest
+import torch
+
+from stereotracking_amd.batched_assoc import BatchedGpuTracker
+from stereotracking_amd.synthetic import synthetic_detection_stream
+from stereotracking_amd.trackers import OCSORTTracker_Disparity
+
+pytestmark = pytest.mark.gpu
+
+SHIPPED = dict(obj_score_thr=0.3, init_track_thr=0.7, weight_iou_with_det_scores=False, match_iou_thr=0.1,
+               num_tentatives=3, vel_consist_weight=0.2, vel_delta_t=3, num_frames_retain=30)
+
+
+def host_reference(streams, T, cfg, M):
+    """Per sequence: the native host tracker frame by frame -> [(rows (k,8), ids (k,))] per frame."""
+    out = []
+    for det in streams:
+        trk = OCSORTTracker_Disparity(**cfg)
+        frames = []
+        tmax = int(det[:, 0].max()) + 1 if len(det) else 0
+        for t in range(tmax):
+            d = det[det[:, 0] == t]
+            rec = np.zeros((1, M + 1, 13), np.float32)
+            k = len(d)
+            rec[0, 0, :3] = (k, M, 1)
+            rec[0, 1:1 + k, 8:12] = d[:, 1:5]
+            rec[0, 1:1 + k, 4], rec[0, 1:1 + k, 6], rec[0, 1:1 + k, 7] = d[:, 5], d[:, 6], d[:, 7]
+            rows, ids, cnt = trk.track_records([t], rec)      # rows come back with the box UNSCALED: re-derive below
+            m = int(cnt[0])
+            frames.append((ids[0, :m].copy(), rows[0, :m, 4:8].copy()))
+        out.append(frames)
+    return out
+
+
+def run_batched(streams, T, cfg, M, max_tracks, cuda):
+    B = len(streams)
+    trk = BatchedGpuTracker(B, max_tracks=max_tracks, max_dets=M, device=cuda, **cfg)
+    res = [[] for _ in range(B)]
+    for t in range(T):
+        dets = np.zeros((B, M, 8), np.float32)
+        counts = np.full(B, -1, np.int32)
+        for b, det in enumerate(streams):
+            tmax = int(det[:, 0].max()) + 1 if len(det) else 0
+            if t >= tmax:
+                continue                                  # this sequence has ended: padding slot
+            d = det[det[:, 0] == t]
+            k = len(d)
+            dets[b, :k, 0:4] = d[:, 1:5]
+            dets[b, :k, 4], dets[b, :k, 6], dets[b, :k, 7] = d[:, 5], d[:, 6], d[:, 7]
+            counts[b] = k
+        rows, ids, n = trk.step(torch.full((B,), t, dtype=torch.int32, device=cuda), torch.from_numpy(dets).to(cuda),
+                                torch.from_numpy(counts).to(cuda))
+        rows, ids, n = rows.cpu().numpy(), ids.cpu().numpy(), n.cpu().numpy()
+        for b in range(B):
+            if counts[b] < 0:
+                assert n[b] == -1
+                continue
+            m = int(n[b])
+            res[b].append((ids[b, :m].copy(), rows[b, :m].copy()))
+    return res
+
+
+def compare(gpu, ref, streams):
+    rows_total = 0
+    for b, (g, r) in enumerate(zip(gpu, ref)):
+        assert len(g) == len(r), f'sequence {b}: {len(g)} frames vs {len(r)}'
+        for t, ((gi, gr), (ri, rr)) in enumerate(zip(g, r)):
+            assert gi.tolist() == ri.tolist(), f'sequence {b} frame {t}: ids differ\n{gi}\n{ri}'
+            # score, label, depth, scale pass through bit for bit; the box is the detection's (scaled) box: look it up
+            assert np.array_equal(gr[:, 4:8].view(np.uint32), rr.view(np.uint32)), f'sequence {b} frame {t}: rows differ'
+            d = streams[b][streams[b][:, 0] == t]
+            for row in gr:                               # every returned row IS one of this frame's detections
+                assert (np.abs(d[:, 1:5] - row[0:4]).max(1) == 0).any()
+            rows_total += len(gi)
+    return rows_total
+
+
+def test_many_short_sequences_equal_the_host_tracker(cuda):
+    T, M = 48, 32
+    streams = [synthetic_detection_stream(100 + s, T=T - (s % 5) * 6, K=4 + s % 4, occlusion=(1, 10 + s % 7, 16 + s % 7),
+                                          duplicates=(s % 2 == 0)) for s in range(24)]
+    ref = host_reference(streams, T, SHIPPED, M)
+    gpu = run_batched(streams, T, SHIPPED, M, 64, cuda)
+    assert compare(gpu, ref, streams) > 24 * 20 * 3
+
+
+def test_dense_sequence_shipped_and_stress_thresholds(cuda):
+    """Hundreds of detections per frame (a random-weight head): 400 x 400 assignments with the stress thresholds."""
+    rng = np.random.RandomState(7)
+    T, n_det = 12, 300
+    pos = rng.uniform([20, 20], [1260, 700], (n_det, 2))
+    vel = rng.uniform(-2, 2, (n_det, 2))
+    size = rng.uniform(12, 60, (n_det, 2))
+    score = rng.uniform(0.01, 0.9, n_det) ** 2
+    rows = []
+    for t in range(T):
+        p = pos + vel * t + rng.normal(0, 0.5, (n_det, 2))
+        keep = rng.uniform(size=n_det) > 0.1
+        b = np.concatenate([p - size / 2, p + size / 2], 1)[keep].astype(np.float32)
+        sc = (score[keep] + rng.normal(0, 0.005, keep.sum())).clip(0.011, 0.99).astype(np.float32)
+        order = np.argsort(-sc, kind='stable')           # detections arrive in score order
+        for i in order:
+            rows.append([t, *b[i], sc[i], 20.0, 1.5])
+    stream = np.asarray(rows, np.float32)
+    for cfg in (SHIPPED, dict(SHIPPED, obj_score_thr=0.02, init_track_thr=0.05)):
+        ref = host_reference([stream], T, cfg, 512)
+        gpu = run_batched([stream], T, cfg, 512, 1024, cuda)
+        n = compare(gpu, ref, [stream])
+        assert n > T * 5
+    assert max(len(i) for i, _ in gpu[0]) > 150          # the stress run really tracks hundreds of objects
+
+
+def test_capacity_overflow_is_reported(cuda):
+    trk = BatchedGpuTracker(2, max_tracks=4, max_dets=8, device=cuda, **dict(SHIPPED, init_track_thr=0.1))
+    dets = torch.zeros(2, 8, 8, device=cuda)
+    for k in range(8):
+        dets[:, k, 0:4] = torch.tensor([20.0 * k, 10.0, 20.0 * k + 15, 40.0], device=cuda)
+        dets[:, k, 4] = 0.9
+    counts = torch.tensor([3, 8], dtype=torch.int32, device=cuda)       # sequence 1 starts 8 tracks > max_tracks = 4
+    with pytest.raises(RuntimeError, match='max_tracks'):
+        trk.step(torch.zeros(2, dtype=torch.int32, device=cuda), dets, counts)
+    rows, ids, n = trk.rows, trk.ids, trk.n
+    assert int(n[0]) == 3 and ids[0, :3].tolist() == [0, 1, 2] and trk.status.tolist() == [0, 1]
+    with pytest.raises(ValueError):
+        trk.step(torch.zeros(2, dtype=torch.int64, device=cuda), dets, counts)
