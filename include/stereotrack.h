@@ -277,6 +277,11 @@ typedef struct StDecodeDesc {
   int nms_mask_rows;      /* candidates (in score order) whose pairwise IoU bits are precomputed chip-wide;
                            * 0 = default 4096.  Sizes the workspace (rows^2 / 8 bytes per image); later
                            * candidates are resolved on the fly by one wave - results do not depend on it */
+  int num_classes;        /* 0 / 1: one class (the shipped config).  2..3: head rows carry num_classes class logits
+                           * (then x, y, w, h, obj); multi_label decode - every (prior, class) pair with score > thr
+                           * is a candidate, in filter_scores_and_topk's order - and class-aware NMS by mmcv
+                           * batched_nms's offset trick (boxes + label * (max coordinate + 1));
+                           * out_labels = class, out_prior_idx = prior */
 } StDecodeDesc;
 
 size_t st_decode_nms_workspace_bytes(const StDecodeDesc* d);

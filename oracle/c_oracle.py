@@ -39,8 +39,10 @@ def _p(a):
     return a.ctypes.data_as(C.c_void_p)
 
 
-def decode_nms(head, N, levels, score_thr, iou_thr, max_det, ori_shape, scale_factor=(1.0, 1.0), pad_param=None):
+def decode_nms(head, N, levels, score_thr, iou_thr, max_det, ori_shape, scale_factor=(1.0, 1.0), pad_param=None,
+               num_classes=1):
     """head: flat float32 numpy array in the product's head_out layout; levels: [(h, w, stride, float_offset)].
+    num_classes > 1: multi_label decode + class-aware NMS (oracle_decode_nms_mc).
     Returns boxes (N,max_det,4), scores, labels (int64), prior_idx (int32), counts (int32)."""
     lib = load()
     head = np.ascontiguousarray(head, dtype=np.float32)
@@ -57,10 +59,16 @@ def decode_nms(head, N, levels, score_thr, iou_thr, max_det, ori_shape, scale_fa
     pad_left = float(pad_param[2]) if pad_param is not None else 0.0
     pad_top = float(pad_param[0]) if pad_param is not None else 0.0
     f = C.c_float
-    rc = lib.oracle_decode_nms(_p(head), C.c_int(N), C.c_int(L), lh, lw, ls, lo, f(score_thr), f(iou_thr),
-                               C.c_int(max_det), f(scale_factor[0]), f(scale_factor[1]), f(pad_left), f(pad_top),
-                               f(ori_shape[1]), f(ori_shape[0]), _p(boxes), _p(scores), _p(labels), _p(prior),
-                               _p(counts))
+    if num_classes > 1:
+        rc = lib.oracle_decode_nms_mc(_p(head), C.c_int(N), C.c_int(L), lh, lw, ls, lo, f(score_thr), f(iou_thr),
+                                      C.c_int(max_det), f(scale_factor[0]), f(scale_factor[1]), f(pad_left),
+                                      f(pad_top), f(ori_shape[1]), f(ori_shape[0]), C.c_int(num_classes), _p(boxes),
+                                      _p(scores), _p(labels), _p(prior), _p(counts))
+    else:
+        rc = lib.oracle_decode_nms(_p(head), C.c_int(N), C.c_int(L), lh, lw, ls, lo, f(score_thr), f(iou_thr),
+                                   C.c_int(max_det), f(scale_factor[0]), f(scale_factor[1]), f(pad_left), f(pad_top),
+                                   f(ori_shape[1]), f(ori_shape[0]), _p(boxes), _p(scores), _p(labels), _p(prior),
+                                   _p(counts))
     if rc != 0:
         raise RuntimeError('oracle_decode_nms failed')
     return boxes, scores, labels, prior, counts

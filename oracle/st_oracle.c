@@ -59,7 +59,7 @@ float oracle_sigmoidf(float x) { return st_sigmoidf(x); }
 
 typedef struct {
   float score;
-  int32_t prior;
+  int32_t prior; /* flat index prior * nc + class: filter_scores_and_topk's nonzero() order */
   float box[4];
 } Cand;
 
@@ -85,6 +85,95 @@ static int cand_cmp(const void* a, const void* b) {
  *   clamp x to [0, ori_w], y to [0, ori_h]; no max_per_img truncation in yolox_style
  * out_count[n] is the number kept; only the first max_det are stored.
  */
+/* Several classes (nc = 2..3; head row = nc class logits, x, y, w, h, obj): multi_label decode - every (prior, class)
+ * pair with sigmoid(cls_c) * sigmoid(obj) > score_thr is a candidate, ties in nonzero() order (prior-major) - and
+ * class-aware NMS as mmcv batched_nms does it [upstream-memory, mmcv 2.0.0rc3]: the IoU is taken on
+ * boxes + label * (boxes.max() + 1) (fp32), so boxes of different classes never overlap and same-class pairs see the
+ * coordinates AFTER the offset addition rounded them.  nc <= 1: the single-class path above, unchanged. */
+int oracle_decode_nms_mc(const float* head, int N, int num_levels, const int* lvl_h, const int* lvl_w,
+                         const int* lvl_stride, const size_t* lvl_off, float score_thr, float iou_thr,
+                         int max_det, float scale_x, float scale_y, float pad_left, float pad_top,
+                         float ori_w, float ori_h, int nc, float* out_boxes, float* out_scores,
+                         int64_t* out_labels, int32_t* out_prior, int32_t* out_count) {
+  if (nc < 1) nc = 1;
+  if (nc + 5 > 8) return -2;
+  int P = 0;
+  for (int l = 0; l < num_levels; ++l) P += lvl_h[l] * lvl_w[l];
+  Cand* cand = (Cand*)malloc(sizeof(Cand) * (size_t)(P > 0 ? P : 1) * nc);
+  unsigned char* sup = (unsigned char*)malloc((size_t)(P > 0 ? P : 1) * nc);
+  if (!cand || !sup) { free(cand); free(sup); return -1; }
+  for (int n = 0; n < N; ++n) {
+    int K = 0, prior = 0;
+    for (int l = 0; l < num_levels; ++l) {
+      const int h = lvl_h[l], w = lvl_w[l];
+      const float s = (float)lvl_stride[l];
+      const float* base = head + lvl_off[l] + (size_t)n * h * w * 8;
+      for (int py = 0; py < h; ++py)
+        for (int px = 0; px < w; ++px, ++prior) {
+          const float* row = base + ((size_t)py * w + px) * 8;
+          const float sobj = st_sigmoidf(row[nc + 4]);
+          const float tx = row[nc] * s, ty = row[nc + 1] * s;
+          const float cx = tx + (float)px * s, cy = ty + (float)py * s;
+          const float bw = st_expf(row[nc + 2]) * s, bh = st_expf(row[nc + 3]) * s;
+          const float hw = bw / 2.0f, hh = bh / 2.0f;
+          for (int c = 0; c < nc; ++c) {
+            const float score = st_sigmoidf(row[c]) * sobj;
+            if (!(score > score_thr)) continue;
+            Cand* q = &cand[K++];
+            q->score = score;
+            q->prior = prior * nc + c;
+            q->box[0] = ((cx - hw) - pad_left) / scale_x;
+            q->box[1] = ((cy - hh) - pad_top) / scale_y;
+            q->box[2] = ((cx + hw) - pad_left) / scale_x;
+            q->box[3] = ((cy + hh) - pad_top) / scale_y;
+          }
+        }
+    }
+    float maxc = -INFINITY;
+    for (int i = 0; i < K; ++i)
+      for (int e = 0; e < 4; ++e) maxc = fmaxf(maxc, cand[i].box[e]);
+    qsort(cand, (size_t)K, sizeof(Cand), cand_cmp);
+    memset(sup, 0, (size_t)(K > 0 ? K : 1));
+    int kept = 0;
+    for (int i = 0; i < K; ++i) {
+      if (sup[i]) continue;
+      const float* bo = cand[i].box;
+      const float offi = nc > 1 ? (float)(cand[i].prior % nc) * (maxc + 1.0f) : 0.0f;
+      float bi[4];
+      for (int e = 0; e < 4; ++e) bi[e] = nc > 1 ? bo[e] + offi : bo[e];
+      if (kept < max_det) {
+        float* ob = out_boxes + ((size_t)n * max_det + kept) * 4;
+        ob[0] = fminf(fmaxf(bo[0], 0.0f), ori_w);
+        ob[1] = fminf(fmaxf(bo[1], 0.0f), ori_h);
+        ob[2] = fminf(fmaxf(bo[2], 0.0f), ori_w);
+        ob[3] = fminf(fmaxf(bo[3], 0.0f), ori_h);
+        out_scores[(size_t)n * max_det + kept] = cand[i].score;
+        out_labels[(size_t)n * max_det + kept] = cand[i].prior % nc;
+        out_prior[(size_t)n * max_det + kept] = cand[i].prior / nc;
+      }
+      ++kept;
+      const float ai = (bi[2] - bi[0]) * (bi[3] - bi[1]);
+      for (int j = i + 1; j < K; ++j) {
+        if (sup[j]) continue;
+        const float offj = nc > 1 ? (float)(cand[j].prior % nc) * (maxc + 1.0f) : 0.0f;
+        float bj[4];
+        for (int e = 0; e < 4; ++e) bj[e] = nc > 1 ? cand[j].box[e] + offj : cand[j].box[e];
+        const float aj = (bj[2] - bj[0]) * (bj[3] - bj[1]);
+        const float xx1 = fmaxf(bi[0], bj[0]), yy1 = fmaxf(bi[1], bj[1]);
+        const float xx2 = fminf(bi[2], bj[2]), yy2 = fminf(bi[3], bj[3]);
+        const float w = fmaxf(0.0f, xx2 - xx1), h = fmaxf(0.0f, yy2 - yy1);
+        const float inter = w * h;
+        const float ovr = inter / ((ai + aj) - inter);
+        if (ovr > iou_thr) sup[j] = 1;
+      }
+    }
+    out_count[n] = kept;
+  }
+  free(cand);
+  free(sup);
+  return 0;
+}
+
 int oracle_decode_nms(const float* head, int N, int num_levels, const int* lvl_h, const int* lvl_w,
                       const int* lvl_stride, const size_t* lvl_off, float score_thr, float iou_thr,
                       int max_det, float scale_x, float scale_y, float pad_left, float pad_top,

@@ -59,7 +59,7 @@ class StDecodeDesc(C.Structure):
         ('level_offset', C.c_size_t * 4),
         ('score_thr', C.c_float), ('iou_thr', C.c_float), ('max_det', C.c_int),
         ('scale_x', C.c_float), ('scale_y', C.c_float), ('pad_left', C.c_float), ('pad_top', C.c_float),
-        ('ori_w', C.c_float), ('ori_h', C.c_float), ('nms_mask_rows', C.c_int),
+        ('ori_w', C.c_float), ('ori_h', C.c_float), ('nms_mask_rows', C.c_int), ('num_classes', C.c_int),
     ]
 
 

@@ -10,12 +10,16 @@
 // hardware approximation) and oracle/st_oracle.c performs the identical sequence on the CPU.
 //
 // Pipeline (4 launches + 1 memset, all sizes read from device memory):
-//   1 decode_filter : per prior: score = sigmoid(cls)*sigmoid(obj), box decode, rescale;
+//   1 decode_filter : per prior (and class: multi_label when num_classes > 1, filter_scores_and_topk's
+//                     (prior, class) pairs): score = sigmoid(cls)*sigmoid(obj), box decode, rescale;
 //                     wave-aggregated append of candidates with score > thr
 //   2 rank_sort     : rank_i = #{j : key_j > key_i}, key = (score bits, ~prior index) -> a
 //                     permutation = stable sort by score desc, prior index asc; O(K^2) compares
 //                     spread over the chip (K is a few hundred in practice, <= 19320)
-//   3 nms_mask      : 64x64 tiles of IoU > thr bits (upper triangle), one wave per tile
+//   3 nms_mask      : 64x64 tiles of IoU > thr bits (upper triangle), one wave per tile; with several classes
+//                     the IoU is taken on boxes + label * (max coordinate + 1), mmcv batched_nms's offset trick
+//                     (boxes of different classes never overlap; same-class pairs see the rounding the
+//                     offset addition causes there, too)
 //   4 nms_reduce    : one wave per image walks the 64-box chunks in score order, resolves the
 //                     diagonal tile serially on a 64-bit word, ORs kept rows into the
 //                     `removed` bitmap, emits kept boxes (clamped) in score order
@@ -60,6 +64,8 @@ struct DecodeArgs {
                      // are resolved on the fly by the reduce kernel (identical results, slower)
   int Tm;            // mcap / 64: mask words per row
   int batch;
+  int nc;            // classes (head row = nc class logits, x, y, w, h, obj; nc + 5 <= 8)
+  int cand_cap;      // P * nc: rows of the candidate arrays
   float score_thr, iou_thr;
   int max_det;
   float scale_x, scale_y, pad_left, pad_top, ori_w, ori_h;
@@ -71,13 +77,13 @@ struct DecodeArgs {
   float* s_score;    // [N][cap]
   int* s_idx;        // [N][cap]
   u64* mask;         // [N][mcap][Tm]
+  float* maxc;       // [N] largest coordinate over the candidates' boxes (class offsets; nc > 1 only)
 };
 
 __global__ __launch_bounds__(256) void decode_filter_kernel(DecodeArgs a) {
   const int n = blockIdx.y;
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
-  bool valid = false;
-  float score = 0.f;
+  float logit[3] = {0.f, 0.f, 0.f}, obj = 0.f;
   f32x4 box = {0.f, 0.f, 0.f, 0.f};
   if (p < a.P) {
     int l = 0;
@@ -87,31 +93,38 @@ __global__ __launch_bounds__(256) void decode_filter_kernel(DecodeArgs a) {
     const int py = q / w, px = q - py * w;
     const float s = (float)a.lvl_stride[l];
     const float* row = a.head + a.lvl_off[l] + ((size_t)n * hw + q) * 8;
-    const f32x4 v0 = *reinterpret_cast<const f32x4*>(row);      // cls, x, y, w
-    const f32x4 v1 = *reinterpret_cast<const f32x4*>(row + 4);  // h, obj, -, -
-    score = st_sigmoidf(v0[0]) * st_sigmoidf(v1[1]);
-    const float cx = v0[1] * s + (float)px * s;
-    const float cy = v0[2] * s + (float)py * s;
-    const float bw = st_expf(v0[3]) * s;
-    const float bh = st_expf(v1[0]) * s;
+    const f32x4 v0 = *reinterpret_cast<const f32x4*>(row);      // nc = 1: cls, x, y, w | h, obj, -, -
+    const f32x4 v1 = *reinterpret_cast<const f32x4*>(row + 4);
+    const float r8[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+    const int nc = a.nc;
+    for (int c = 0; c < nc; ++c) logit[c] = r8[c];
+    obj = r8[nc + 4];
+    const float cx = r8[nc] * s + (float)px * s;
+    const float cy = r8[nc + 1] * s + (float)py * s;
+    const float bw = st_expf(r8[nc + 2]) * s;
+    const float bh = st_expf(r8[nc + 3]) * s;
     const float hw2 = bw / 2.0f, hh2 = bh / 2.0f;
     box[0] = ((cx - hw2) - a.pad_left) / a.scale_x;
     box[1] = ((cy - hh2) - a.pad_top) / a.scale_y;
     box[2] = ((cx + hw2) - a.pad_left) / a.scale_x;
     box[3] = ((cy + hh2) - a.pad_top) / a.scale_y;
-    valid = score > a.score_thr;
   }
-  const u64 ballot = __ballot(valid);
-  if (ballot == 0) return;
+  const float sobj = st_sigmoidf(obj);
   const int lane = threadIdx.x & 63;
-  int base = 0;
-  if (lane == __builtin_ctzll(ballot)) base = atomicAdd(&a.count[n], __builtin_popcountll(ballot));
-  base = __shfl(base, __builtin_ctzll(ballot));
-  if (valid) {
-    const int pos = base + __builtin_popcountll(ballot & ((1ull << lane) - 1ull));
-    a.cand_key[(size_t)n * a.P + pos] =
-        ((u64)__float_as_uint(score) << 32) | (u64)(0xFFFFFFFFu - (unsigned)p);
-    a.cand_box[(size_t)n * a.P + pos] = box;
+  for (int c = 0; c < a.nc; ++c) {   // uniform trip count
+    const float score = st_sigmoidf(logit[c]) * sobj;
+    const bool valid = p < a.P && score > a.score_thr;
+    const u64 ballot = __ballot(valid);
+    if (ballot == 0) continue;
+    int base = 0;
+    if (lane == __builtin_ctzll(ballot)) base = atomicAdd(&a.count[n], __builtin_popcountll(ballot));
+    base = __shfl(base, __builtin_ctzll(ballot));
+    if (valid) {
+      const int pos = base + __builtin_popcountll(ballot & ((1ull << lane) - 1ull));
+      const unsigned flat = (unsigned)p * (unsigned)a.nc + (unsigned)c;   // filter_scores_and_topk's nonzero() order
+      a.cand_key[(size_t)n * a.cand_cap + pos] = ((u64)__float_as_uint(score) << 32) | (u64)(0xFFFFFFFFu - flat);
+      a.cand_box[(size_t)n * a.cand_cap + pos] = box;
+    }
   }
 }
 
@@ -119,8 +132,23 @@ __global__ __launch_bounds__(256) void rank_sort_kernel(DecodeArgs a) {
   __shared__ u64 skeys[256];
   const int n = blockIdx.y;
   const int K = a.count[n];
-  const u64* keys = a.cand_key + (size_t)n * a.P;
-  const f32x4* boxes = a.cand_box + (size_t)n * a.P;
+  const u64* keys = a.cand_key + (size_t)n * a.cand_cap;
+  const f32x4* boxes = a.cand_box + (size_t)n * a.cand_cap;
+  if (a.nc > 1 && blockIdx.x == 0) {   // boxes.max() over the candidates (mmcv batched_nms: max_coordinate)
+    __shared__ float smax[256];
+    float m = -__builtin_inff();
+    for (int i = threadIdx.x; i < K; i += 256) {
+      const f32x4 b = boxes[i];
+      m = fmaxf(m, fmaxf(fmaxf(b[0], b[1]), fmaxf(b[2], b[3])));
+    }
+    smax[threadIdx.x] = m;
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+      if ((int)threadIdx.x < st) smax[threadIdx.x] = fmaxf(smax[threadIdx.x], smax[threadIdx.x + st]);
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) a.maxc[n] = smax[0];
+  }
   for (int i0 = blockIdx.x * 256; i0 < K; i0 += gridDim.x * 256) {
     const int i = i0 + threadIdx.x;
     const u64 ki = i < K ? keys[i] : 0ull;
@@ -152,6 +180,15 @@ __device__ __forceinline__ bool iou_gt(const f32x4& bi, float ai, const f32x4& b
   return ovr > thr;
 }
 
+// the box NMS compares: boxes + label * (max_coordinate + 1) when there are several classes (label = flat % nc)
+__device__ __forceinline__ f32x4 nms_box(const DecodeArgs& a, int n, int i, f32x4 b) {
+  if (a.nc > 1) {
+    const float off = (float)(a.s_idx[(size_t)n * a.cap + i] % a.nc) * (a.maxc[n] + 1.0f);
+    b[0] = b[0] + off; b[1] = b[1] + off; b[2] = b[2] + off; b[3] = b[3] + off;
+  }
+  return b;
+}
+
 __global__ __launch_bounds__(256) void nms_mask_kernel(DecodeArgs a) {
   const int n = blockIdx.y;
   const int K = min(min(a.count[n], a.cap), a.mcap);   // the mask covers the first mcap candidates
@@ -165,8 +202,8 @@ __global__ __launch_bounds__(256) void nms_mask_kernel(DecodeArgs a) {
     if (tj < ti) continue;  // wave-uniform
     const int j = tj * 64 + lane, i = ti * 64 + lane;
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-    const f32x4 bj = j < K ? boxes[j] : zero;  // column box of this lane, broadcast by readlane
-    const f32x4 bi = i < K ? boxes[i] : zero;
+    const f32x4 bj = j < K ? nms_box(a, n, j, boxes[j]) : zero;  // column box of this lane, broadcast by readlane
+    const f32x4 bi = i < K ? nms_box(a, n, i, boxes[i]) : zero;
     const float ai = (bi[2] - bi[0]) * (bi[3] - bi[1]);
     const int jn = min(64, K - tj * 64);
     u64 bits = 0;
@@ -202,7 +239,8 @@ __global__ __launch_bounds__(64) void nms_reduce_kernel(DecodeArgs a, float* out
     u64 rem = removed[c];
     const int i = c * 64 + lane;
     const int nb = min(64, K - c * 64);
-    const f32x4 bi = i < K ? boxes[i] : zero;
+    const f32x4 bo = i < K ? boxes[i] : zero;                  // the box that is returned
+    const f32x4 bi = i < K ? nms_box(a, n, i, bo) : zero;      // the box NMS compares
     const float ai = (bi[2] - bi[0]) * (bi[3] - bi[1]);
     u64 d = 0ull;
     if (c < Tm) {
@@ -235,7 +273,7 @@ __global__ __launch_bounds__(64) void nms_reduce_kernel(DecodeArgs a, float* out
     // column chunks the mask does not cover: lane = column, the kept rows of this chunk are broadcast one by one
     for (int w = max(c + 1, Tm); w < T; ++w) {   // wave-uniform
       const int j = w * 64 + lane;
-      const f32x4 bj = j < K ? boxes[j] : zero;
+      const f32x4 bj = j < K ? nms_box(a, n, j, boxes[j]) : zero;
       bool sup = false;
       u64 kk = keep;
       while (kk) {
@@ -253,21 +291,23 @@ __global__ __launch_bounds__(64) void nms_reduce_kernel(DecodeArgs a, float* out
       const int pos = outcount + __builtin_popcountll(keep & ((1ull << lane) - 1ull));
       if (pos < a.max_det) {
         f32x4 o;
-        o[0] = fminf(fmaxf(bi[0], 0.0f), a.ori_w);
-        o[1] = fminf(fmaxf(bi[1], 0.0f), a.ori_h);
-        o[2] = fminf(fmaxf(bi[2], 0.0f), a.ori_w);
-        o[3] = fminf(fmaxf(bi[3], 0.0f), a.ori_h);
+        o[0] = fminf(fmaxf(bo[0], 0.0f), a.ori_w);
+        o[1] = fminf(fmaxf(bo[1], 0.0f), a.ori_h);
+        o[2] = fminf(fmaxf(bo[2], 0.0f), a.ori_w);
+        o[3] = fminf(fmaxf(bo[3], 0.0f), a.ori_h);
         const size_t oo = (size_t)n * a.max_det + pos;
         *reinterpret_cast<f32x4*>(out_boxes + oo * 4) = o;
         out_scores[oo] = scores[i];
-        out_labels[oo] = 0;
-        out_prior[oo] = idx[i];
+        out_labels[oo] = idx[i] % a.nc;
+        out_prior[oo] = idx[i] / a.nc;
       }
     }
     outcount += __builtin_popcountll(keep);
     __syncthreads();
   }
-  if (lane == 0) out_count[n] = outcount;
+  // more candidates than the NMS handles (only possible with several classes): reported as an overflow nobody can
+  // mistake for a count (every consumer treats count > max_det as an error)
+  if (lane == 0) out_count[n] = a.count[n] > a.cap ? 0x7FFFFFFF : outcount;
   // rows past the count are DEFINED by this kernel (zero boxes / scores / labels, prior index -1): the caller's
   // output buffers are persistent and need no clearing launch per batch
   const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
@@ -281,8 +321,8 @@ __global__ __launch_bounds__(64) void nms_reduce_kernel(DecodeArgs a, float* out
 }
 
 struct DecodeLayout {
-  size_t count, cand_key, cand_box, s_box, s_score, s_idx, mask, total;
-  int P, cap, mcap, Tm;
+  size_t count, cand_key, cand_box, s_box, s_score, s_idx, mask, maxc, total;
+  int P, cap, mcap, Tm, nc, cand_cap;
 };
 
 static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
@@ -297,10 +337,16 @@ static int decode_layout(const StDecodeDesc& d, DecodeLayout& L) {
     ST_REQUIRE(d.level_h[l] > 0 && d.level_w[l] > 0 && d.level_stride[l] > 0, "st_decode_nms: bad level %d", l);
     P += (long long)d.level_h[l] * d.level_w[l];
   }
-  ST_REQUIRE(P < (1 << 30), "st_decode_nms: too many priors");
+  ST_REQUIRE(P < (1 << 28), "st_decode_nms: too many priors");
+  L.nc = d.num_classes > 0 ? d.num_classes : 1;
+  ST_REQUIRE(L.nc + 5 <= 8, "st_decode_nms: num_classes must be in [1, 3] (head row = 8 floats)");
   L.P = (int)P;
-  L.cap = L.P;  // nms_pre default (100000) >= priors: every candidate enters NMS
-  ST_REQUIRE((L.cap + 63) / 64 <= 512, "st_decode_nms: more than 32768 candidates per image not supported");
+  L.cand_cap = L.P * L.nc;      // (prior, class) pairs (multi_label; one class: the priors)
+  // nms_pre default (100000) >= priors: every candidate enters NMS.  The reduce kernel's LDS bitmap holds 32768
+  // candidates: one class never exceeds it at the supported sizes; with several classes more than 32768 pairs above
+  // score_thr in one image are reported as an overflow (count = INT_MAX), never dropped silently
+  ST_REQUIRE(L.nc > 1 || (L.P + 63) / 64 <= 512, "st_decode_nms: more than 32768 candidates per image not supported");
+  L.cap = std::min(L.cand_cap, 32768);
   // IoU bit mask for the first `mcap` candidates in score order (a few hundred to a few thousand pass the score
   // threshold in practice); later candidates are resolved on the fly: the workspace no longer grows with P^2
   ST_REQUIRE(d.nms_mask_rows >= 0, "st_decode_nms: nms_mask_rows must be >= 0");
@@ -308,12 +354,13 @@ static int decode_layout(const StDecodeDesc& d, DecodeLayout& L) {
   L.Tm = L.mcap / 64;
   size_t o = 0;
   L.count = o; o = align256(o + sizeof(int) * d.batch);
-  L.cand_key = o; o = align256(o + sizeof(u64) * (size_t)d.batch * L.P);
-  L.cand_box = o; o = align256(o + sizeof(f32x4) * (size_t)d.batch * L.P);
+  L.cand_key = o; o = align256(o + sizeof(u64) * (size_t)d.batch * L.cand_cap);
+  L.cand_box = o; o = align256(o + sizeof(f32x4) * (size_t)d.batch * L.cand_cap);
   L.s_box = o; o = align256(o + sizeof(f32x4) * (size_t)d.batch * L.cap);
   L.s_score = o; o = align256(o + sizeof(float) * (size_t)d.batch * L.cap);
   L.s_idx = o; o = align256(o + sizeof(int) * (size_t)d.batch * L.cap);
   L.mask = o; o = align256(o + sizeof(u64) * (size_t)d.batch * L.mcap * L.Tm);
+  L.maxc = o; o = align256(o + sizeof(float) * (size_t)d.batch);
   L.total = o;
   return ST_OK;
 }
@@ -352,7 +399,7 @@ extern "C" int st_decode_nms(const StDecodeDesc* d, const float* head_out_dev, v
     start += d->level_h[l] * d->level_w[l];
   }
   a.lvl_start[d->num_levels] = start;
-  a.P = L.P; a.cap = L.cap; a.mcap = L.mcap; a.Tm = L.Tm; a.batch = d->batch;
+  a.P = L.P; a.cap = L.cap; a.mcap = L.mcap; a.Tm = L.Tm; a.batch = d->batch; a.nc = L.nc; a.cand_cap = L.cand_cap;
   a.score_thr = d->score_thr; a.iou_thr = d->iou_thr; a.max_det = d->max_det;
   a.scale_x = d->scale_x; a.scale_y = d->scale_y; a.pad_left = d->pad_left; a.pad_top = d->pad_top;
   a.ori_w = d->ori_w; a.ori_h = d->ori_h;
@@ -363,10 +410,11 @@ extern "C" int st_decode_nms(const StDecodeDesc* d, const float* head_out_dev, v
   a.s_score = reinterpret_cast<float*>(ws + L.s_score);
   a.s_idx = reinterpret_cast<int*>(ws + L.s_idx);
   a.mask = reinterpret_cast<u64*>(ws + L.mask);
+  a.maxc = reinterpret_cast<float*>(ws + L.maxc);
 
   ST_CHECK_HIP(hipMemsetAsync(a.count, 0, sizeof(int) * d->batch, stream));
   hipLaunchKernelGGL(decode_filter_kernel, dim3((L.P + 255) / 256, d->batch), dim3(256), 0, stream, a);
-  hipLaunchKernelGGL(rank_sort_kernel, dim3(std::min(64, (L.P + 255) / 256), d->batch), dim3(256), 0, stream, a);
+  hipLaunchKernelGGL(rank_sort_kernel, dim3(std::min(64, (L.cand_cap + 255) / 256), d->batch), dim3(256), 0, stream, a);
   hipLaunchKernelGGL(nms_mask_kernel, dim3(128, d->batch), dim3(256), 0, stream, a);
   hipLaunchKernelGGL(nms_reduce_kernel, dim3(d->batch), dim3(64), 0, stream, a, out_boxes_dev, out_scores_dev,
                      reinterpret_cast<long long*>(out_labels_dev), out_prior_idx_dev, out_count_dev);

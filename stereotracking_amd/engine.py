@@ -189,6 +189,7 @@ class HipDetector:
         d.pad_top = float(pad_param[0]) if pad_param is not None else 0.0
         d.ori_h, d.ori_w = float(ori_shape[0]), float(ori_shape[1])
         d.nms_mask_rows = int(nms_mask_rows)
+        d.num_classes = self.num_classes
         return d
 
     def decode_nms(self, head_out, score_thr=0.01, iou_thr=0.5, max_det=1000, ori_shape=None,

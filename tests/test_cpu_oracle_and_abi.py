@@ -237,3 +237,99 @@ def test_oracle_detector_golden():
         assert r.shape == ref.shape
         # same code, same seeds: only the BLAS/oneDNN summation order may differ between hosts
         assert np.abs(r.numpy() - ref).max() <= 1e-4 * max(1.0, np.abs(ref).max())
+
+
+def torch_decode_nms_multiclass(head, N, levels, score_thr, iou_thr, ori_shape, nc):
+    """Independent torch formulation of the multi-class path [upstream-memory: mmyolo predict_by_feat with
+    multi_label=True, mmdet filter_scores_and_topk, mmcv batched_nms offset trick]."""
+    outs = []
+    for n in range(N):
+        rows, priors, strides = [], [], []
+        for h, w, s, off in levels:
+            r = torch.from_numpy(head[off:off + N * h * w * 8].reshape(N, h * w, 8)[n])
+            ys, xs = torch.meshgrid(torch.arange(h), torch.arange(w), indexing='ij')
+            priors.append(torch.stack([xs.reshape(-1) * s, ys.reshape(-1) * s], -1).float())
+            strides.append(torch.full((h * w,), float(s)))
+            rows.append(r)
+        r, p, s = torch.cat(rows), torch.cat(priors), torch.cat(strides)
+        scores = torch.sigmoid(r[:, :nc]) * torch.sigmoid(r[:, nc + 4:nc + 5])        # (P, nc)
+        xy = r[:, nc:nc + 2] * s[:, None] + p
+        wh = r[:, nc + 2:nc + 4].exp() * s[:, None]
+        boxes = torch.cat([xy - wh / 2, xy + wh / 2], -1)
+        valid = torch.nonzero(scores > score_thr)                                      # row-major (prior, class)
+        sc = scores[valid[:, 0], valid[:, 1]]
+        order = torch.sort(sc, descending=True, stable=True)[1]
+        pri, lab, sc = valid[order, 0], valid[order, 1], sc[order]
+        b = boxes[pri]
+        bo = b + (lab.float() * (b.max() + 1.0))[:, None] if len(b) else b             # batched_nms offsets
+        area = (bo[:, 2] - bo[:, 0]) * (bo[:, 3] - bo[:, 1])
+        keep, sup = [], torch.zeros(len(pri), dtype=torch.bool)
+        for i in range(len(pri)):
+            if sup[i]:
+                continue
+            keep.append(i)
+            lt = torch.max(bo[i, :2], bo[i + 1:, :2])
+            rb = torch.min(bo[i, 2:], bo[i + 1:, 2:])
+            wh_ = (rb - lt).clamp(min=0)
+            inter = wh_[:, 0] * wh_[:, 1]
+            sup[i + 1:] |= inter / (area[i] + area[i + 1:] - inter) > iou_thr
+        kb = b[keep].clone()
+        kb[:, 0::2] = kb[:, 0::2].clamp(0, ori_shape[1])
+        kb[:, 1::2] = kb[:, 1::2].clamp(0, ori_shape[0])
+        outs.append((pri[keep].numpy(), lab[keep].numpy(), kb.numpy(), sc[keep].numpy()))
+    return outs
+
+
+@pytest.mark.parametrize('nc', [2, 3])
+def test_oracle_multiclass_decode_nms_matches_torch_formulation(nc):
+    """num_classes 2..3 (rows = class logits, x, y, w, h, obj): multi_label candidates in (prior, class) order,
+    class-aware NMS on offset boxes; the same priors / labels / order as the independent torch formulation, floats to
+    1e-5 (libm vs the oracle's polynomial exp); and with ONE class the multi-class entry equals the single-class one."""
+    rng = np.random.RandomState(30 + nc)
+    N, H, W = 2, 96, 160
+    levels, off = [], 0
+    for s_ in (8, 16, 32):
+        levels.append((H // s_, W // s_, s_, off))
+        off += N * (H // s_) * (W // s_) * 8
+    head = np.zeros(off, np.float32)
+    for h, w, s_, o in levels:
+        rows = head[o:o + N * h * w * 8].reshape(N, h * w, 8)
+        rows[..., :nc] = rng.normal(-1.5, 2.0, rows.shape[:2] + (nc,))
+        rows[..., nc:nc + 2] = rng.normal(0, 1.0, rows.shape[:2] + (2,))
+        rows[..., nc + 2:nc + 4] = rng.normal(0.6, 0.7, rows.shape[:2] + (2,))
+        rows[..., nc + 4] = rng.normal(-1.0, 2.0, rows.shape[:2])
+    # exact duplicates within and across classes: ties in score (order = prior, then class) and IoU == 1
+    r0 = head[:N * levels[0][0] * levels[0][1] * 8].reshape(N, -1, 8)
+    r0[0, 5] = r0[0, 4]
+    r0[0, 7, :nc] = r0[0, 7, 0]
+    M = 600
+    b, sc, lab, pri, cnt = c_oracle.decode_nms(head, N, levels, 0.05, 0.5, M, (H - 6, W), num_classes=nc)
+    ref = torch_decode_nms_multiclass(head, N, levels, 0.05, 0.5, (H - 6, W), nc)
+    assert cnt.min() > 30 and len(set(lab[0, :cnt[0]].tolist())) == nc
+    for n in range(N):
+        k = int(cnt[n])
+        assert k == len(ref[n][0]) <= M
+        assert np.array_equal(pri[n, :k], ref[n][0]) and np.array_equal(lab[n, :k], ref[n][1])
+        assert np.abs(b[n, :k] - ref[n][2]).max() < 1e-3 and np.abs(sc[n, :k] - ref[n][3]).max() < 1e-5
+        assert np.all(np.diff(sc[n, :k]) <= 0)
+    # one class through the multi-class entry == the single-class path
+    one = np.zeros_like(head)
+    for h, w, s_, o in levels:
+        src = head[o:o + N * h * w * 8].reshape(N, h * w, 8)
+        dst = one[o:o + N * h * w * 8].reshape(N, h * w, 8)
+        dst[..., 0] = src[..., 0]
+        dst[..., 1:6] = src[..., nc:nc + 5]
+    a = c_oracle.decode_nms(one, N, levels, 0.05, 0.5, M, (H - 6, W))
+    lib = c_oracle.load()
+    import ctypes as C
+    L = len(levels)
+    arr = lambda t, v: (t * L)(*v)
+    bb, ss, ll, pp, cc = (np.zeros((N, M, 4), np.float32), np.zeros((N, M), np.float32), np.zeros((N, M), np.int64),
+                          np.full((N, M), -1, np.int32), np.zeros(N, np.int32))
+    f = C.c_float
+    ptr_ = lambda x: x.ctypes.data_as(C.c_void_p)
+    rc = lib.oracle_decode_nms_mc(ptr_(one), C.c_int(N), C.c_int(L), arr(C.c_int, [l[0] for l in levels]),
+                                  arr(C.c_int, [l[1] for l in levels]), arr(C.c_int, [l[2] for l in levels]),
+                                  arr(C.c_size_t, [l[3] for l in levels]), f(0.05), f(0.5), C.c_int(M), f(1), f(1), f(0),
+                                  f(0), f(W), f(H - 6), C.c_int(1), ptr_(bb), ptr_(ss), ptr_(ll), ptr_(pp), ptr_(cc))
+    assert rc == 0 and np.array_equal(cc, a[4]) and np.array_equal(pp, a[3]) and np.array_equal(bb, a[0])
