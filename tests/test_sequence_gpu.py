@@ -220,3 +220,26 @@ def test_config2_full_size_64_frame_sequence(cuda):
     os.makedirs('gpurun_out', exist_ok=True)
     json.dump(rec, open('gpurun_out/r03_config2.json', 'w'), indent=1)
     print(rec)
+
+
+def test_video_replica_driver_with_metrics(cuda):
+    """The reference's multi-GPU mode (whole videos per rank, video_sampler.py:25-70; evaluation gathers,
+    mot_drone_metrics.py:336-358) at world size 1 on the GPU: three short videos through the dense path + a fresh
+    tracker per video, MOTChallenge rows collected and scored; a second pass over the same videos gives the same
+    tracks (the uploader and the pipeline carry no state between videos).  (World 2: tests/test_cpu_metrics.py.)"""
+    from stereotracking_amd.metrics import MOTDroneMetrics
+    from stereotracking_amd.sequence import run_video_replicas
+    pipe, _ = make_pipe(4)
+    videos = {f'seq{i}': list(synthetic_sequence(5 + i, 3, 80, 160, 32, seed=20 + i)) for i in range(3)}
+    gts = {name: [[dict(instance_id=int(g[0]), bbox=[float(v) for v in g[1:5]], location=[0, 0, float(g[5])])
+                   for g in f['gt']] for f in frames] for name, frames in videos.items()}
+    m = MOTDroneMetrics(depth_thr=80)
+    res, scores = run_video_replicas(pipe, videos, make_tracker, _Model(), cuda, metrics=m, gts=gts)
+    assert sorted(res) == ['seq0', 'seq1', 'seq2'] and [len(res[f'seq{i}']) for i in range(3)] == [5, 6, 7]
+    assert sum(len(t) for r in res.values() for t in r) > 0
+    assert set(scores['per_video']) == set(videos) and 0.0 <= scores['combined']['IDF1'] <= 1.0
+    assert scores['combined']['TP'] + scores['combined']['FN'] == sum(len(g) for v in gts.values() for g in v)
+    res2, _ = run_video_replicas(pipe, videos, make_tracker, _Model(), cuda)
+    for name in videos:
+        for a, b in zip(res[name], res2[name]):
+            assert a.instances_id.tolist() == b.instances_id.tolist() and torch.equal(a.bboxes, b.bboxes)

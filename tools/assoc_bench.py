@@ -59,3 +59,43 @@ for B in [int(a) for a in sys.argv[1:]] or [64, 256, 1024, 4096]:
     assert int(g.status.max()) == 0
     print(f'B={B:5d}: {dt / T * 1e3:7.3f} ms per step = {dt / T / B * 1e6:7.3f} us per sequence-frame '
           f'({host_us / (dt / T / B * 1e6):5.1f}x one host thread)')
+
+# ---- dense sequences: hundreds of detections per frame (random-weight head), stress thresholds -----------------------
+rng = np.random.RandomState(7)
+Td, n_det, Md = 12, 300, 512
+pos = rng.uniform([20, 20], [1260, 700], (n_det, 2)); vel = rng.uniform(-2, 2, (n_det, 2))
+size = rng.uniform(12, 60, (n_det, 2)); score = rng.uniform(0.01, 0.9, n_det) ** 2
+dd, cc = np.zeros((Td, Md, 8), np.float32), np.zeros(Td, np.int32)
+for t in range(Td):
+    p = pos + vel * t + rng.normal(0, 0.5, (n_det, 2))
+    keep = rng.uniform(size=n_det) > 0.1
+    b = np.concatenate([p - size / 2, p + size / 2], 1)[keep].astype(np.float32)
+    sc = (score[keep] + rng.normal(0, 0.005, keep.sum())).clip(0.011, 0.99).astype(np.float32)
+    o = np.argsort(-sc, kind='stable')
+    k = len(o)
+    dd[t, :k, 0:4], dd[t, :k, 4], dd[t, :k, 6], dd[t, :k, 7], cc[t] = b[o], sc[o], 20.0, 1.5, k
+STRESS = dict(CFG, obj_score_thr=0.02, init_track_thr=0.05)
+rec = np.zeros((Td, Md + 1, 13), np.float32)
+rec[:, 0, 0], rec[:, 0, 1], rec[:, 0, 2] = cc, Md, 1
+rec[:, 1:, 8:12], rec[:, 1:, 4:8] = dd[:, :, 0:4], dd[:, :, 4:8]
+trk = OCSORTTracker_Disparity(**STRESS)
+n, t0 = 0, time.perf_counter()
+while time.perf_counter() - t0 < 1.0:
+    trk.track_records(list(range(Td)), rec)
+    n += Td
+host_us = (time.perf_counter() - t0) / n * 1e6
+print(f'dense (~270 detections, ~250 tracks per frame, stress thresholds): host {host_us:.0f} us per sequence-frame')
+for B in (1, 16, 256):
+    g = BatchedGpuTracker(B, max_tracks=1024, max_dets=Md, device=dev, **STRESS)
+    dets = torch.from_numpy(np.repeat(dd[:, None], B, 1)).to(dev)
+    counts = torch.from_numpy(np.repeat(cc[:, None], B, 1)).to(dev)
+    fids = [torch.full((B,), t, dtype=torch.int32, device=dev) for t in range(Td)]
+    for rep in range(2):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for t in range(Td):
+            g.step(fids[t], dets[t], counts[t], check_status=False)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+    assert int(g.status.max()) == 0
+    print(f'  B={B:4d}: {dt / Td * 1e3:8.2f} ms per step = {dt / Td / B * 1e6:9.1f} us per sequence-frame')
