@@ -261,85 +261,147 @@ struct Lap {
     }
     return j < C ? half : 0.0;
   }
-  __device__ void reduce_columns() {
-    for (int i = 0; i < n; ++i) row_to_col[i] = -1;
-    for (int j = 0; j < n; ++j) { col_to_row[j] = 0; v[j] = kBig; }
-    for (int i = 0; i < n; ++i)
-      for (int j = 0; j < n; ++j) {
+  // ---- wave-cooperative form: every lane of the sequence's wave calls these; the O(n^2) scans run across the 64
+  // lanes with EXACTLY the comparisons' outcomes of the serial solver (csrc/lapjv.cpp) - per-column work is
+  // independent, value-only minima are order-free, and the (best, second) pair of a row scan is "lowest index of
+  // the minimum, lowest index of the second smallest value among the rest", which is what the serial update rule
+  // leaves behind (rows containing an unmatchable 1e6 sentinel fall back to the serial scan on lane 0).
+  __device__ void reduce_columns(int lane, int* ctl) {
+    for (int i = lane; i < n; i += 64) { row_to_col[i] = -1; col_to_row[i] = 0; v[i] = kBig; once[i] = 1; }
+    __syncthreads();
+    for (int j = lane; j < n; j += 64) {       // a lane owns its columns: rows in ascending order, strict <
+      double vj = kBig;
+      int cj = 0;
+      for (int i = 0; i < n; ++i) {
         const double a = at(i, j);
-        if (a < v[j]) { v[j] = a; col_to_row[j] = i; }
+        if (a < vj) { vj = a; cj = i; }
       }
-    for (int i = 0; i < n; ++i) once[i] = 1;
-    for (int j = n - 1; j >= 0; --j) {
-      const int i = col_to_row[j];
-      if (row_to_col[i] < 0) {
-        row_to_col[i] = j;
-      } else {
-        once[i] = 0;
-        col_to_row[j] = -1;
-      }
+      v[j] = vj;
+      col_to_row[j] = cj;
     }
-    n_free = 0;
+    __syncthreads();
+    if (lane == 0) {
+      for (int j = n - 1; j >= 0; --j) {
+        const int i = col_to_row[j];
+        if (row_to_col[i] < 0) {
+          row_to_col[i] = j;
+        } else {
+          once[i] = 0;
+          col_to_row[j] = -1;
+        }
+      }
+      int nf = 0;
+      for (int i = 0; i < n; ++i)
+        if (row_to_col[i] < 0) free_rows[nf++] = i;
+      n_free = nf;
+      ctl[0] = nf;
+    }
+    __syncthreads();
+    n_free = ctl[0];
+    // reduction transfer, rows in ascending order (a row's slack uses the prices the earlier rows left)
     for (int i = 0; i < n; ++i) {
-      if (row_to_col[i] < 0) {
-        free_rows[n_free++] = i;
-      } else if (once[i]) {
-        const int j = row_to_col[i];
-        double slack = kBig;
-        for (int k = 0; k < n; ++k) {
-          if (k == j) continue;
-          const double r = at(i, k) - v[k];
-          if (r < slack) slack = r;
-        }
-        v[j] -= slack;
+      const int j = row_to_col[i];
+      if (j < 0 || !once[i]) continue;          // uniform: all lanes read the same values
+      double slack = kBig;
+      for (int k = lane; k < n; k += 64) {
+        if (k == j) continue;
+        const double r = at(i, k) - v[k];
+        if (r < slack) slack = r;
+      }
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) {
+        const double o = __shfl_xor(slack, off);
+        if (o < slack) slack = o;
+      }
+      __syncthreads();
+      if (lane == 0) v[j] -= slack;
+      __syncthreads();
+    }
+  }
+  // serial row scan (the solver's own loop): used by lane 0 for rows that contain a sentinel
+  __device__ void scan_row_serial(int i, int& best, int& second, double& u1, double& u2) const {
+    best = 0; second = -1;
+    u1 = at(i, 0) - v[0]; u2 = kBig;
+    for (int j = 1; j < n; ++j) {
+      const double r = at(i, j) - v[j];
+      if (r < u2) {
+        if (r >= u1) { u2 = r; second = j; }
+        else { u2 = u1; u1 = r; second = best; best = j; }
       }
     }
   }
-  __device__ void reduce_rows() {
-    const int todo = n_free;
-    int cur = 0, kept = 0;
+  __device__ void reduce_rows(int lane, int* ctl, double* ctld) {
+    // ctl: 1 = cur, 2 = kept, 3 = todo, 4 = row i of this iteration (-1: done), 5.. scan results
+    if (lane == 0) { ctl[1] = 0; ctl[2] = 0; ctl[3] = n_free; }
     long long sweeps = 0;
-    while (cur < todo) {
+    __syncthreads();
+    while (true) {
+      if (lane == 0) ctl[4] = ctl[1] < ctl[3] ? free_rows[ctl[1]] : -1;
+      __syncthreads();
+      const int i = ctl[4];
+      if (i < 0) break;
       ++sweeps;
-      const int i = free_rows[cur++];
-      int best = 0, second = -1;
-      double u1 = at(i, 0) - v[0], u2 = kBig;
-      for (int j = 1; j < n; ++j) {
+      // parallel scan: lexicographic minimum of (r, j), then of the rest
+      double b1 = kBig * 4; int j1 = 0x7fffffff; bool sentinel = false;
+      for (int j = lane; j < n; j += 64) {
         const double r = at(i, j) - v[j];
-        if (r < u2) {
-          if (r >= u1) { u2 = r; second = j; }
-          else { u2 = u1; u1 = r; second = best; best = j; }
-        }
+        if (!(r < kBig)) sentinel = true;
+        if (r < b1 || (r == b1 && j < j1)) { b1 = r; j1 = j; }
       }
-      int owner = col_to_row[best];
-      const double lowered = v[best] - (u2 - u1);
-      const bool lowers = lowered < v[best];
-      if (sweeps < (long long)cur * n) {
-        if (lowers) {
-          v[best] = lowered;
-        } else if (owner >= 0 && second >= 0) {
-          best = second;
-          owner = col_to_row[second];
-        }
-        if (owner >= 0) {
-          if (lowers) free_rows[--cur] = owner;
-          else free_rows[kept++] = owner;
-        }
-      } else if (owner >= 0) {
-        free_rows[kept++] = owner;
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) {
+        const double ob = __shfl_xor(b1, off);
+        const int oj = __shfl_xor(j1, off);
+        if (ob < b1 || (ob == b1 && oj < j1)) { b1 = ob; j1 = oj; }
       }
-      row_to_col[i] = best;
-      col_to_row[best] = i;
+      const bool any_sentinel = __ballot(sentinel) != 0ull;
+      double b2 = kBig * 4; int j2 = 0x7fffffff;
+      for (int j = lane; j < n; j += 64) {
+        if (j == j1) continue;
+        const double r = at(i, j) - v[j];
+        if (r < b2 || (r == b2 && j < j2)) { b2 = r; j2 = j; }
+      }
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) {
+        const double ob = __shfl_xor(b2, off);
+        const int oj = __shfl_xor(j2, off);
+        if (ob < b2 || (ob == b2 && oj < j2)) { b2 = ob; j2 = oj; }
+      }
+      __syncthreads();
+      if (lane == 0) {
+        int best, second;
+        double u1, u2;
+        if (any_sentinel || n < 2) scan_row_serial(i, best, second, u1, u2);
+        else { best = j1; u1 = b1; second = j2; u2 = b2; }
+        int cur = ctl[1] + 1, kept = ctl[2];
+        int owner = col_to_row[best];
+        const double lowered = v[best] - (u2 - u1);
+        const bool lowers = lowered < v[best];
+        if (sweeps < (long long)cur * n) {
+          if (lowers) {
+            v[best] = lowered;
+          } else if (owner >= 0 && second >= 0) {
+            best = second;
+            owner = col_to_row[second];
+          }
+          if (owner >= 0) {
+            if (lowers) free_rows[--cur] = owner;
+            else free_rows[kept++] = owner;
+          }
+        } else if (owner >= 0) {
+          free_rows[kept++] = owner;
+        }
+        row_to_col[i] = best;
+        col_to_row[best] = i;
+        ctl[1] = cur; ctl[2] = kept;
+      }
+      __syncthreads();
     }
-    n_free = kept;
+    n_free = ctl[2];
+    (void)ctld;
   }
-  __device__ int shortest_path(int start) {
+  __device__ int shortest_path(int start) {   // lane 0 (the SCAN / TODO partition is order-dependent)
     int lo = 0, hi = 0, ready = 0, sink = -1;
-    for (int j = 0; j < n; ++j) {
-      cols[j] = j;
-      pred[j] = start;
-      d[j] = at(start, j) - v[j];
-    }
     while (sink < 0) {
       if (lo == hi) {
         ready = lo;
@@ -388,20 +450,32 @@ struct Lap {
     }
     return sink;
   }
-  __device__ void solve() {
-    reduce_columns();
-    for (int pass = 0; pass < 2 && n_free > 0; ++pass) reduce_rows();
+  __device__ void solve(int lane, int* ctl, double* ctld) {
+    reduce_columns(lane, ctl);
+    for (int pass = 0; pass < 2; ++pass) {
+      if (n_free <= 0) break;                    // uniform (n_free is set from ctl on every lane)
+      reduce_rows(lane, ctl, ctld);
+    }
     for (int f = 0; f < n_free; ++f) {
       const int start = free_rows[f];
-      int j = shortest_path(start);
-      int i = -1;
-      while (i != start) {
-        i = pred[j];
-        col_to_row[j] = i;
-        const int prev = row_to_col[i];
-        row_to_col[i] = j;
-        j = prev;
+      for (int j = lane; j < n; j += 64) {       // the path search's initial distances, across the lanes
+        cols[j] = j;
+        pred[j] = start;
+        d[j] = at(start, j) - v[j];
       }
+      __syncthreads();
+      if (lane == 0) {
+        int j = shortest_path(start);
+        int i = -1;
+        while (i != start) {
+          i = pred[j];
+          col_to_row[j] = i;
+          const int prev = row_to_col[i];
+          row_to_col[i] = j;
+          j = prev;
+        }
+      }
+      __syncthreads();
     }
   }
 };
@@ -500,15 +574,15 @@ __device__ void assign_stage(const Cfg& cfg, DTrack* tracks, const int* tidx, in
     s.cost[(size_t)r * Cn + c] = (double)dist;
   }
   __syncthreads();
-  if (lane == 0) {
-    Lap lap;
-    lap.cost = s.cost; lap.R = R; lap.C = Cn; lap.n = R + Cn;
-    lap.half = (1.0 - (double)cfg.match_iou_thr) / 2.0;
-    lap.v = s.v; lap.d = s.d; lap.row_to_col = s.row_to_col; lap.col_to_row = s.col_to_row;
-    lap.free_rows = s.free_rows; lap.pred = s.pred; lap.cols = s.cols; lap.once = s.once; lap.n_free = 0;
-    lap.solve();
-    for (int c = 0; c < Cn; ++c) s.d2r[c] = lap.col_to_row[c] < R ? lap.col_to_row[c] : -1;
-  }
+  __shared__ int lap_ctl[8];
+  __shared__ double lap_ctld[2];
+  Lap lap;
+  lap.cost = s.cost; lap.R = R; lap.C = Cn; lap.n = R + Cn;
+  lap.half = (1.0 - (double)cfg.match_iou_thr) / 2.0;
+  lap.v = s.v; lap.d = s.d; lap.row_to_col = s.row_to_col; lap.col_to_row = s.col_to_row;
+  lap.free_rows = s.free_rows; lap.pred = s.pred; lap.cols = s.cols; lap.once = s.once; lap.n_free = 0;
+  lap.solve(lane, lap_ctl, lap_ctld);
+  for (int c = lane; c < Cn; c += 64) s.d2r[c] = lap.col_to_row[c] < R ? lap.col_to_row[c] : -1;
   __syncthreads();
 }
 
@@ -628,17 +702,22 @@ __global__ __launch_bounds__(64) void assoc_step_kernel(Cfg cfg, const int* __re
     }
     __syncthreads();
   }
-  // BaseTracker.update: feed every output row to its track (new tracks get their slots first, serially, in order)
+  // BaseTracker.update: feed every output row to its track.  Rows [0, n_matched) are the matched detections (their
+  // track slot is known: no search by id), the rest start new tracks in fresh slots, in order.
   if (lane == 0) {
     int ntr = sh[0];
     const int n_order = sh[1];
+    const int n_matched = first ? 0 : sh[6];
     for (int i = 0; i < n_order; ++i) {
-      int k = -1;
-      for (int q = 0; q < ntr; ++q)
-        if (tracks[q].id == s.ids[i]) { k = q; break; }
-      if (k < 0) {
-        if (ntr >= T) { sh[8] = kTrackOverflow; k = -2; }
-        else { k = ntr++; tracks[k].id = -1 - (long long)i; }   // placeholder id: initialised below
+      int k;
+      if (i < n_matched) {
+        k = s.matched_trk[i];
+      } else if (ntr >= T) {
+        sh[8] = kTrackOverflow;
+        k = 0;
+      } else {
+        k = ntr++;
+        tracks[k].id = -1;   // marks a slot to initialise below
       }
       s.tidx[i] = k;
     }
@@ -659,19 +738,32 @@ __global__ __launch_bounds__(64) void assoc_step_kernel(Cfg cfg, const int* __re
     oid[i] = s.ids[i];
   }
   __syncthreads();
-  if (lane == 0) {   // pop the invalid tracks (order-preserving compaction)
+  // pop the invalid tracks: order-preserving compaction; lane 0 decides the destinations, the wave moves the records
+  if (lane == 0) {
     int w = 0;
     const int ntr = sh[0];
     for (int k = 0; k < ntr; ++k) {
       const DTrack& t = tracks[k];
       const bool drop = frame_id - t.last_frame >= cfg.num_frames_retain || (t.tentative && t.last_frame != frame_id);
-      if (!drop) {
-        if (w != k) tracks[w] = tracks[k];
-        ++w;
-      }
+      s.rest[k] = drop ? -1 : w;
+      if (!drop) ++w;
     }
     hdr->n_tracks = w;
     out_n[b] = sh[1];
+  }
+  __syncthreads();
+  {
+    constexpr int WORDS = (int)(sizeof(DTrack) / 8);
+    static_assert(sizeof(DTrack) % 8 == 0, "DTrack is moved as 8-byte words");
+    const int ntr = sh[0];
+    for (int k = 0; k < ntr; ++k) {          // ascending: a destination is never a slot that is still to be read
+      const int w = s.rest[k];
+      if (w < 0 || w == k) continue;         // uniform
+      const unsigned long long* src = reinterpret_cast<const unsigned long long*>(&tracks[k]);
+      unsigned long long* dst = reinterpret_cast<unsigned long long*>(&tracks[w]);
+      for (int e = lane; e < WORDS; e += 64) dst[e] = src[e];
+      __syncthreads();
+    }
   }
 }
 
