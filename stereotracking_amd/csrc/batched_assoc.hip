@@ -594,12 +594,28 @@ __global__ __launch_bounds__(64) void assoc_step_kernel(Cfg cfg, const int* __re
                                                         const int* __restrict__ counts, char* state_all,
                                                         size_t state_stride, char* scratch_all, size_t scratch_stride,
                                                         float* __restrict__ out_rows, long long* __restrict__ out_ids,
-                                                        int* __restrict__ out_n, int* __restrict__ status) {
+                                                        int* __restrict__ out_n, int* __restrict__ status,
+                                                        int lap_in_lds) {
   const int b = blockIdx.x, lane = threadIdx.x;
   const int T = cfg.max_tracks, M = cfg.max_dets;
   SeqHeader* hdr = reinterpret_cast<SeqHeader*>(state_all + (size_t)b * state_stride);
   DTrack* tracks = reinterpret_cast<DTrack*>(reinterpret_cast<char*>(hdr) + sizeof(SeqHeader));
   Scratch s = carve(scratch_all + (size_t)b * scratch_stride, T, M);
+  if (lap_in_lds) {   // the assignment's working arrays (37 B per row / column of the extended matrix) in LDS
+    extern __shared__ double ba_dyn[];
+    const size_t n = (size_t)T + M;
+    char* base = reinterpret_cast<char*>(ba_dyn);
+    size_t o = 0;
+    auto take = [&](size_t bytes) { char* q = base + o; o += align8(bytes); return q; };
+    s.v = (double*)take(sizeof(double) * n);
+    s.d = (double*)take(sizeof(double) * n);
+    s.row_to_col = (int*)take(sizeof(int) * n);
+    s.col_to_row = (int*)take(sizeof(int) * n);
+    s.free_rows = (int*)take(sizeof(int) * n);
+    s.pred = (int*)take(sizeof(int) * n);
+    s.cols = (int*)take(sizeof(int) * n);
+    s.once = take(n);
+  }
   const float* dets = dets_all + (size_t)b * M * 8;
   const int frame_id = frame_ids[b];
   const int n = counts[b];
@@ -775,6 +791,8 @@ struct StBatchedTracker {
   st::ba::Cfg cfg;
   int batch;
   size_t state_stride, scratch_stride;
+  size_t lap_lds_bytes;   // dynamic LDS for the assignment's working arrays; 0 = they stay in the L2-resident scratch
+  int lds_set;
 };
 
 extern "C" int st_batched_tracker_create(const StTrackerConfig* cfg, int batch, int max_tracks, int max_dets,
@@ -796,6 +814,12 @@ extern "C" int st_batched_tracker_create(const StTrackerConfig* cfg, int batch, 
   t->batch = batch;
   t->state_stride = ba::align8(sizeof(ba::SeqHeader) + sizeof(ba::DTrack) * (size_t)max_tracks);
   t->scratch_stride = ba::scratch_bytes(max_tracks, max_dets);
+  {
+    const size_t n = (size_t)max_tracks + max_dets;
+    const size_t need = 2 * ba::align8(sizeof(double) * n) + 5 * ba::align8(sizeof(int) * n) + ba::align8(n);
+    t->lap_lds_bytes = need <= 64 * 1024 ? need : 0;
+    t->lds_set = 0;
+  }
   *out = t.release();
   return ST_OK;
 }
@@ -821,10 +845,12 @@ extern "C" int st_batched_tracker_step(StBatchedTracker* t, const int32_t* frame
   ST_REQUIRE(frame_ids_dev && dets_dev && counts_dev && state_dev && scratch_dev && out_rows_dev && out_ids_dev &&
                  out_counts_dev && status_dev,
              "st_batched_tracker_step: null pointer");
-  hipLaunchKernelGGL(ba::assoc_step_kernel, dim3(t->batch), dim3(64), 0, static_cast<hipStream_t>(stream), t->cfg,
-                     frame_ids_dev, dets_dev, counts_dev, static_cast<char*>(state_dev), t->state_stride,
-                     static_cast<char*>(scratch_dev), t->scratch_stride, out_rows_dev,
-                     reinterpret_cast<long long*>(out_ids_dev), out_counts_dev, status_dev);
+  ST_ENSURE_DYNAMIC_LDS(ba::assoc_step_kernel, t->lap_lds_bytes, t->lds_set);
+  hipLaunchKernelGGL(ba::assoc_step_kernel, dim3(t->batch), dim3(64), t->lap_lds_bytes,
+                     static_cast<hipStream_t>(stream), t->cfg, frame_ids_dev, dets_dev, counts_dev,
+                     static_cast<char*>(state_dev), t->state_stride, static_cast<char*>(scratch_dev),
+                     t->scratch_stride, out_rows_dev, reinterpret_cast<long long*>(out_ids_dev), out_counts_dev,
+                     status_dev, t->lap_lds_bytes ? 1 : 0);
   ST_CHECK_HIP(hipGetLastError());
   return ST_OK;
 }

@@ -9,9 +9,17 @@ with open(sys.argv[1]) as f:
     for r in csv.DictReader(f):
         rows.append((int(r['Start_Timestamp']), int(r['End_Timestamp']), r['Kernel_Name'][:60]))
 rows.sort()
-tail_ms = float(sys.argv[2]) if len(sys.argv) > 2 else 160.0
-t_end = max(r[1] for r in rows)
-rows = [r for r in rows if r[0] >= t_end - tail_ms * 1e6]
+tail_ms = float(sys.argv[2]) if len(sys.argv) > 2 else 60.0
+# the window of `tail_ms` with the most kernel launches of the conv families = the timed in-flight loop (the roofline
+# pass and the secondary legs that follow it are serialized and much sparser)
+starts = [r[0] for r in rows if 'conv' in r[2]]
+best, lo = (0, starts[0]), 0
+for hi in range(len(starts)):
+    while starts[hi] - starts[lo] > tail_ms * 1e6:
+        lo += 1
+    if hi - lo + 1 > best[0]:
+        best = (hi - lo + 1, starts[lo])
+rows = [r for r in rows if best[1] <= r[0] <= best[1] + tail_ms * 1e6]
 t0 = rows[0][0]
 busy, cur_s, cur_e, gaps = 0, rows[0][0], rows[0][1], []
 last_name = rows[0][2]
