@@ -243,3 +243,39 @@ def test_video_replica_driver_with_metrics(cuda):
     for name in videos:
         for a, b in zip(res[name], res2[name]):
             assert a.instances_id.tolist() == b.instances_id.tolist() and torch.equal(a.bboxes, b.bboxes)
+
+
+def test_raw_upload_of_disparity_codes_equals_float_upload(cuda):
+    """The disparity-INPUT configuration (the reference's own: precomputed disparity PNGs) through the raw uploader:
+    frames cross PCIe as uint8 pixels + uint16 PNG codes (code = 16 * px, loading_disparity.py:82,129-134) and are
+    converted by st_pack_raw_inputs; the detections must equal, bit for bit, those of the float upload path
+    (frames_to_batch: the values LoadDisparityFromFile + Pad_Disparity + the preprocessor produce on the host).
+    A disparity map that no PNG could hold (16 * px not integral) falls back to the float upload."""
+    from stereotracking_amd.sequence import HostSequence, RawFrameUploader, disparity_png_codes, frames_to_batch
+    frames = list(synthetic_sequence(6, 3, 80, 160, 32, seed=8))
+    assert all(disparity_png_codes(f['disp']) is not None for f in frames)
+    pipe = StereoDensePipeline(4, (80, 160), 0.375, 0.33, 1, stereo=False, max_det=256)
+    sd = synthetic_state_dict(pipe.param_table(), seed=9, prior_prob=0.2, logit_std=2.5)
+    pipe.load_state_dict(sd, autotune=False)
+    rec_raw, cnt_raw = detect_shard(pipe, frames, cuda)                                  # uint8 + uint16 upload
+    rec_res, _ = detect_shard(pipe, HostSequence(frames, use_right=False), cuda)           # page-locked resident
+    ref = []
+    for i in range(0, 6, 4):
+        chunk = frames[i:i + 4]
+        n_real = len(chunk)
+        b = frames_to_batch(chunk + [chunk[-1]] * (4 - n_real), cuda, use_right=False)     # fp32 upload
+        ref.append(pipe.pack_detections(pipe.run(b['img'], disp_postp=b['disp_postp']), scaled=True, n_real=n_real))
+    ref = torch.cat(ref)
+    torch.cuda.synchronize()
+    assert int(cnt_raw[:6].min()) > 0
+    assert torch.equal(rec_raw.nan_to_num(-7.0), ref.nan_to_num(-7.0))
+    assert torch.equal(rec_res.nan_to_num(-7.0), ref.nan_to_num(-7.0))
+    odd = [dict(f, disp=f['disp'] + 0.03) for f in frames]                                # not PNG-representable
+    assert disparity_png_codes(odd[0]['disp']) is None
+    rec_odd, _ = detect_shard(pipe, odd, cuda)                                            # float fallback, no error
+    assert rec_odd.shape == rec_raw.shape
+    with pytest.raises(ValueError):
+        HostSequence(odd, use_right=False)
+    up = RawFrameUploader(4, (80, 160), cuda, use_right=False)
+    with pytest.raises(ValueError):
+        up.upload(odd[:4])
