@@ -333,3 +333,26 @@ def test_oracle_multiclass_decode_nms_matches_torch_formulation(nc):
                                   arr(C.c_size_t, [l[3] for l in levels]), f(0.05), f(0.5), C.c_int(M), f(1), f(1), f(0),
                                   f(0), f(W), f(H - 6), C.c_int(1), ptr_(bb), ptr_(ss), ptr_(ll), ptr_(pp), ptr_(cc))
     assert rc == 0 and np.array_equal(cc, a[4]) and np.array_equal(pp, a[3]) and np.array_equal(bb, a[0])
+
+
+def test_oracle_backbone_reproduces_the_reference_docstring_example():
+    """The ONLY known answer the reference holds for this path (it ships no tests or fixtures): the docstring example
+    of the backbone class, reference mmtrack/models/backbones/csp_darknet_disparity_v1.py:50-62 - a default-size model
+    (deepen 1.0, widen 1.0) on a 1x3x416x416 input prints level shapes (1,256,52,52), (1,512,26,26), (1,1024,13,13).
+    The oracle restatement must produce exactly these, and its arch table must be the reference's (:66-69)."""
+    from oracle import torch_model as tm
+    cls = next(getattr(tm, n) for n in dir(tm) if hasattr(getattr(tm, n), 'arch') and hasattr(getattr(tm, n), '_stage'))
+    assert cls.arch == [[64, 128, 3, True, False], [128, 256, 9, True, False], [256, 512, 9, True, False],
+                        [512, 1024, 3, False, True]]
+    torch.manual_seed(0)
+    model = cls(deepen_factor=1.0, widen_factor=1.0).eval()
+    x = torch.rand(1, 3, 416, 416)
+    with torch.no_grad():
+        outs = model(dict(img=x, disp_postp=torch.rand(1, 3, 416, 416)))
+    assert [tuple(o.shape) for o in outs] == [(1, 256, 52, 52), (1, 512, 26, 26), (1, 1024, 13, 13)]
+    # the shipped YOLOX-s sizing (deepen 0.33, widen 0.5) at the path's 736 x 1280: SURVEY.md §3.2 shapes
+    small = cls(deepen_factor=0.33, widen_factor=0.5).eval()
+    with torch.no_grad():
+        outs = small(dict(img=torch.rand(1, 3, 64, 96), disp_postp=torch.rand(1, 3, 64, 96)))
+    assert [tuple(o.shape) for o in outs] == [(1, 128, 8, 12), (1, 256, 4, 6), (1, 512, 2, 3)]
+    assert len([m for m in small.stage2.modules() if type(m).__name__ == 'DarknetBottleneck']) == 3   # round(9 * 0.33)
