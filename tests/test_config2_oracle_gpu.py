@@ -29,8 +29,7 @@ import numpy as np
 import pytest
 import torch
 
-from parity_utils import (compare_kept, explain_kept_difference, match_track_rows, rel_err, unscale_boxes_np,
-                          write_record)
+from parity_utils import compare_kept, match_track_rows, rel_err, unscale_boxes_np, write_record
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -89,12 +88,9 @@ def test_config2_sequence_against_oracle_pipeline_and_oracle_tracker(name, cuda)
                       f'{int(g["AGG"])} aggregation convs, model.test_step (8 frames per plan, 3 contexts), '
                       f'{name} tracker thresholds', frames=[])
     phi, inv = {}, {}                     # gpu id -> oracle id and back: ONE bijection over the whole sequence
-    swapped_priors = set()                # priors that sat at a swapped position of the score order in some frame
-    born_at = {}                          # gpu id -> prior index of the detection it was started from
     tot = dict(track_rows=0, matched=0, inconsistent=0, only_gpu=0, only_oracle=0, det_sym_diff=0, det_swaps=0,
                frames_with_equal_det_order=0, frames_with_equal_ids_in_order=0)
     worst = dict(box=0.0, score=0.0, depth=0.0, track_box=0.0, gap_at_swaps=0.0)
-    unexplained = []
     for t in range(T):
         det, trk = outs[t].pred_det_instances, outs[t].pred_track_instances
         gp, rp = det.prior_idx.cpu().numpy(), g[f'prior{t}']
@@ -109,11 +105,6 @@ def test_config2_sequence_against_oracle_pipeline_and_oracle_tracker(name, cuda)
         pos_r = {int(p): k for k, p in enumerate(rp)}
         common = [k for k, p in enumerate(gp) if int(p) in pos_r]
         ir = [pos_r[int(gp[k])] for k in common]
-        # positions whose prior differs between the two score orders (restricted to the common priors)
-        ca, cb = gp[common], rp[np.sort(ir)]
-        swapped_priors.update(int(p) for p in ca[ca != cb])
-        swapped_priors.update(int(p) for p in cb[ca != cb])
-        swapped_priors.update(int(p) for p in set(gp.tolist()) ^ set(rp.tolist()))
         worst['box'] = max(worst['box'], rel_err(det.bboxes[common].cpu(), g[f'boxes{t}'][ir]))
         worst['score'] = max(worst['score'], float(np.abs(det.scores[common].cpu().numpy() - g[f'scores{t}'][ir]).max()))
         # --- tracks of this frame -------------------------------------------------------------------------------
@@ -127,6 +118,22 @@ def test_config2_sequence_against_oracle_pipeline_and_oracle_tracker(name, cuda)
         tot['track_rows'] += len(r_ids)
         tot['only_gpu'] += len(only_g)
         tot['only_oracle'] += len(only_r)
+        # depth of the track boxes (the second extract_depth pass, ocsort_disparity.py:99-104) against the depth the
+        # oracle attached to the same box; a box edge within float noise of an integer selects another pixel window
+        # (a discrete change): such rows are counted, not compared
+        g_depth = trk.depth.cpu().double().numpy()
+        for i, j in pairs:
+            dr, dg = float(rt[j, 7]), float(g_depth[i])
+            tot['depth_rows'] = tot.get('depth_rows', 0) + 1
+            if np.isnan(dr) or np.isnan(dg) or dr == -1 or dg == -1:
+                tot['depth_class_mismatch'] = tot.get('depth_class_mismatch', 0) + int(
+                    (np.isnan(dr) != np.isnan(dg)) or ((dr == -1) != (dg == -1)))
+                continue
+            e = abs(dg - dr) / max(1.0, abs(dr))
+            if e > 1e-3:
+                tot['depth_over_tol'] = tot.get('depth_over_tol', 0) + 1
+            else:
+                worst['depth'] = max(worst['depth'], e)
         for i, j in pairs:
             a, b = int(g_ids[i]), int(r_ids[j])
             if phi.get(a, b) != b or inv.get(b, a) != a:
@@ -139,11 +146,6 @@ def test_config2_sequence_against_oracle_pipeline_and_oracle_tracker(name, cuda)
                                   det_positions_swapped=ck['positions_swapped'], tracks_gpu=len(g_ids),
                                   tracks_oracle=len(r_ids), ids_equal_in_order=bool(
                                       len(g_ids) == len(r_ids) and np.array_equal(g_ids, r_ids))))
-        if ck['kept_set_sym_diff']:
-            # margins come from the REFERENCE run: rebuild oracle-side head rows is not possible here (the fixture
-            # holds no head), so the bound below is on the COUNT; the e2e head-level proof obligation lives in
-            # tests/test_bench_config_parity_gpu.py
-            pass
     relabeled = {a: b for a, b in phi.items() if a != b}
     # birth frame of every id on each side; a relabeled id must be exchanged with an id born in the same frame
     birth_g, birth_r = {}, {}
@@ -167,6 +169,7 @@ def test_config2_sequence_against_oracle_pipeline_and_oracle_tracker(name, cuda)
     assert worst['box'] <= 1e-3 and worst['score'] <= 1e-3 and worst['track_box'] <= 1e-3, worst
     assert worst['gap_at_swaps'] <= NOISE, worst             # order swaps only between scores inside the float noise
     assert tot['det_sym_diff'] <= max(2, sum(f['det_oracle'] for f in rec['frames']) // 100), tot
+    assert tot.get('depth_over_tol', 0) + tot.get('depth_class_mismatch', 0) <= max(2, tot.get('depth_rows', 0) // 100), tot
     if name == 'shipped':
         # the SHIPPED configuration: every track row inside the bijection, relabels only inside one frame's new ids
         assert tot['inconsistent'] == 0 and tot['only_gpu'] == 0 and tot['only_oracle'] == 0, tot
