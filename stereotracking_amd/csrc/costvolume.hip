@@ -24,6 +24,7 @@
 namespace st {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ float cv_expf(float x) {  // same polynomial as decode_nms.hip / oracle
   if (x > 88.72283f) return __builtin_inff();
@@ -171,11 +172,19 @@ __global__ __launch_bounds__(128) void costvolume_tiled_kernel(const float* __re
   constexpr int CC4 = CVT_CC / 4;
   constexpr int NL = CVT_TX * CC4 / 128, NR = (RW16 * CC4 + 127) / 128;   // float4 per thread per chunk
 
-  float acc[4][DG];
+  // Accumulators in DIAGONAL pairs: cost[x+p][d0+k] and cost[x+p+1][d0+k+1] both multiply R window element
+  // i = DG + p - k, so (acc[p][k], acc[p+1][k+1]) += (L[p], L[p+1]) * R[i] is ONE v_pk_fma_f32 with the R operand
+  // broadcast by op_sel - no register shuffles (what SLP vectorisation of the scalar loop paid for its packing).
+  // Per channel: 2 (DG - 1) packed + 4 scalar FMAs instead of 4 DG; each output's chain is still fmaf over c
+  // ascending, so the volume is bit-identical.  accs[q][0] = acc[2q][DG-1], accs[q][1] = acc[2q+1][0].
+  f32x2 accd[2][DG - 1];
+  float accs[2][2];
 #pragma unroll
-  for (int p = 0; p < 4; ++p)
+  for (int q = 0; q < 2; ++q) {
 #pragma unroll
-    for (int k = 0; k < DG; ++k) acc[p][k] = 0.f;
+    for (int k = 0; k < DG - 1; ++k) accd[q][k] = f32x2{0.f, 0.f};
+    accs[q][0] = accs[q][1] = 0.f;
+  }
 
   // Staging of one channel chunk, transposed to [c][x].  Lane order: 16 consecutive lanes = 16 consecutive
   // pixels of one channel quad (conflict-free transposing LDS writes with rows of 4 * odd floats).  The global
@@ -242,25 +251,45 @@ __global__ __launch_bounds__(128) void costvolume_tiled_kernel(const float* __re
     for (int c = 0; c < cc; c += 2) {
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
+        // UNCONDITIONAL prefetch of channel c+h+1: after the chunk's last channel it reads one row past the
+        // chunk (the next region of the LDS allocation, which carries one slack row for this) and the values
+        // are never used.  With a `cn < cc` guard the loop body had branches, the compiler waited for every
+        // read batch right after issuing it and copied one register set into the other per iteration:
+        // 115 -> 93 us for the bench volume (build/cv_abl ablations).
         const int cn = c + h + 1;
-        if (cn < cc) {
-          lv[h ^ 1] = *reinterpret_cast<const f32x4*>(lp + cn * rowL);
+        lv[h ^ 1] = *reinterpret_cast<const f32x4*>(lp + cn * rowL);
 #pragma unroll
-          for (int q = 0; q < NW / 4; ++q) rv[h ^ 1][q] = *reinterpret_cast<const f32x4*>(rp + cn * rowR + 4 * q);
-        }
+        for (int q = 0; q < NW / 4; ++q) rv[h ^ 1][q] = *reinterpret_cast<const f32x4*>(rp + cn * rowR + 4 * q);
 #pragma unroll
-        for (int p = 0; p < 4; ++p)
+        for (int q = 0; q < 2; ++q) {
+          const f32x2 lpair = q ? f32x2{lv[h][2], lv[h][3]} : f32x2{lv[h][0], lv[h][1]};
 #pragma unroll
-          for (int k = 0; k < DG; ++k) {
-            const int i = DG + p - k;   // window index of x + p - d0 - k
-            acc[p][k] = fmaf(lv[h][p], rv[h][i >> 2][i & 3], acc[p][k]);
+          for (int k = 0; k < DG - 1; ++k) {
+            const int i = DG + 2 * q - k;   // window index of x + 2q - d0 - k (= that of x + 2q + 1 - d0 - (k + 1))
+            const float r = rv[h][i >> 2][i & 3];
+            accd[q][k] = __builtin_elementwise_fma(lpair, f32x2{r, r}, accd[q][k]);
           }
+          constexpr int ilo = 1, ihi = DG + 1;   // + 2q: windows of (p = 2q, k = DG-1) and (p = 2q+1, k = 0)
+          accs[q][0] = fmaf(lpair[0], rv[h][(ilo + 2 * q) >> 2][(ilo + 2 * q) & 3], accs[q][0]);
+          accs[q][1] = fmaf(lpair[1], rv[h][(ihi + 2 * q) >> 2][(ihi + 2 * q) & 3], accs[q][1]);
+        }
       }
     }
     if (more) stage_store(buf ^ 1);
     __syncthreads();
   }
 
+  float acc[4][DG];   // back to [pixel][disparity] (register renaming only)
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+#pragma unroll
+    for (int k = 0; k < DG - 1; ++k) {
+      acc[2 * q][k] = accd[q][k][0];
+      acc[2 * q + 1][k + 1] = accd[q][k][1];
+    }
+    acc[2 * q][DG - 1] = accs[q][0];
+    acc[2 * q + 1][0] = accs[q][1];
+  }
   // ---- cost = acc / C (0 where the match falls left of the image), optional volume store, fused soft-argmin
   const float fC = (float)C;
   const bool pow2 = (C & (C - 1)) == 0;   // then x * (1/C) == x / C exactly (no subnormal results here)
@@ -438,7 +467,7 @@ extern "C" int st_costvolume_softargmin(const float* featL_dev, const float* fea
   }
   if (dgt <= 32 && (out_cost_dev == nullptr || (reinterpret_cast<uintptr_t>(out_cost_dev) & 15) == 0)) {
     const int rowLt = cvt_row(CVT_TX), rowRt = cvt_row(CVT_TX + 4 * dgt);
-    const size_t ldst = (size_t)2 * CVT_CC * (rowLt + rowRt) * sizeof(float);
+    const size_t ldst = ((size_t)2 * CVT_CC * (rowLt + rowRt) + rowRt) * sizeof(float);   // + the prefetch slack row
     const dim3 gridt((Wf + CVT_TX - 1) / CVT_TX, Hf, N), blockt(128);
 #define ST_CVT_LAUNCH(DGV)                                                                                    \
   do {                                                                                                         \
