@@ -21,7 +21,7 @@
 // depths are positive, so the unsigned order equals the float order); the two segment bounds are
 // selected together (two histograms per pass); the trimmed mean is accumulated in fp64 and rounded
 // once (numpy uses fp32 pairwise summation: equal to ~1e-6 relative, inside the 1e-3 float
-// tolerance of the path).  Windows of up to 4096 pixels (every realistic drone box) are cached in
+// tolerance of the path).  Windows of up to BD_CACHE pixels (every realistic drone box) are cached in
 // LDS by the counting pass, so the following passes never touch memory again.
 #include <algorithm>
 
@@ -31,13 +31,14 @@ namespace st {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-// One SMALL workgroup per box: drone boxes are tens of pixels wide (8-60 px objects, 4-80 px boxes of
-// the synthetic head), so a box is ~15 elements per lane for BD_THREADS lanes and the kernel's time is the ~20
-// workgroup barriers of the 6 passes, not the data.  512-thread workgroups (round 2) kept 8 waves waiting at every
-// barrier and only 2 boxes per CU in flight: 192 us for ~3000 boxes.  128 threads and a 16 KiB window cache put 6
-// boxes on a CU at once; windows above BD_CACHE pixels stream from L2 in every pass (rare, still exact).
+// One SMALL workgroup per box: drone boxes are tens of pixels wide (8-60 px objects; the bench
+// workload's ~2900 boxes average 300 pixels, the largest is 2400), so a box is a few elements per lane and the kernel's
+// time is the barriers and LDS round trips of its passes, not the data: what matters is how many boxes a CU works on at
+// once.  512-thread workgroups (round 2): 192 us.  128 threads, 16 KiB cache, 20 barriers per box: 95 us.  Round 3:
+// first radix histogram counted by the counting pass, corner loads issued up front, 14 barriers, and 17 KiB of LDS
+// per box (9 boxes per CU): 58 us.  Windows above BD_CACHE pixels stream from L2 in every pass (rare, still exact).
 constexpr int BD_THREADS = 128;
-constexpr int BD_CACHE = 4096;   // floats of LDS window cache (16 KiB)
+constexpr int BD_CACHE = 2560;   // floats of LDS window cache (10 KiB): 50 x 50 pixels
 
 __device__ __forceinline__ int py_slice_index(int i, int len) {
   if (i < 0) {
@@ -100,7 +101,10 @@ struct Window {
 };
 
 // values (bit patterns) at NR 0-based ranks among the valid depths, selected together (NR histograms per
-// pass, 4 passes of 8 bits); all threads call it
+// pass, 4 passes of 8 bits); all threads call it.
+// Precondition (set up by the kernel's counting pass, one barrier before the call): hist[0] = histogram of the TOP
+// byte of every valid depth - all ranks share the empty prefix, so the first radix pass needs no sweep of its own.
+// A pass is  count | barrier | prefix sums -> sh | barrier | use sh, re-zero the histograms | barrier.
 constexpr int BD_NR = 7;
 __device__ void select_ranks(const Window& w, const int* ranks, unsigned (*hist)[256], unsigned* sh, unsigned* out) {
   unsigned prefix[BD_NR], mask = 0;
@@ -108,22 +112,23 @@ __device__ void select_ranks(const Window& w, const int* ranks, unsigned (*hist)
 #pragma unroll
   for (int q = 0; q < BD_NR; ++q) { prefix[q] = 0; r[q] = ranks[q]; }
   for (int shift = 24; shift >= 0; shift -= 8) {
-    for (int b = threadIdx.x; b < BD_NR * 256; b += blockDim.x) hist[b >> 8][b & 255] = 0;
-    __syncthreads();
-    w.for_each([&](float d) {
-      if (depth_valid(d)) {
-        const unsigned u = __float_as_uint(d), um = u & mask, bin = (u >> shift) & 255u;
+    unsigned (*hc)[256] = hist;
+    if (shift != 24) {
+      w.for_each([&](float d) {
+        if (depth_valid(d)) {
+          const unsigned u = __float_as_uint(d), um = u & mask, bin = (u >> shift) & 255u;
 #pragma unroll
-        for (int q = 0; q < BD_NR; ++q) {
-          // ranks that still share a prefix share a histogram: count once, in the first of them
-          bool first = true;
+          for (int q = 0; q < BD_NR; ++q) {
+            // ranks that still share a prefix share a histogram: count once, in the first of them
+            bool first = true;
 #pragma unroll
-          for (int q2 = 0; q2 < q; ++q2) first = first && (prefix[q2] != prefix[q]);
-          if (first && um == prefix[q]) atomicAdd(&hist[q][bin], 1u);
+            for (int q2 = 0; q2 < q; ++q2) first = first && (prefix[q2] != prefix[q]);
+            if (first && um == prefix[q]) atomicAdd(&hc[q][bin], 1u);
+          }
         }
-      }
-    });
-    __syncthreads();
+      });
+      __syncthreads();
+    }
     // one wave per rank: 64-lane prefix sum over the 256 bins (4 bins per lane), the lane whose bins
     // straddle the rank reports (bin, count below it)
     const int wv0 = threadIdx.x >> 6, ln = threadIdx.x & 63, nwv = blockDim.x >> 6;
@@ -139,7 +144,7 @@ __device__ void select_ranks(const Window& w, const int* ranks, unsigned (*hist)
         if (q2 < wv && prefix[q2] == pq) src = q2;
       unsigned h[4];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) h[j] = hist[src][4 * ln + j];
+      for (int j = 0; j < 4; ++j) h[j] = hc[src][4 * ln + j];
       const unsigned tot = h[0] + h[1] + h[2] + h[3];
       unsigned incl = tot;
 #pragma unroll
@@ -164,7 +169,10 @@ __device__ void select_ranks(const Window& w, const int* ranks, unsigned (*hist)
       r[q] -= (int)sh[2 * q + 1];
     }
     mask |= 255u << shift;
-    __syncthreads();
+    if (shift != 0) {   // every reader of the histograms is behind the barrier above
+      for (int b = threadIdx.x; b < BD_NR * 256; b += blockDim.x) hist[b >> 8][b & 255] = 0;
+      __syncthreads();
+    }
   }
 #pragma unroll
   for (int q = 0; q < BD_NR; ++q) out[q] = prefix[q];
@@ -224,18 +232,33 @@ __global__ __launch_bounds__(BD_THREADS) void box_depth_kernel(const float* __re
   const bool use_cache = w.total <= BD_CACHE;
   w.cache = nullptr;
 
-  // ---- pass 0: number of valid depths (and fill the LDS window cache)
+  // the 4 corner means only depend on the box: their (dependent, uncached) loads are issued here and land while the
+  // passes below run; they are compared with the median after the selection
+  const float v_tl = corner_mean(disp, H, W, y1, y1 + 2, x1, x1 + 2, bf, is_depth);
+  const float v_tr = corner_mean(disp, H, W, y1, y1 + 2, x2 - 2, x2, bf, is_depth);
+  const float v_bl = corner_mean(disp, H, W, y2 - 2, y2, x1, x1 + 2, bf, is_depth);
+  const float v_br = corner_mean(disp, H, W, y2 - 2, y2, x2 - 2, x2, bf, is_depth);
+
+  // ---- pass 0: number of valid depths, histogram of their top byte (= the first radix pass of select_ranks), and the
+  // LDS window cache
   if (threadIdx.x == 0) s_len = 0;
+  for (int b = threadIdx.x; b < 256; b += blockDim.x) hist[0][b] = 0;
   __syncthreads();
   int local = 0;
+  auto tally = [&](float d) {
+    if (depth_valid(d)) {
+      ++local;
+      atomicAdd(&hist[0][__float_as_uint(d) >> 24], 1u);
+    }
+  };
   if (use_cache) {
     for (int e = threadIdx.x; e < w.total; e += blockDim.x) {
       const float d = w.get(e);
       cache[e] = d;
-      local += depth_valid(d);
+      tally(d);
     }
   } else {
-    w.for_each([&](float d) { local += depth_valid(d); });
+    w.for_each(tally);
   }
   if (local) atomicAdd(&s_len, local);
   __syncthreads();
@@ -274,14 +297,7 @@ __global__ __launch_bounds__(BD_THREADS) void box_depth_kernel(const float* __re
     }
     select_ranks(w, ranks, hist, sh, bits);
     const float d_mid = __uint_as_float(bits[0]);
-    int cnt = 0;
-    {
-      const float v_tl = corner_mean(disp, H, W, y1, y1 + 2, x1, x1 + 2, bf, is_depth);
-      const float v_tr = corner_mean(disp, H, W, y1, y1 + 2, x2 - 2, x2, bf, is_depth);
-      const float v_bl = corner_mean(disp, H, W, y2 - 2, y2, x1, x1 + 2, bf, is_depth);
-      const float v_br = corner_mean(disp, H, W, y2 - 2, y2, x2 - 2, x2, bf, is_depth);
-      cnt = (v_tl > d_mid) + (v_tr > d_mid) + (v_bl > d_mid) + (v_br > d_mid);
-    }
+    const int cnt = (v_tl > d_mid) + (v_tr > d_mid) + (v_bl > d_mid) + (v_br > d_mid);
     // frac = min(1 - cnt/4, 0.4): cnt <= 2 -> 0.4, cnt == 3 -> 0.25, cnt == 4 -> 0
     const int csel = cnt <= 2 ? 0 : (cnt == 3 ? 1 : 2);
     const int a = cand_a[csel], b = cand_b[csel];
