@@ -73,9 +73,13 @@ __device__ __forceinline__ void conv_epilogue(const ConvKArgs& p, f32x16 (&acc)[
   // the SGPR-base + 32-bit VGPR-offset form.  The common case (tile fully inside, no split / upsample)
   // runs without per-element predicates.
   const bool full_tile = (m0 + BM <= p.M) && (n0 + BN <= p.Cout);
-  const bool simple = full_tile && !p.up && !p.out2;
+  // a tile that lies on ONE side of the split stores through one (pointer, stride, offset) triple chosen once per
+  // workgroup (CSP main|short convs: split = Cout / 2 is a multiple of the tile width)
+  const bool side1 = !p.out2 || n0 + BN <= p.split, side2 = p.out2 && n0 >= p.split;
+  const bool simple = full_tile && !p.up && (side1 || side2);
   if (simple) {
-    float* __restrict__ o1 = p.out1 + p.out1_off;
+    float* __restrict__ o1 = side1 ? p.out1 + p.out1_off : p.out2 + p.out2_off - p.split;
+    const unsigned o_ld = side1 ? (unsigned)p.out1_ld : (unsigned)p.out2_ld;
     const float* __restrict__ rs = p.res ? p.res + p.res_off : nullptr;
 #pragma unroll
     for (int tj = 0; tj < TN; ++tj) {
@@ -95,7 +99,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvKArgs& p, f32x16 (&acc)[
           float v = acc[ti][tj][r] + bj;
           if (p.act) v = silu_f32(v);
           if (rs) v = (v + rv[r]) * p.post_scale;
-          o1[(mb + (r & 3) + 8 * (r >> 2)) * (unsigned)p.out1_ld + j] = v;
+          o1[(mb + (r & 3) + 8 * (r >> 2)) * o_ld + j] = v;
         }
       }
     }
@@ -118,9 +122,26 @@ __device__ __forceinline__ void conv_epilogue(const ConvKArgs& p, f32x16 (&acc)[
           rv[r] = (m < p.M && vj) ? p.res[(unsigned)m * (unsigned)p.res_ld + p.res_off + j] : 0.f;
         }
       }
+      // (n, oy, ox) of the lane's rows for the upsampled store: ONE division pair per 32x32 tile, then the 16 rows
+      // (m + 0,1,2,3, 8,9,10,11, ...) by stepping - the per-element divisions were ~1300 vector instructions per wave
+      int un = 0, uy = 0, ux = 0;
+      if (p.up) {
+        const int mfirst = m0 + wm * 32 * TM + ti * 32 + 4 * lh;
+        un = mfirst / p.HoWo;
+        const int rem = mfirst - un * p.HoWo;
+        uy = rem / p.Wo;
+        ux = rem - uy * p.Wo;
+      }
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int m = m0 + wm * 32 * TM + ti * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (p.up && r > 0) {   // step from row r-1: +1 inside a group of 4, +5 to the next group
+          ux += (r & 3) ? 1 : 5;
+          while (ux >= p.Wo) {
+            ux -= p.Wo;
+            if (++uy == p.Ho) { uy = 0; ++un; }
+          }
+        }
         if (m < p.M && vj) {
           float v = acc[ti][tj][r] + bj;
           if (p.act) v = silu_f32(v);
@@ -130,12 +151,8 @@ __device__ __forceinline__ void conv_epilogue(const ConvKArgs& p, f32x16 (&acc)[
           else
             p.out2[(unsigned)m * (unsigned)p.out2_ld + p.out2_off + (j - p.split)] = v;
           if (p.up) {
-            const int n = m / p.HoWo;
-            const int rem = m - n * p.HoWo;
-            const int oy = rem / p.Wo;
-            const int ox = rem - oy * p.Wo;
             const unsigned W2 = 2u * p.Wo;
-            const unsigned base = ((unsigned)n * 2u * p.Ho + 2u * oy) * W2 + 2u * ox;
+            const unsigned base = ((unsigned)un * 2u * p.Ho + 2u * uy) * W2 + 2u * ux;
             float* u = p.up + p.up_off + j;
             u[base * (unsigned)p.up_ld] = v;
             u[(base + 1) * (unsigned)p.up_ld] = v;
@@ -160,7 +177,12 @@ __device__ __forceinline__ void conv_epilogue(const ConvKArgs& p, f32x16 (&acc)[
 //          swizzle applied on the SOURCE side (lane (row, q) fetches k-group q ^ ((row>>1)&7)) and undone
 //          by the same XOR in the fragment reads (cdna_hip_programming.md rule 21): conflict-free for the
 //          ds_read_b128 lane groups.
-template <int TM, int TN, int WM, int WN, int NBUF, int ABL = 0, int ILV = 1, int DMA = 0>
+// PW = 1: the layer is POINTWISE (1x1, stride 1, no padding - half of the launches of the network).  Input pixel =
+//         output pixel and k = channel: no divisions or tap masks in the set-up, and the per-chunk address update of
+//         the staging loads is one add.  The general set-up is ~300 vector instructions per lane and the general
+//         update ~20 per chunk; on the fp32 matrix path VALU time adds to MFMA time (tools/micro/mfma_peak.hip), and a
+//         K = 128 layer has only 64 MFMAs per wave to hide them behind.
+template <int TM, int TN, int WM, int WN, int NBUF, int ABL = 0, int ILV = 1, int DMA = 0, int PW = 0>
 __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(ConvKArgs p) {
   static_assert(NBUF == 2 || (WM == 1 && WN == 1), "single LDS buffer needs a single-wave block");
   static_assert(!DMA || (NBUF == 2 && 64 * WM * WN >= 128), "LDS-DMA variant: double buffer, >= 2 waves");
@@ -212,6 +234,11 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(ConvKArgs p) {
     const int m = m0 + r0 + a * ROWS;
     const bool vm = m < p.M;
     const int mm = vm ? m : 0;
+    if (PW) {
+      rowoff[a] = (mm * p.in_ld + p.in_off) * 4;
+      vmask[a] = vm ? 1u : 0u;
+      continue;
+    }
     const int n = mm / p.HoWo;
     const int rem = mm - n * p.HoWo;
     const int oy = rem / p.Wo;
@@ -231,12 +258,14 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(ConvKArgs p) {
 
   // running (tap, c) of this lane's 4-float group and the tap's byte offset; advanced by 32 per chunk
   int kc_c = kq * 4, kc_kh = 0, kc_kw = 0, kc_k = kq * 4;
-  while (kc_c >= p.Cin) {
-    kc_c -= p.Cin;
-    if (++kc_kw == p.KW) { kc_kw = 0; ++kc_kh; }
+  if (!PW) {
+    while (kc_c >= p.Cin) {
+      kc_c -= p.Cin;
+      if (++kc_kw == p.KW) { kc_kw = 0; ++kc_kh; }
+    }
   }
-  int kc_tap = kc_kh * p.KW + kc_kw;
-  int kc_off = ((kc_kh * p.Wi + kc_kw) * p.in_ld + kc_c) * 4;
+  int kc_tap = PW ? 0 : kc_kh * p.KW + kc_kw;
+  int kc_off = PW ? kc_k * 4 : ((kc_kh * p.Wi + kc_kw) * p.in_ld + kc_c) * 4;
 
   f32x4 areg[AP], breg[BP];
   // one 16-B staging item of this thread: A row `a` (im2col gather, zero fill) / W row `b`
@@ -252,6 +281,10 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(ConvKArgs p) {
   auto advance = [&]() {  // move this lane's (kh, kw, c) to the next K-chunk
     if (ABL == 6) return;
     kc_k += BK;
+    if (PW) {   // k = channel: the lane's group moves 32 channels on
+      kc_off += BK * 4;
+      return;
+    }
     kc_c += BK;
     while (kc_c >= p.Cin) {
       kc_c -= p.Cin;
@@ -604,12 +637,12 @@ static int launch_ws(const ConvKArgs& a, int m_tiles, hipStream_t stream) {
 
 #endif  // ST_ABLATION
 
-template <int TM, int TN, int WM, int WN, int NBUF = 2, int ABL = 0, int ILV = 1, int DMA = 0>
+template <int TM, int TN, int WM, int WN, int NBUF = 2, int ABL = 0, int ILV = 1, int DMA = 0, int PW = 0>
 static int launch_variant(const ConvKArgs& a, int m_tiles, hipStream_t stream) {
   constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
   constexpr size_t lds = (size_t)NBUF * (BM + BN) * (DMA ? 32 : LDK) * sizeof(float);
   static bool attr_set = false;
-  auto kern = conv_igemm_kernel<TM, TN, WM, WN, NBUF, ABL, ILV, DMA>;
+  auto kern = conv_igemm_kernel<TM, TN, WM, WN, NBUF, ABL, ILV, DMA, PW>;
   if (!attr_set) {
     ST_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -787,29 +820,31 @@ int conv2d_launch(const StConvDesc& d, hipStream_t stream, int force_variant, in
 #else
   ST_REQUIRE(force_variant < 100, "conv: ablation builds exist only in the ST_ABLATION (tools) library");
 #endif
+  // pointwise layers run the PW instance of the picked tile variant (same tiles, shorter address code)
+  const bool pw = d.KH == 1 && d.KW == 1 && d.stride == 1 && d.pad == 0;
   switch (pick) {
-    case 0: return launch_variant<2, 2, 2, 2>(a, m_tiles, stream);
-    case 1: return launch_variant<2, 2, 2, 1>(a, m_tiles, stream);
-    case 2: return launch_variant<2, 1, 2, 1>(a, m_tiles, stream);
-    case 3: return launch_variant<1, 1, 2, 2>(a, m_tiles, stream);
-    case 4: return launch_variant<1, 1, 2, 1>(a, m_tiles, stream);
-    case 5: return launch_variant<1, 2, 4, 1>(a, m_tiles, stream);
-    case 6: return launch_variant<1, 1, 4, 1>(a, m_tiles, stream);
-    case 7: return launch_variant<1, 2, 2, 2>(a, m_tiles, stream);
-    case 8: return launch_variant<2, 2, 4, 1>(a, m_tiles, stream);
-    case 9: return launch_variant<2, 2, 1, 1, 1>(a, m_tiles, stream);
-    case 10: return launch_variant<2, 1, 1, 1, 1>(a, m_tiles, stream);
-    case 11: return launch_variant<1, 2, 1, 1, 1>(a, m_tiles, stream);
-    case 12: return launch_variant<2, 2, 2, 2, 2, 0, 1, 1>(a, m_tiles, stream);
-    case 13: return launch_variant<1, 1, 2, 2, 2, 0, 1, 1>(a, m_tiles, stream);
-    case 14: return launch_variant<1, 2, 2, 2, 2, 0, 1, 1>(a, m_tiles, stream);
-    case 15: return launch_variant<1, 1, 4, 1, 2, 0, 1, 1>(a, m_tiles, stream);
-    case 16: return launch_variant<1, 2, 4, 1, 2, 0, 1, 1>(a, m_tiles, stream);
-    case 17: return launch_variant<2, 2, 2, 2, 2, 0, 0, 1>(a, m_tiles, stream);
-    case 18: return launch_variant<1, 1, 2, 2, 2, 0, 0, 1>(a, m_tiles, stream);
-    case 19: return launch_variant<2, 2, 4, 2, 2, 0, 1, 1>(a, m_tiles, stream);
-    case 20: return launch_variant<2, 2, 4, 2, 2, 0, 0, 1>(a, m_tiles, stream);
-    case 21: return launch_variant<2, 2, 4, 2, 2, 0, 1, 0>(a, m_tiles, stream);
+    case 0: return pw ? launch_variant<2, 2, 2, 2, 2, 0, 1, 0, 1>(a, m_tiles, stream) : launch_variant<2, 2, 2, 2, 2, 0, 1, 0, 0>(a, m_tiles, stream);
+    case 1: return pw ? launch_variant<2, 2, 2, 1, 2, 0, 1, 0, 1>(a, m_tiles, stream) : launch_variant<2, 2, 2, 1, 2, 0, 1, 0, 0>(a, m_tiles, stream);
+    case 2: return pw ? launch_variant<2, 1, 2, 1, 2, 0, 1, 0, 1>(a, m_tiles, stream) : launch_variant<2, 1, 2, 1, 2, 0, 1, 0, 0>(a, m_tiles, stream);
+    case 3: return pw ? launch_variant<1, 1, 2, 2, 2, 0, 1, 0, 1>(a, m_tiles, stream) : launch_variant<1, 1, 2, 2, 2, 0, 1, 0, 0>(a, m_tiles, stream);
+    case 4: return pw ? launch_variant<1, 1, 2, 1, 2, 0, 1, 0, 1>(a, m_tiles, stream) : launch_variant<1, 1, 2, 1, 2, 0, 1, 0, 0>(a, m_tiles, stream);
+    case 5: return pw ? launch_variant<1, 2, 4, 1, 2, 0, 1, 0, 1>(a, m_tiles, stream) : launch_variant<1, 2, 4, 1, 2, 0, 1, 0, 0>(a, m_tiles, stream);
+    case 6: return pw ? launch_variant<1, 1, 4, 1, 2, 0, 1, 0, 1>(a, m_tiles, stream) : launch_variant<1, 1, 4, 1, 2, 0, 1, 0, 0>(a, m_tiles, stream);
+    case 7: return pw ? launch_variant<1, 2, 2, 2, 2, 0, 1, 0, 1>(a, m_tiles, stream) : launch_variant<1, 2, 2, 2, 2, 0, 1, 0, 0>(a, m_tiles, stream);
+    case 8: return pw ? launch_variant<2, 2, 4, 1, 2, 0, 1, 0, 1>(a, m_tiles, stream) : launch_variant<2, 2, 4, 1, 2, 0, 1, 0, 0>(a, m_tiles, stream);
+    case 9: return pw ? launch_variant<2, 2, 1, 1, 1, 0, 1, 0, 1>(a, m_tiles, stream) : launch_variant<2, 2, 1, 1, 1, 0, 1, 0, 0>(a, m_tiles, stream);
+    case 10: return pw ? launch_variant<2, 1, 1, 1, 1, 0, 1, 0, 1>(a, m_tiles, stream) : launch_variant<2, 1, 1, 1, 1, 0, 1, 0, 0>(a, m_tiles, stream);
+    case 11: return pw ? launch_variant<1, 2, 1, 1, 1, 0, 1, 0, 1>(a, m_tiles, stream) : launch_variant<1, 2, 1, 1, 1, 0, 1, 0, 0>(a, m_tiles, stream);
+    case 12: return pw ? launch_variant<2, 2, 2, 2, 2, 0, 1, 1, 1>(a, m_tiles, stream) : launch_variant<2, 2, 2, 2, 2, 0, 1, 1, 0>(a, m_tiles, stream);
+    case 13: return pw ? launch_variant<1, 1, 2, 2, 2, 0, 1, 1, 1>(a, m_tiles, stream) : launch_variant<1, 1, 2, 2, 2, 0, 1, 1, 0>(a, m_tiles, stream);
+    case 14: return pw ? launch_variant<1, 2, 2, 2, 2, 0, 1, 1, 1>(a, m_tiles, stream) : launch_variant<1, 2, 2, 2, 2, 0, 1, 1, 0>(a, m_tiles, stream);
+    case 15: return pw ? launch_variant<1, 1, 4, 1, 2, 0, 1, 1, 1>(a, m_tiles, stream) : launch_variant<1, 1, 4, 1, 2, 0, 1, 1, 0>(a, m_tiles, stream);
+    case 16: return pw ? launch_variant<1, 2, 4, 1, 2, 0, 1, 1, 1>(a, m_tiles, stream) : launch_variant<1, 2, 4, 1, 2, 0, 1, 1, 0>(a, m_tiles, stream);
+    case 17: return pw ? launch_variant<2, 2, 2, 2, 2, 0, 0, 1, 1>(a, m_tiles, stream) : launch_variant<2, 2, 2, 2, 2, 0, 0, 1, 0>(a, m_tiles, stream);
+    case 18: return pw ? launch_variant<1, 1, 2, 2, 2, 0, 0, 1, 1>(a, m_tiles, stream) : launch_variant<1, 1, 2, 2, 2, 0, 0, 1, 0>(a, m_tiles, stream);
+    case 19: return pw ? launch_variant<2, 2, 4, 2, 2, 0, 1, 1, 1>(a, m_tiles, stream) : launch_variant<2, 2, 4, 2, 2, 0, 1, 1, 0>(a, m_tiles, stream);
+    case 20: return pw ? launch_variant<2, 2, 4, 2, 2, 0, 0, 1, 1>(a, m_tiles, stream) : launch_variant<2, 2, 4, 2, 2, 0, 0, 1, 0>(a, m_tiles, stream);
+    case 21: return pw ? launch_variant<2, 2, 4, 2, 2, 0, 1, 0, 1>(a, m_tiles, stream) : launch_variant<2, 2, 4, 2, 2, 0, 1, 0, 0>(a, m_tiles, stream);
 #ifdef ST_ABLATION
     case 22: return launch_ws<2, 2, 2, 2>(a, m_tiles, stream);
     case 23: return launch_ws<1, 1, 2, 2>(a, m_tiles, stream);
