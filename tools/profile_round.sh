@@ -18,7 +18,10 @@ PM="--steps 4 --warmup 2 --no-cpu-baseline --no-test-step --sustain-seconds 0 --
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CU_CYCLES --kernel-trace --output-format csv -d $R/$OUT/pmc_mfma -- python3 $R/bench.py $PM > /dev/null 2> $R/$OUT/pmc_mfma.err
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $R/$OUT/pmc_fetch -- python3 $R/bench.py $PM > /dev/null 2> $R/$OUT/pmc_fetch.err
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $R/$OUT/pmc_write -- python3 $R/bench.py $PM > /dev/null 2> $R/$OUT/pmc_write.err
+rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_SALU GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $R/$OUT/pmc_valu1 -- python3 $R/bench.py $PM > /dev/null 2> $R/$OUT/pmc_valu1.err
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_VALU_MFMA_COEXEC_CYCLES SQ_ACTIVE_INST_VALU --kernel-trace --output-format csv -d $R/$OUT/pmc_valu2 -- python3 $R/bench.py $PM > /dev/null 2> $R/$OUT/pmc_valu2.err
 cd $R
+python tools/pmc_valu.py $(find $OUT/pmc_valu1 -name "*counter_collection.csv" | head -1) $(find $OUT/pmc_valu2 -name "*counter_collection.csv" | head -1) > $OUT/valu_mfma.txt
 find $OUT -name "*_kernel_stats.csv" | head
 python tools/pmc_mfma.py $(find $OUT/pmc_mfma -name "*counter_collection.csv" | head -1) $OUT/mfma_busy.json > $OUT/mfma_busy.txt
 python tools/pmc_summary.py $(find $OUT/pmc_fetch -name "*counter_collection.csv" | head -1) $(find $OUT/pmc_write -name "*counter_collection.csv" | head -1) $OUT/hbm_traffic.json > $OUT/hbm_traffic.txt
