@@ -135,6 +135,53 @@ def test_conv_all_tile_variants(variant, cout, cuda):
     assert_close(got, ref_conv(x, w, b, 1, 1, 1))
 
 
+@pytest.mark.parametrize('variant,cout', [(0, 128), (1, 64), (2, 32), (3, 64), (4, 32), (5, 64), (6, 32), (7, 128),
+                                          (8, 64), (9, 64), (10, 32), (11, 64), (12, 128), (13, 64), (14, 128), (15, 32),
+                                          (16, 64), (17, 128), (18, 64), (19, 128), (20, 128), (21, 128)])
+def test_conv_pointwise_instances_of_all_tile_variants(variant, cout, cuda):
+    """1x1 / stride 1 / no padding layers run the POINTWISE instance of the picked tile variant (division-free set-up,
+    one add per K-chunk): ragged pixel count, K tail (Cin = 72), input channel slice, against torch."""
+    torch.manual_seed(100 + variant)
+    x = torch.randn(2, 72, 11, 13) + 1.5   # non-zero mean: a wrong K-tail or row mask shows up
+    w = torch.randn(cout, 72, 1, 1) / 72 ** 0.5
+    b = torch.randn(cout)
+    got, _ = run_conv(x, w, b, 1, 0, 1, cuda, variant=variant, in_ld=80, in_off=4)
+    assert_close(got, ref_conv(x, w, b, 1, 0, 1))
+
+
+@pytest.mark.parametrize('variant,cout,split', [(3, 128, 64),    # tile (64) on one side of the split: uniform stores
+                                                (3, 128, 32),    # split inside a tile: per-element side selection
+                                                (0, 256, 128), (7, 256, 128), (13, 128, 64)])
+@pytest.mark.parametrize('res', [False, True])
+def test_conv_split_stores_whole_tile_and_mixed(variant, cout, split, res, cuda):
+    torch.manual_seed(variant + cout + split)
+    x = torch.randn(2, 64, 16, 16)            # 512 pixels: full tiles for every variant above
+    w = torch.randn(cout, 64, 1, 1) / 8.0
+    b = torch.randn(cout)
+    r = torch.randn(2, cout, 16, 16) if res else None
+    got, _ = run_conv(x, w, b, 1, 0, 1, cuda, variant=variant, split=split, res=r, post_scale=0.5 if res else 1.0)
+    assert_close(got, ref_conv(x, w, b, 1, 0, 1, r, 0.5 if res else 1.0))
+
+
+@pytest.mark.parametrize('shape', [(2, 8, 12), (3, 5, 3), (1, 23, 40)])   # rows of 12 / 3 / 40 pixels: the 16 rows of a
+def test_conv_upsampled_store_coordinates(shape, cuda):                      # lane wrap lines and images
+    N, H, W = shape
+    torch.manual_seed(H * W)
+    x = torch.randn(N, 64, H, W)
+    w = torch.randn(64, 64, 1, 1) / 8.0
+    b = torch.randn(64)
+    for variant in (3, 0, 13):
+        if variant == 0:
+            w2, b2 = torch.randn(128, 64, 1, 1) / 8.0, torch.randn(128)
+            got, up = run_conv(x, w2, b2, 1, 0, 1, cuda, variant=variant, up=True)
+            ref = ref_conv(x, w2, b2, 1, 0, 1)
+        else:
+            got, up = run_conv(x, w, b, 1, 0, 1, cuda, variant=variant, up=True)
+            ref = ref_conv(x, w, b, 1, 0, 1)
+        assert_close(got, ref)
+        assert torch.equal(up, F.interpolate(got, scale_factor=2, mode='nearest'))
+
+
 @pytest.mark.parametrize('variant', [12, 13, 15, 18])
 @pytest.mark.parametrize('case', [(2, 12, 20, 36, 128, 3, 1), (1, 32, 23, 41, 64, 3, 2), (1, 24, 10, 12, 64, 3, 2),
                                   (2, 64, 7, 9, 192, 1, 1)])
