@@ -19,7 +19,10 @@ import os
 import sys
 import time
 
-import torch
+os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')   # one hardware queue per in-flight context (stereotracking_amd/__init__.py)
+os.environ.setdefault('HIP_FORCE_DEV_KERNARG', '1')   # kernel arguments in device memory (same file)
+
+import torch  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
@@ -38,8 +41,11 @@ def parse():
     ap.add_argument('--agg-layers', type=int, default=2, help='3x3 aggregation convs over the cost volume')
     ap.add_argument('--max-det', type=int, default=1000,
                     help='rows of the fixed-size detection buffer per frame (a capacity: overflow is an error)')
-    ap.add_argument('--inflight', type=int, default=3,
+    ap.add_argument('--inflight', type=int, default=4,
                     help='pipeline contexts fed round-robin, one HIP stream each (1 = strictly serial steps)')
+    ap.add_argument('--shell-inflight', type=int, default=3,
+                    help='contexts of the MOT shell in the test_step leg (a synchronous call fills and drains them: '
+                         '3 is faster than 4 there)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-test-step', action='store_true',
                     help='skip the second leg through Config.fromfile -> MODELS.build -> model.test_step')
@@ -345,7 +351,7 @@ def test_step_leg(args, sd, batch_cpu, dev, pairs_target):
     cfg.model.stereo['max_disp'] = args.max_disp
     cfg.model.stereo['agg_layers'] = args.agg_layers
     B, F = args.batch, max(args.batch, args.frames_per_call)
-    model = MODELS.build(dict(cfg.model, dense_batch=B, inflight=max(1, args.inflight), max_det=args.max_det,
+    model = MODELS.build(dict(cfg.model, dense_batch=B, inflight=max(1, args.shell_inflight), max_det=args.max_det,
                               tuning_cache=os.environ.get('ST_TUNE_CACHE')))
     model.detector.load_state_dict({k: v for k, v in sd.items() if not k.startswith('stereo.')}, strict=False)
     model.stereo.load_state_dict({k[len('stereo.'):]: v for k, v in sd.items() if k.startswith('stereo.')})
@@ -584,7 +590,8 @@ def main():
                                'full YOLOX-s two-branch backbone+PAFPN+head, cost volume at 1/4 res '
                                f'({args.max_disp // 4} levels) + {args.agg_layers} 3x3 aggregation convs + soft-argmin, '
                                'decode+NMS, per-box depth',
-                   'global_batch': world * B, 'inflight_contexts': len(runner),
+                   'global_batch': world * B, 'inflight_contexts': len(runner), 'gpu_max_hw_queues': os.environ.get('GPU_MAX_HW_QUEUES'),
+                   'hip_force_dev_kernarg': os.environ.get('HIP_FORCE_DEV_KERNARG'),
                    'parallelism': f'frames sharded x{world}, one all-gather of detections per step ({backend})',
                    'detections_kept_rank0': counts, 'max_det': pipe.max_det, 'detections_overflow': False},
         'sustained': sustained,

@@ -1,5 +1,5 @@
 """GPU parity of BASELINE.json configs[1] EXACTLY as bench.py runs it: 8 synthetic 1280x720 stereo pairs per
-step, D=192, full two-branch YOLOX-s, 2 aggregation convs, 3 in-flight contexts, AUTOTUNED tile variants
+step, D=192, full two-branch YOLOX-s, 2 aggregation convs, 4 in-flight contexts, AUTOTUNED tile variants
 (Winograd, fused front, LDS-resident 1x1 + chain, LDS-DMA tiles), bench.py's own weights and seeds.
 
   (a) tuned vs untuned: all 8 pairs of the tuned in-flight run against an autotune=False serial run — every
@@ -41,7 +41,7 @@ def test_benched_configuration_parity(cuda):
     from stereotracking_amd.pipeline import InflightPipelines, StereoDensePipeline
     args = (B, (H, W), 0.5, 0.33, 1)
     kw = dict(stereo=True, max_disp=D, agg_layers=AGG)
-    runner = InflightPipelines(3, *args, **kw)
+    runner = InflightPipelines(4, *args, **kw)
     sd = synthetic_state_dict(runner.param_table(), seed=0)          # bench.py's weights
     runner.load_state_dict(sd, autotune=True)
     pipe = runner.pipes[0]
@@ -50,7 +50,7 @@ def test_benched_configuration_parity(cuda):
     batch = synthetic_batch(list(range(B)), H, W, D)                  # bench.py's rank-0 seeds
     img, right = batch['img'].to(cuda), batch['right'].to(cuda)
     outs = []
-    for _ in range(3):     # one batch per context: all three must agree bit for bit
+    for _ in range(len(runner)):     # one batch per context: all of them must agree bit for bit
         out, _ = runner.submit(img, right, post=lambda o, ctx: {k: v.clone() for k, v in o.items()})
         outs.append(out)
     runner.synchronize()
@@ -60,7 +60,7 @@ def test_benched_configuration_parity(cuda):
             assert torch.equal(o[k].nan_to_num(-7.0), out[k].nan_to_num(-7.0)), f'contexts disagree on {k}'
         assert torch.equal(head_used(pipe.det, o['head']), head_used(pipe.det, out['head']))
 
-    rec = dict(config=f'configs[1]: N={B} {W}x{H} D={D} agg={AGG} autotune=on inflight=3',
+    rec = dict(config=f'configs[1]: N={B} {W}x{H} D={D} agg={AGG} autotune=on inflight={len(runner)}',
                tuned_variants=sorted(set(names)))
     counts = out['counts'].cpu().numpy()
     rec['kept_per_image'] = counts.tolist()
