@@ -13,7 +13,7 @@ python bench.py $COMMON > $OUT/bench_plain.json 2> $OUT/bench_plain.err         
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$OUT/stats_inflight1 -- python3 $R/bench.py $COMMON --inflight 1 > $R/$OUT/bench_rocprof_inflight1.json 2> $R/$OUT/rocprof1.err
-rocprofv3 --kernel-trace --stats --output-format csv -d $R/$OUT/stats_inflight3 -- python3 $R/bench.py $COMMON > $R/$OUT/bench_rocprof_inflight3.json 2> $R/$OUT/rocprof3.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/$OUT/stats_inflight -- python3 $R/bench.py $COMMON > $R/$OUT/bench_rocprof_inflight.json 2> $R/$OUT/rocprof3.err
 PM="--steps 4 --warmup 2 --no-cpu-baseline --no-test-step --sustain-seconds 0 --inflight 1"
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CU_CYCLES --kernel-trace --output-format csv -d $R/$OUT/pmc_mfma -- python3 $R/bench.py $PM > /dev/null 2> $R/$OUT/pmc_mfma.err
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $R/$OUT/pmc_fetch -- python3 $R/bench.py $PM > /dev/null 2> $R/$OUT/pmc_fetch.err
