@@ -255,7 +255,7 @@ __global__ __launch_bounds__(128) void costvolume_tiled_kernel(const float* __re
         // chunk (the next region of the LDS allocation, which carries one slack row for this) and the values
         // are never used.  With a `cn < cc` guard the loop body had branches, the compiler waited for every
         // read batch right after issuing it and copied one register set into the other per iteration:
-        // 115 -> 93 us for the bench volume (build/cv_abl ablations).
+        // 115 -> 93 us for the bench volume on random features (timing-only ablations).
         const int cn = c + h + 1;
         lv[h ^ 1] = *reinterpret_cast<const f32x4*>(lp + cn * rowL);
 #pragma unroll
