@@ -292,6 +292,8 @@ def cpu_baseline(sd, batch_cpu, max_disp, seconds, agg_layers, max_det=1000):
     ori_h, ori_w = 720, 1280
     D = max_disp // 4
 
+    keep = {}
+
     def one_pair():
         with torch.no_grad():
             fl = ora.backbone.stage1_features(img).permute(0, 2, 3, 1).contiguous().numpy()
@@ -312,6 +314,7 @@ def cpu_baseline(sd, batch_cpu, max_disp, seconds, agg_layers, max_det=1000):
         boxes, scores, labels, prior, counts = c_oracle.decode_nms(head, 1, levels, 0.01, 0.5, max_det, (ori_h, ori_w))
         k = min(int(counts[0]), max_det)      # the same capacity as the GPU's detection buffer: no box dropped
         odepth.bbox_postp_depth(torch.from_numpy(boxes[0, :k]), disp)
+        keep['disp'] = disp
         return k
 
     one_pair()  # warm-up (oneDNN primitive caches)
@@ -329,7 +332,7 @@ def cpu_baseline(sd, batch_cpu, max_disp, seconds, agg_layers, max_det=1000):
     one_pair()
     dt1 = time.perf_counter() - t1
     torch.set_num_threads(threads)
-    return dict(value=round(n / dt, 4), unit='stereo frame-pairs/s', cores=threads, kind='port',
+    return dict(oracle_disp_pair0=keep['disp'], value=round(n / dt, 4), unit='stereo frame-pairs/s', cores=threads, kind='port',
                 value_1_thread=round(1.0 / dt1, 4),
                 sample=f'{n} x 1 synthetic 1280x720 pair (D={max_disp}, {agg_layers} aggregation convs, full YOLOX-s '
                        'two-branch), CPU oracle '
@@ -563,6 +566,19 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
+    # self-validation for the day a multi-GPU node runs this: every rank reports (rank, local device index, device
+    # uuid, name); N ranks must have used N DISTINCT devices
+    import stereotracking_amd
+    hw_queues = stereotracking_amd.effective_hw_queues()
+    props = torch.cuda.get_device_properties(dev)
+    me = dict(rank=rank, device_index=dev_index, uuid=str(getattr(props, 'uuid', '')), name=props.name)
+    ranks_seen = [me]
+    if world > 1:
+        ranks_seen = [None] * world
+        dist.all_gather_object(ranks_seen, me)
+        if backend == 'nccl' and len({(r['uuid'] or r['device_index']) for r in ranks_seen}) != world:
+            raise SystemExit(f'ranks share devices: {ranks_seen}')
+
     sustained = None
     if args.sustain_seconds > 0:     # a longer region for the eye of a GPU-busy sampler; `value` stays the K-step figure
         n_s, t1 = 0, time.perf_counter()
@@ -575,6 +591,7 @@ def main():
         sustained = dict(seconds=round(dts, 3), steps=n_s, value=round(world * B * n_s / dts, 3))
 
     counts = out['counts'].cpu().tolist()
+    disp_pair0 = out['disp_postp'][0, 0].cpu()                   # BASELINE metric's "disparity L1 vs ref" (rank 0, pair 0)
     rec_counts = out['records'][:, 0, 0].cpu().long().tolist()   # what the tracker side of the all-gather sees
     if rec_counts[rank * B:(rank + 1) * B] != counts:
         raise SystemExit(f'gathered frame records disagree with the local counts: {rec_counts} vs {counts}')
@@ -592,7 +609,9 @@ def main():
                                'decode+NMS, per-box depth',
                    'global_batch': world * B, 'inflight_contexts': len(runner), 'gpu_max_hw_queues': os.environ.get('GPU_MAX_HW_QUEUES'),
                    'hip_force_dev_kernarg': os.environ.get('HIP_FORCE_DEV_KERNARG'),
-                   'parallelism': f'frames sharded x{world}, one all-gather of detections per step ({backend})',
+                   'parallelism': (f'frames sharded x{world}, one all-gather of detections per step ({backend})'
+                                   if world > 1 else 'single process, no process group (no collective in the step)'),
+                   'ranks_seen': ranks_seen, 'hw_queues': hw_queues,
                    'detections_kept_rank0': counts, 'max_det': pipe.max_det, 'detections_overflow': False},
         'sustained': sustained,
     }
@@ -607,7 +626,8 @@ def main():
         roof['pipeline_frac'] = round(66.96e9 * line['value'] / world / (PEAK_FP32_MFMA_TFLOPS * 1e12), 4)
         roof['pipeline_definition'] = ('SURVEY.md 8(d): 66.96 GFLOP of direct convolution per pair x pairs/s per GPU / '
                                        '157.3 TFLOP/s (Winograd layers counted at their direct-convolution flops: an '
-                                       'algorithmic rate, may exceed what the pipes execute)')
+                                       'algorithmic rate, may exceed what the pipes execute; the disparity stem executes K=36 of its 108 '
+                                       'because disp_postp\'s three planes are identical: 1.09 of the 66.96 GFLOP are not executed)')
         roof['measured'] = ('separate serialized pass on one context after the timed region: with inflight > 1 the '
                             'timed region overlaps kernels of consecutive batches, which inflates per-launch durations '
                             '(compare profiles/*_inflight1 for the serialized rocprof summary)')
@@ -623,6 +643,15 @@ def main():
             line['batched_gpu_association'] = batched_association_line(dev)
         if world == 1 and not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline(sd, batch_cpu, args.max_disp, args.cpu_seconds, args.agg_layers, args.max_det)
+            # BASELINE.json's metric string ends in "disparity L1 vs ref": the GPU's disparity of pair 0 (from the last
+            # timed step) against the CPU oracle's disparity of the same pair (computed by the cpu_baseline leg above,
+            # OUTSIDE the timed region).  "ref" = the oracle: the reference ships no stereo matcher.
+            ref_d = line['cpu_baseline'].pop('oracle_disp_pair0')[0, 0]
+            ad = (disp_pair0 - ref_d).abs()
+            line['disparity_l1_vs_oracle'] = dict(
+                l1_px=float(ad.mean()), max_abs_px=float(ad.max()),
+                max_rel=float((ad / ref_d.abs().clamp(min=1.0)).max()), mean_disp_px=float(ref_d.mean()),
+                pair='rank 0 pair 0 of the timed workload', ref='oracle (CPU fp32 restatement of the stereo module)')
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

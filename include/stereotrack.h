@@ -407,7 +407,10 @@ int st_tracker_get_track(const StTracker* t, int index, int64_t* id, double* mea
  *    state / scratch: caller-owned device buffers of st_batched_tracker_{state,scratch}_bytes (state zero-filled
  *    before the first step).  out_rows (batch, max_dets, 8), out_ids (batch, max_dets), out_counts (batch),
  *    status (batch): 0 ok, 1 = more than max_tracks live tracks, 2 = counts[b] > max_dets (that sequence's
- *    output count is 0; the caller checks status).  Enqueued on `stream`, no host sync.
+ *    output count is 0; the caller checks status).  A non-zero status is STICKY: the overflow is detected after the
+ *    association has mutated the sequence's tracks, so the sequence is invalid from then on and every later step
+ *    reports the same status with an output count of 0 until a step with frame_id 0 resets it.
+ *    Enqueued on `stream`, no host sync.
  * ---------------------------------------------------------------------- */
 typedef struct StBatchedTracker StBatchedTracker;
 int st_batched_tracker_create(const StTrackerConfig* cfg, int batch, int max_tracks, int max_dets,

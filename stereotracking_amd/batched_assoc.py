@@ -55,7 +55,8 @@ class BatchedGpuTracker:
 
     def step(self, frame_ids, dets, counts, check_status=True):
         """frame_ids (batch,) int32, dets (batch, max_dets, 8) float32, counts (batch,) int32 - CUDA tensors.
-        check_status: one host sync to raise on a capacity overflow (False: read `self.status` yourself)."""
+        check_status: one host sync to raise on a capacity overflow (False: read `self.status` yourself).  A non-zero
+        status is sticky per sequence: the device state of that sequence is invalid until a step with frame_id 0."""
         for t, dt, shape in ((frame_ids, torch.int32, (self.batch,)), (dets, torch.float32, (self.batch, self.max_dets, 8)),
                              (counts, torch.int32, (self.batch,))):
             if not (t.is_cuda and t.dtype == dt and tuple(t.shape) == shape and t.is_contiguous()):

@@ -49,7 +49,10 @@ struct DTrack {
   int vel_placeholder;
 };
 
-struct SeqHeader { int n_tracks; int pad; long long num_tracks; };
+// `poisoned`: sticky status of the sequence.  A capacity overflow is detected after the association has already
+// mutated the tracks (Kalman predictions, observation windows, ids handed out), so the sequence is INVALID from then
+// on: every later step reports the same status with an output count of 0 until frame_id 0 resets it.
+struct SeqHeader { int n_tracks; int poisoned; long long num_tracks; };
 
 struct Cfg {
   float obj_score_thr, init_track_thr, match_iou_thr, vel_consist_weight;
@@ -626,12 +629,16 @@ __global__ __launch_bounds__(64) void assoc_step_kernel(Cfg cfg, const int* __re
     if (lane == 0) out_n[b] = -1;
     return;
   }
+  if (frame_id != 0 && hdr->poisoned != kOk) {   // an earlier step overflowed: the state is not a tracker state any more
+    if (lane == 0) { out_n[b] = 0; status[b] = hdr->poisoned; }
+    return;
+  }
   if (n > M) {
-    if (lane == 0) { out_n[b] = 0; status[b] = kDetOverflow; }
+    if (lane == 0) { out_n[b] = 0; status[b] = kDetOverflow; hdr->poisoned = kDetOverflow; }
     return;
   }
   if (lane == 0) {
-    if (frame_id == 0) { hdr->n_tracks = 0; hdr->num_tracks = 0; }
+    if (frame_id == 0) { hdr->n_tracks = 0; hdr->num_tracks = 0; hdr->poisoned = kOk; }
     sh[0] = hdr->n_tracks;
     sh[8] = kOk;
     int n_order = 0;
@@ -742,7 +749,7 @@ __global__ __launch_bounds__(64) void assoc_step_kernel(Cfg cfg, const int* __re
   }
   __syncthreads();
   if (sh[8] != kOk) {
-    if (lane == 0) { status[b] = sh[8]; out_n[b] = 0; }
+    if (lane == 0) { status[b] = sh[8]; out_n[b] = 0; hdr->poisoned = sh[8]; }
     return;
   }
   for (int i = lane; i < sh[1]; i += 64) {

@@ -218,9 +218,19 @@ def append_prediction_results(file_path, results):
             ids = trk.get('instances_id').cpu().numpy()
             labels = trk.get('labels').cpu().numpy()
             scores = trk.get('scores').cpu().numpy()
-            depth, gt_depth = trk.get('depth'), trk.get('gt_depth')
+            # plain floats, as the reference's d_values list yields them (a 0-d tensor would print as `tensor(10.)`)
+            depth = _as_float_list(trk.get('depth'), len(ids))
+            gt_depth = _as_float_list(trk.get('gt_depth'), len(ids))
             for iid, label, box, d, gd, sc in zip(ids, labels, boxes, depth, gt_depth, scores):
                 writer.writerow([frame_id, iid, label, *box, d, gd, sc])
+
+
+def _as_float_list(v, n):
+    if v is None:
+        return [float('nan')] * n
+    if torch.is_tensor(v):
+        v = v.detach().cpu().numpy()
+    return [float(x) for x in np.asarray(v, dtype=np.float64).reshape(-1)]
 
 
 def save_prediction_results(file_path):
@@ -285,6 +295,14 @@ class OCSORT_Disparity(nn.Module):
             import os
             if os.path.exists(results_csv):
                 os.remove(results_csv)
+        self._pre_lazy = False
+        if self.data_preprocessor is not None:
+            import inspect
+            fwd = getattr(self.data_preprocessor, 'forward', self.data_preprocessor)
+            try:
+                self._pre_lazy = 'lazy_raw' in inspect.signature(fwd).parameters
+            except (TypeError, ValueError):
+                self._pre_lazy = False
         self.lib = _lib.load()
         self._dense = {}          # (batch, ori_h, ori_w, stereo) -> [InflightPipelines, weights version]
         self._staging = {}        # name -> pinned host buffer (grow-only): no pinned allocation on the per-chunk path
@@ -298,9 +316,9 @@ class OCSORT_Disparity(nn.Module):
     def test_step(self, data):
         import time
         t0 = time.perf_counter()
-        try:
+        if self._pre_lazy:     # decided once from the preprocessor's signature (__init__), not by catching TypeError
             data = self.data_preprocessor(data, False, lazy_raw=True)
-        except TypeError:      # a preprocessor without the lazy option (e.g. mmengine's own class)
+        else:                  # a preprocessor without the lazy option (e.g. mmengine's own class)
             data = self.data_preprocessor(data, False)
         self.timings['pre_s'] += time.perf_counter() - t0
         return self.forward(data['inputs'], data['data_samples'], mode='predict')
@@ -554,6 +572,13 @@ class OCSORT_Disparity(nn.Module):
             # side stream (the chunk's forward pass has completed: `ev` above), reading the chunk's own disparity copy
             td = time.perf_counter()
             mt = max([len(t) for t in tracks_of] + [1])
+            # the page-locked (ctx, slot) pair below was the SOURCE of an asynchronous host->device copy two rounds ago:
+            # wait for that copy's event before the host overwrites the buffer (it has long completed in practice -
+            # now it is ordered, not probable)
+            slot_key = ('track_slot_event', id(runner), job['ctx'], job['slot'])
+            prev_ev = self._staging.get(slot_key)
+            if prev_ev is not None:
+                prev_ev.synchronize()
             tb = self._pinned(('track_boxes', id(runner), job['ctx'], job['slot']), (B, mt, 4)).zero_()
             tc = self._pinned(('track_counts', id(runner), job['ctx'], job['slot']), (B,), torch.int32).zero_()
             for i, t in enumerate(tracks_of):
@@ -571,6 +596,7 @@ class OCSORT_Disparity(nn.Module):
                 dh.copy_(torch.stack(cols), non_blocking=True)
                 ev2 = torch.cuda.Event()
                 ev2.record(stream)
+                self._staging[slot_key] = ev2      # recorded after the copies that read tb / tc
             pending.append((s, e, tracks_of, dh, ev2, (tbd, tcd)))
             self.timings['depth_s'] += time.perf_counter() - td
             while pending and pending[0][4].query():       # earlier chunks whose track depth has landed: complete

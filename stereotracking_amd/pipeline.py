@@ -19,13 +19,72 @@ from .engine import HipDetector, _require_cuda
 from .stereo import StereoCostVolume
 
 
-def default_tuning_cache():
-    """The tuning cache every entry point shares (bench.py, the MOT shell, the parity tests): $ST_TUNE_CACHE, else the
-    committed configs/tuning/mi355x.json.  One committed plan per graph makes the kernel instances - and with them the
-    fp32 summation order, i.e. every float the path returns - the same in the parity tests and in the bench run."""
+def committed_tuning_plans():
+    """configs/tuning/mi355x.json: the plans committed with the repository.  READ-ONLY for the package - one committed
+    plan per graph makes the kernel instances (and with them the fp32 summation order, i.e. every float the path
+    returns) the same in the parity tests and in the bench run; nothing here ever writes to a tracked file."""
     import os
-    return os.environ.get('ST_TUNE_CACHE') or os.path.join(
-        os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'configs', 'tuning', 'mi355x.json')
+    return os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'configs', 'tuning', 'mi355x.json')
+
+
+def default_tuning_cache():
+    """Where NEWLY measured plans are remembered: $ST_TUNE_CACHE, else $XDG_CACHE_HOME (or ~/.cache)
+    /stereotracking_amd/tuning.json.  Lookups consult this file first when $ST_TUNE_CACHE names it explicitly (tools
+    trying out a plan), otherwise the committed plans first."""
+    import os
+    explicit = os.environ.get('ST_TUNE_CACHE')
+    if explicit:
+        return explicit
+    base = os.environ.get('XDG_CACHE_HOME') or os.path.join(os.path.expanduser('~'), '.cache')
+    return os.path.join(base, 'stereotracking_amd', 'tuning.json')
+
+
+def _read_plans(path):
+    """-> (dict, ok).  ok is False when the file exists but cannot be parsed (then it must not be overwritten)."""
+    import json
+    import os
+    if not path or not os.path.exists(path):
+        return {}, True
+    try:
+        with open(path) as f:
+            d = json.load(f)
+        return (d, True) if isinstance(d, dict) else ({}, False)
+    except (OSError, ValueError):
+        return {}, False
+
+
+def _store_plans(path, updates):
+    """Merge `updates` into the JSON file at `path`: exclusive lock on a side file, RE-READ under the lock, write a
+    temporary file, os.replace (atomic).  Concurrent ranks / test processes that tune at the same time cannot
+    truncate each other's file; a file that exists but does not parse is left alone."""
+    import fcntl
+    import json
+    import os
+    import tempfile
+    try:
+        d = os.path.dirname(os.path.abspath(path))
+        os.makedirs(d, exist_ok=True)
+        with open(path + '.lock', 'w') as lock:
+            fcntl.flock(lock, fcntl.LOCK_EX)
+            cur, ok = _read_plans(path)
+            if not ok:
+                return False
+            cur.update(updates)
+            fd, tmp = tempfile.mkstemp(prefix='.tuning.', dir=d)
+            with os.fdopen(fd, 'w') as f:
+                json.dump(cur, f, indent=0, sort_keys=True)
+            os.replace(tmp, path)
+        return True
+    except OSError:
+        return False    # a read-only install keeps working: the plan was measured, it is just not remembered
+
+
+def _device_tag():
+    """gfx architecture + CU count of the current device: part of every plan key (a plan measured on one part says
+    nothing about another)."""
+    p = torch.cuda.get_device_properties(torch.cuda.current_device())
+    arch = str(getattr(p, 'gcnArchName', 'gpu')).split(':')[0]
+    return f'{arch}_cu{p.multi_processor_count}'
 
 
 class StereoDensePipeline:
@@ -63,45 +122,43 @@ class StereoDensePipeline:
 
     def load_state_dict(self, sd, prefix='', autotune=True, tuning_cache=None):
         """Upload weights; then pick conv tile variants by measurement, or restore them from
-        `tuning_cache` (a JSON file keyed by the graph signature; default: default_tuning_cache()) when it holds this
-        graph.  tuning_cache=False: always measure, never read or write a cache."""
-        import json
-        import os
-        if tuning_cache is None:
-            tuning_cache = default_tuning_cache()
+        a plan file (JSON keyed by graph signature + device) when one holds this graph: the COMMITTED plans
+        (committed_tuning_plans(), read-only) and the user cache (default_tuning_cache(), where new measurements are
+        merged atomically).  `tuning_cache=<path>` / $ST_TUNE_CACHE: that file is consulted first and receives new
+        measurements.  tuning_cache=False: always measure, never read or write a cache."""
         self.det.load_state_dict(sd, prefix)
         pre = prefix + 'stereo.'
         self.stereo_module.load_state_dict({k[len(pre):]: v for k, v in sd.items() if k.startswith(pre)})
         if not autotune:
             return
+        import os
         key = (f'v{self.det.lib.st_version()}_b{self.batch}_{self.height}x{self.width}_w{self.det.widen_factor:g}'
                f'_d{self.det.deepen_factor:g}_s{int(self.stereo)}_a{self.agg_layers}_D{self.D}'
-               f'_ops{self.det.lib.st_detector_num_ops(self.det.handle)}')
-        cache = {}
-        if tuning_cache and os.path.exists(tuning_cache):
-            try:
-                cache = json.load(open(tuning_cache))
-            except (OSError, ValueError):
-                cache = {}
-        if key in cache and (not self.agg_layers or key + '_agg' in cache):
-            self.det.set_tuning(cache[key])
-            if self.agg_layers:
-                self.stereo_module.variant = int(cache[key + '_agg'])
-            return
+               f'_ops{self.det.lib.st_detector_num_ops(self.det.handle)}_{_device_tag()}')
+        sources = []
+        if tuning_cache is not False:
+            explicit = tuning_cache or os.environ.get('ST_TUNE_CACHE')
+            store = explicit or default_tuning_cache()
+            sources = [store, committed_tuning_plans()] if explicit else [committed_tuning_plans(), store]
+            for path in sources:
+                cache, _ = _read_plans(path)
+                if key in cache and (not self.agg_layers or key + '_agg' in cache):
+                    self.det.set_tuning(cache[key])
+                    if self.agg_layers:
+                        self.stereo_module.variant = int(cache[key + '_agg'])
+                    self.tuning_source = path
+                    return
         self.det.autotune()
         if self.agg_layers:
             s = self.feat_stride
             dev = torch.device('cuda', torch.cuda.current_device())
             self.stereo_module.autotune(dev, self.batch, self.height // s, self.width // s)
-        if tuning_cache:
-            cache[key] = self.det.get_tuning()
+        self.tuning_source = 'measured'
+        if tuning_cache is not False:
+            upd = {key: self.det.get_tuning()}
             if self.agg_layers:
-                cache[key + '_agg'] = self.stereo_module.variant
-            try:
-                os.makedirs(os.path.dirname(os.path.abspath(tuning_cache)), exist_ok=True)
-                json.dump(cache, open(tuning_cache, 'w'), indent=0, sort_keys=True)
-            except OSError:
-                pass    # a read-only install keeps working: the plan was measured, it is just not remembered
+                upd[key + '_agg'] = self.stereo_module.variant
+            _store_plans(store, upd)     # never the committed file (unless a tool names it explicitly)
 
     # ---- buffers -----------------------------------------------------------------------------------
     def _buffers(self, dev):

@@ -67,6 +67,59 @@ def oracle_pipeline(ora, sd, img, right, levels, ori_hw, max_disp, temperature, 
                 scales=np.array([float(v) for v in s_ref], np.float64), scaled_boxes=sb_ref)
 
 
+def make_oracle64(ora):
+    """A float64 copy of the oracle detector (the 'exact' evaluation both fp32 evaluations are measured against)."""
+    import copy
+    return copy.deepcopy(ora).double()
+
+
+def stereo_fp64(fl, fr, max_disp_lr, temperature, sd, agg_layers, scale, pad_hw, valid_hw, prefix='stereo.'):
+    """The stereo module's arithmetic (oracle/st_oracle.c: cost volume, aggregation convs, soft-argmin, bilinear
+    upsample; same formulas) evaluated in float64 torch.  fl / fr: (1,C,Hf,Wf) double -> disp (1,3,H,W) double."""
+    import torch.nn.functional as F
+    _, Cc, Hf, Wf = fl.shape
+    cost = torch.zeros(1, max_disp_lr, Hf, Wf, dtype=torch.float64)
+    for d in range(max_disp_lr):
+        cost[0, d, :, d:] = (fl[0, :, :, d:] * fr[0, :, :, :Wf - d]).sum(0) / Cc
+    x = cost
+    for l in range(agg_layers):
+        x = F.conv2d(x, sd[f'{prefix}agg.{l}.weight'].double(), sd[f'{prefix}agg.{l}.bias'].double(), padding=1)
+        if l < agg_layers - 1:
+            x = F.silu(x)
+    p = torch.softmax(temperature * x, dim=1)
+    lr = (p * torch.arange(max_disp_lr, dtype=torch.float64).view(1, -1, 1, 1)).sum(1, keepdim=True)
+    up = F.interpolate(lr, scale_factor=scale, mode='bilinear', align_corners=False) * scale
+    H, W = pad_hw
+    out = torch.zeros(1, 1, H, W, dtype=torch.float64)
+    vh, vw = valid_hw
+    out[..., :vh, :vw] = up[..., :vh, :vw]
+    return out.expand(1, 3, H, W).contiguous()
+
+
+def oracle_pipeline64(ora64, sd, img, right, levels, ori_hw, max_disp, temperature, agg_layers):
+    """One pair through the path's arithmetic in float64: -> dict(disp (1,3,H,W) f64, scores (P,) f64, boxes (P,4) f64
+    for EVERY prior, decoded / clamped as oracle/st_oracle.c does)."""
+    H, W = ori_hw
+    with torch.no_grad():
+        fl = ora64.backbone.stage1_features(img.double())
+        fr = ora64.backbone.stage1_features(right.double())
+        disp = stereo_fp64(fl, fr, max_disp // 4, float(temperature), sd, agg_layers, 4, tuple(img.shape[-2:]), (H, W))
+        rows = head_to_rows(*ora64(dict(img=img.double(), disp_postp=disp)))
+    sc, bx = [], []
+    for r, (h, w, s, _) in zip(rows, levels):
+        r = r[0].numpy()
+        ys, xs = np.divmod(np.arange(h * w), w)
+        score = (1 / (1 + np.exp(-r[:, 0]))) * (1 / (1 + np.exp(-r[:, 5])))
+        cx, cy = r[:, 1] * s + xs * s, r[:, 2] * s + ys * s
+        bw, bh = np.exp(r[:, 3]) * s, np.exp(r[:, 4]) * s
+        b = np.stack([cx - bw / 2, cy - bh / 2, cx + bw / 2, cy + bh / 2], 1)
+        b[:, 0::2] = np.clip(b[:, 0::2], 0, W)
+        b[:, 1::2] = np.clip(b[:, 1::2], 0, H)
+        sc.append(score)
+        bx.append(b)
+    return dict(disp=disp, scores=np.concatenate(sc), boxes=np.concatenate(bx), rows=rows)
+
+
 def align_kept(pa, pb):
     """Two kept-prior lists (score order) -> (ia, ib): positions of the COMMON priors in each, in a's order."""
     posb = {int(p): k for k, p in enumerate(pb)}

@@ -131,3 +131,63 @@ def test_capacity_overflow_is_reported(cuda):
     assert int(n[0]) == 3 and ids[0, :3].tolist() == [0, 1, 2] and trk.status.tolist() == [0, 1]
     with pytest.raises(ValueError):
         trk.step(torch.zeros(2, dtype=torch.int64, device=cuda), dets, counts)
+    # the overflow is STICKY: sequence 1 keeps reporting it (count 0) on later frames, sequence 0 carries on; frame 0 resets
+    small = torch.tensor([3, 2], dtype=torch.int32, device=cuda)
+    trk.step(torch.ones(2, dtype=torch.int32, device=cuda), dets, small, check_status=False)
+    assert trk.status.tolist() == [0, 1] and trk.n.tolist() == [3, 0] and trk.ids[0, :3].tolist() == [0, 1, 2]
+    trk.step(torch.zeros(2, dtype=torch.int32, device=cuda), dets, small, check_status=False)
+    assert trk.status.tolist() == [0, 0] and trk.n.tolist() == [3, 2]
+
+
+# ---- against the ORACLE tracker's committed fixtures (round 4: the row rule of SURVEY.md 8 f-4 on hardware) ----------
+import os  # noqa: E402
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+STRESS = dict(SHIPPED, obj_score_thr=0.02, init_track_thr=0.05)
+
+
+def batched_rows(det, T, cfg, cuda, max_dets, max_tracks):
+    """One sequence through BatchedGpuTracker -> rows [t, id, box (4), score, depth, scale] float64, the layout of the
+    oracle fixtures (tests/golden/make_golden.run_oracle_tracker)."""
+    trk = BatchedGpuTracker(1, max_tracks=max_tracks, max_dets=max_dets, device=cuda, **cfg)
+    out = []
+    for t in range(T):
+        d = det[det[:, 0] == t]
+        k = len(d)
+        assert k <= max_dets
+        dets = np.zeros((1, max_dets, 8), np.float32)
+        dets[0, :k, 0:4] = d[:, 1:5]
+        dets[0, :k, 4], dets[0, :k, 6], dets[0, :k, 7] = d[:, 5], d[:, 6], d[:, 7]
+        rows, ids, n = trk.step(torch.full((1,), t, dtype=torch.int32, device=cuda), torch.from_numpy(dets).to(cuda),
+                                torch.tensor([k], dtype=torch.int32, device=cuda))
+        m = int(n[0])
+        r, i = rows[0, :m].cpu().double().numpy(), ids[0, :m].cpu().numpy()
+        for j in range(m):
+            out.append([t, int(i[j]), *r[j, 0:4], r[j, 4], r[j, 6], r[j, 7]])
+    return np.asarray(out, np.float64).reshape(-1, 9)
+
+
+def test_oracle_tracker_fixture_64_frames(cuda):
+    """tests/golden/tracker_sequence.npz: the ORACLE tracker (oracle/tracker.py, restatement of reference
+    ocsort_tracker_disparity.py:345-618) on the 64-frame stream with dropped detections and an 8-frame occlusion,
+    shipped thresholds.  assoc_step_kernel must return the same ids, in the same order, with bit-identical rows."""
+    g = np.load(os.path.join(GOLDEN, 'tracker_sequence.npz'))
+    det, ref, T = g['detections'], g['tracks'], int(g['num_frames'])
+    got = batched_rows(det, T, SHIPPED, cuda, 32, 64)
+    assert got.shape == ref.shape and np.array_equal(got, ref)
+    assert len(set(ref[:, 1].tolist())) >= 6
+
+
+@pytest.mark.parametrize('name,cfg', [('shipped', SHIPPED), ('stress', STRESS)])
+@pytest.mark.parametrize('px', ['', 'wn_'])
+def test_oracle_tracker_fixture_config2(px, name, cfg, cuda):
+    """tests/golden/config2_sequence.npz: the ORACLE pipeline's detection stream of the configs[2] sequences (380-680
+    detections per frame at 1280x720; blurred and white-noise textures) and the ORACLE tracker's rows for the shipped
+    and the stress thresholds (up to ~400 tracks per frame, 9618 rows).  Device association == oracle, row for row."""
+    g = np.load(os.path.join(GOLDEN, 'config2_sequence.npz'))
+    det, ref, T = g[px + 'detections'], g[px + 'tracks_' + name], int(g['T'])
+    got = batched_rows(det, T, cfg, cuda, 1024, 4096)
+    assert got.shape == ref.shape, (got.shape, ref.shape)
+    assert np.array_equal(got[:, :2], ref[:, :2]), 'frame / id columns differ'
+    assert np.array_equal(got, ref)
+    assert len(ref) > T

@@ -321,3 +321,32 @@ def test_stereo_config_builds_cost_volume_module_with_aggregation():
         st(torch.zeros(1, 48, 4, 4))
     with pytest.raises(ValueError):
         MODELS.build(dict(type='StereoCostVolume', max_disp=40, agg_layers=1))   # 10 levels: not a multiple of 4
+
+
+def _store_worker(args):
+    path, k = args
+    from stereotracking_amd.pipeline import _store_plans
+    return _store_plans(path, {f'key{k}': [k] * 50})
+
+
+def test_tuning_cache_store_is_atomic_and_merging(tmp_path):
+    """plans measured by concurrent ranks / test processes are MERGED (lock + re-read + tmp file +
+    os.replace); a file that does not parse is never overwritten; the committed plan file is not the write target."""
+    import json
+    import multiprocessing as mp
+    from stereotracking_amd import pipeline as pl
+    path = str(tmp_path / 'cache' / 'tuning.json')
+    with mp.get_context('spawn').Pool(4) as pool:
+        assert all(pool.map(_store_worker, [(path, k) for k in range(16)]))
+    got = json.load(open(path))
+    assert sorted(got) == sorted(f'key{k}' for k in range(16))      # nobody's key was dropped
+    bad = str(tmp_path / 'bad.json')
+    open(bad, 'w').write('{"truncated": [1, 2')
+    assert pl._store_plans(bad, {'x': 1}) is False
+    assert open(bad).read() == '{"truncated": [1, 2'
+    assert pl._read_plans(bad) == ({}, False)
+    os.environ.pop('ST_TUNE_CACHE', None)
+    assert os.path.abspath(pl.default_tuning_cache()) != os.path.abspath(pl.committed_tuning_plans())
+    assert not pl.default_tuning_cache().startswith(ROOT + os.sep + 'configs')
+    plans, ok = pl._read_plans(pl.committed_tuning_plans())
+    assert ok and all('gfx950_cu256' in k for k in plans)            # device identity is part of every key

@@ -155,6 +155,10 @@ def test_prediction_results_csv_side_effect(tmp_path):
     lines = open(path).read().strip().split('\n')
     assert lines[0].split(',') == CSV_HEADER and len(lines) == 1 + 3 * 2
     assert lines[1].split(',')[:7] == ['0', '3', '0', '1.0', '2.0', '3.0', '4.0']
+    # depth / gt_depth / score are plain floats (the reference writes a Python list's values), never `tensor(10.)`
+    assert [float(v) for v in lines[1].split(',')[7:]] == [10.0, 10.0, 0.5]
+    assert [float(v) for v in lines[2].split(',')[7:]] == [-1.0, -1.0, 0.25]
+    assert 'tensor' not in open(path).read()
     assert lines[-1].split(',')[0] == '2'
     import pytest
     with pytest.raises(ValueError):

@@ -16,7 +16,7 @@ import time
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from stereotracking_amd.pipeline import InflightPipelines, default_tuning_cache  # noqa: E402
+from stereotracking_amd.pipeline import InflightPipelines, committed_tuning_plans  # noqa: E402
 from stereotracking_amd.synthetic import synthetic_batch, synthetic_state_dict  # noqa: E402
 
 ap = argparse.ArgumentParser()
@@ -24,7 +24,7 @@ ap.add_argument('--passes', type=int, default=1)
 ap.add_argument('--steps', type=int, default=24)
 ap.add_argument('--reps', type=int, default=3)
 ap.add_argument('--gain', type=float, default=0.004, help='relative improvement a change must show (noise floor)')
-ap.add_argument('--out', default=default_tuning_cache())
+ap.add_argument('--out', default=committed_tuning_plans())
 a = ap.parse_args()
 dev = torch.device('cuda:0')
 runner = InflightPipelines(3, 8, (720, 1280), 0.5, 0.33, 1, stereo=True, max_disp=192, agg_layers=2)
