@@ -284,21 +284,19 @@ def track_gathered(dets, counts, num_frames, tracker, model):
     return results
 
 
-def run_sharded_sequence(pipe, frames, tracker, model, device):
-    """configs[3]: shard `frames` over the ranks, detect, all-gather once, track everywhere."""
-    frames = list(frames)
-    T = len(frames)
-    start, stop, chunk = sdist.shard_frames(T)
-    B = (pipe.pipes[0] if hasattr(pipe, 'submit') else pipe).batch
-    per_rank = (chunk + B - 1) // B * B   # equal padded length on every rank
-    mine = frames[start:stop]
-    if mine:
-        dets, _ = detect_shard(pipe, mine, device, check_overflow=False)   # raised after the gather, on every rank
-    else:
-        dets = torch.zeros(0, pipe.max_det + 1, 8, device=device)
+def gather_shard_records(dets, num_frames, batch, device):
+    """The exchange step of configs[3]: this rank's (F_local, M + 1, C) frame records -> the records of ALL
+    `num_frames` frames in frame order, on every rank.  Pads the shard to the common padded length (ceil(chunk / batch)
+    * batch slots per rank, ragged last shards included), issues ONE all-gather through the process's communication
+    stream (dist.DetectionGatherer) and drops the per-rank padding again."""
+    T = int(num_frames)
+    _, _, chunk = sdist.shard_frames(T)
+    per_rank = (chunk + batch - 1) // batch * batch   # equal padded length on every rank
     pad = per_rank - dets.shape[0]
+    if pad < 0:
+        raise ValueError(f'shard holds {dets.shape[0]} records, more than the padded shard length {per_rank}')
     if pad:
-        dets = torch.cat([dets, dets.new_zeros(pad, pipe.max_det + 1, 8)])
+        dets = torch.cat([dets, dets.new_zeros((pad,) + tuple(dets.shape[1:]))])
     # ONE collective (the records carry their own counts), on the process's communication stream
     all_dets, done = sdist.DetectionGatherer(device).gather(dets)
     if done is not None:
@@ -306,7 +304,21 @@ def run_sharded_sequence(pipe, frames, tracker, model, device):
     _, world = sdist.world()
     # drop the per-rank padding: rank r holds frames [r*chunk, r*chunk + chunk) in its first `chunk` slots
     idx = torch.cat([torch.arange(r * per_rank, r * per_rank + chunk) for r in range(world)])[:T]
-    return track_gathered(all_dets[idx.to(all_dets.device)], None, T, tracker, model)
+    return all_dets[idx.to(all_dets.device)]
+
+
+def run_sharded_sequence(pipe, frames, tracker, model, device):
+    """configs[3]: shard `frames` over the ranks, detect, all-gather once, track everywhere."""
+    frames = list(frames)
+    T = len(frames)
+    start, stop, chunk = sdist.shard_frames(T)
+    B = (pipe.pipes[0] if hasattr(pipe, 'submit') else pipe).batch
+    mine = frames[start:stop]
+    if mine:
+        dets, _ = detect_shard(pipe, mine, device, check_overflow=False)   # raised after the gather, on every rank
+    else:
+        dets = torch.zeros(0, pipe.max_det + 1, 8, device=device)
+    return track_gathered(gather_shard_records(dets, T, B, device), None, T, tracker, model)
 
 
 def run_video_replicas(pipe, videos, make_tracker, model, device, metrics=None, gts=None):

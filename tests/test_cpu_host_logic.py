@@ -350,3 +350,76 @@ def test_tuning_cache_store_is_atomic_and_merging(tmp_path):
     assert not pl.default_tuning_cache().startswith(ROOT + os.sep + 'configs')
     plans, ok = pl._read_plans(pl.committed_tuning_plans())
     assert ok and all('gfx950_cu256' in k for k in plans)            # device identity is part of every key
+
+
+# ---- configs[3] at its stated shape: 512 frames, world 8, gloo (VERDICT r3 next #8a) --------------------------------
+def _records_from_stream(det, T, M):
+    """Detection rows [t, box, score, depth, scale] -> (T, M + 1, 8) frame records (pack_detections layout)."""
+    rec = np.zeros((T, M + 1, 8), np.float32)
+    for t in range(T):
+        d = det[det[:, 0] == t]
+        k = len(d)
+        rec[t, 0, :3] = (k, M, 1)
+        rec[t, 1:1 + k, 0:4] = d[:, 1:5]
+        rec[t, 1:1 + k, 4], rec[t, 1:1 + k, 6], rec[t, 1:1 + k, 7] = d[:, 5], d[:, 6], d[:, 7]
+    return torch.from_numpy(rec)
+
+
+def _config3_tracks(records, T):
+    from stereotracking_amd.motion import KalmanFilter
+    from stereotracking_amd.sequence import track_gathered
+    from stereotracking_amd.trackers import OCSORTTracker_Disparity
+
+    class _M:
+        motion = KalmanFilter()
+    trk = OCSORTTracker_Disparity(obj_score_thr=0.3, init_track_thr=0.7, weight_iou_with_det_scores=False,
+                                  match_iou_thr=0.1, num_tentatives=3, vel_consist_weight=0.2, vel_delta_t=3,
+                                  num_frames_retain=30)
+    res = track_gathered(records, None, T, trk, _M())
+    return [r.instances_id.tolist() for r in res], [float(r.bboxes.double().sum()) for r in res]
+
+
+def _config3_worker(rank, world, port, T, B, q):
+    import torch.distributed as dist
+    from stereotracking_amd import dist as sdist
+    from stereotracking_amd.sequence import gather_shard_records
+    from stereotracking_amd.synthetic import synthetic_detection_stream
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    torch.set_num_threads(1)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    records = _records_from_stream(synthetic_detection_stream(77, T, K=8, occlusion=(2, 200, 215)), T, 16)
+    start, stop, _ = sdist.shard_frames(T)
+    everything = gather_shard_records(records[start:stop].clone(), T, B, torch.device('cpu'))
+    ids, sums = _config3_tracks(everything, T)
+    q.put((rank, start, stop, bool(torch.equal(everything, records)), ids, sums))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('T', [512, 509])
+def test_config3_sharded_sequence_world8_gloo(T):
+    """BASELINE configs[3] at its stated shape, on CPU: 512 recorded frame records sharded 8-way (T = 509: ragged, the
+    last rank holds 61 of 64 slots, and the shards are padded to a multiple of the 8-frame launch plan) -> ONE
+    all-gather (gloo) -> the tracker on every rank: the gathered records equal the unsharded ones bit for bit and the
+    track ids / boxes equal the single-process run on every rank (reference sharding: video_sampler.py:25-70; gather:
+    mot_drone_metrics.py:336-358)."""
+    from stereotracking_amd.synthetic import synthetic_detection_stream
+    world, B = 8, 8
+    ref_ids, ref_sums = _config3_tracks(
+        _records_from_stream(synthetic_detection_stream(77, T, K=8, occlusion=(2, 200, 215)), T, 16), T)
+    assert len(set(i for f in ref_ids for i in f)) >= 8 and sum(len(f) for f in ref_ids) > 3 * T
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_config3_worker, args=(r, world, port, T, B, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=300) for _ in range(world)), key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    chunk = (T + world - 1) // world
+    for rank, start, stop, equal, ids, sums in res:
+        assert (start, stop) == (min(rank * chunk, T), min(rank * chunk + chunk, T))
+        assert equal, f'rank {rank}: gathered records differ from the unsharded stream'
+        assert ids == ref_ids and sums == ref_sums, f'rank {rank}: tracks differ from the single-process run'
