@@ -422,6 +422,17 @@ int st_batched_tracker_step(StBatchedTracker* t, const int32_t* frame_ids_dev, c
                             const int32_t* counts_dev, void* state_dev, void* scratch_dev, float* out_rows_dev,
                             int64_t* out_ids_dev, int32_t* out_counts_dev, int32_t* status_dev, st_stream_t stream);
 
+/* ----------------------------------------------------------------------
+ * Dataset reader helper (host, no GPU): reverse the PNG scanline filters (RFC 2083 6: None/Sub/Up/Average/Paeth).
+ * Replaces the OpenCV PNG decode behind mmcv.imfrombytes(..., flag='unchanged') that the reference's loaders call
+ * (mmtrack/datasets/transforms/loading_disparity.py:74-75 uint16 disparity, :213-215 uint16 depth; mmcv's
+ * LoadImageFromFile for the uint8 left / right images).  Container parsing and inflate stay in the host language
+ * (Python zlib, stereotracking_amd/datasets.py).
+ *   filtered: height rows of (1 filter-type byte + stride data bytes), as inflate yields them;
+ *   bpp: bytes per complete pixel (1 gray8, 2 gray16, 3 rgb8, 4 rgba8, 6 rgb16, 8 rgba16); out: height x stride.
+ * ---------------------------------------------------------------------- */
+int st_png_unfilter(const uint8_t* filtered, int height, int stride, int bpp, uint8_t* out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -112,6 +112,22 @@ class HostSequence:
             self.codes = torch.from_numpy(np.stack(codes).view(np.int16)).pin_memory()
         self.gt = [f.get('gt') for f in frames]
 
+    @classmethod
+    def from_raw(cls, left, right=None, codes=None, gt=None, pin=True):
+        """From decoded dataset bytes (datasets.load_video): left / right uint8 (T,3,h,w), codes uint16 (T,h,w) PNG
+        disparity codes (65535 = invalid) - no float round trip."""
+        self = cls.__new__(cls)
+        mk = (lambda a: torch.from_numpy(np.ascontiguousarray(a)).pin_memory()) if pin else \
+            (lambda a: torch.from_numpy(np.ascontiguousarray(a)))
+        self.use_right = right is not None
+        self.left = mk(np.asarray(left, np.uint8))
+        self.right = mk(np.asarray(right, np.uint8)) if right is not None else None
+        self.codes = mk(np.asarray(codes, np.uint16).view(np.int16)) if codes is not None else None
+        if (self.right is None) == (self.codes is None):
+            raise ValueError('HostSequence.from_raw takes either right images or disparity codes')
+        self.gt = list(gt) if gt is not None else [None] * self.left.shape[0]
+        return self
+
     def __len__(self):
         return self.left.shape[0]
 
@@ -321,7 +337,7 @@ def run_sharded_sequence(pipe, frames, tracker, model, device):
     return track_gathered(gather_shard_records(dets, T, B, device), None, T, tracker, model)
 
 
-def run_video_replicas(pipe, videos, make_tracker, model, device, metrics=None, gts=None):
+def run_video_replicas(pipe, videos, make_tracker, model, device, metrics=None, gts=None, already_sharded=False):
     """The reference's multi-GPU mode (mmtrack/datasets/samplers/video_sampler.py:25-70): WHOLE videos are dealt to
     the ranks in contiguous blocks (dist.shard_videos = np.array_split over the video list), every rank runs its videos
     sequentially with a fresh tracker per video and there is NO communication in the loop; only the evaluation gathers
@@ -329,7 +345,8 @@ def run_video_replicas(pipe, videos, make_tracker, model, device, metrics=None, 
     frame dicts (or HostSequence); `gts`: optional dict name -> per-frame lists of gt instance dicts.
     -> (dict name -> per-frame track InstanceData for THIS rank's videos, scores dict or None)."""
     names = sorted(videos)
-    mine = [names[i] for i in sdist.shard_videos(len(names))]
+    # already_sharded: `videos` holds only THIS rank's videos (datasets.load_videos reads a rank's share of the files)
+    mine = names if already_sharded else [names[i] for i in sdist.shard_videos(len(names))]
     uploader = None
     results = {}
     for name in mine:
