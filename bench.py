@@ -135,6 +135,8 @@ def conv_roofline(pipe, img, right, steps):
         n_events = n_launch      # every op of the plan is bracketed by its own event pair, fused-away ops included
         if VARIANT_TILES[v] == 'front3x3s2':
             n_launch //= 3      # one launch computes three ops of the plan (3x3/s2 + main|short + conv1)
+        if VARIANT_TILES[v] == 'wino2x2g+':
+            n_launch = 0        # riders of a grouped Winograd launch: computed by the 'wino2x2g' op in front of them
         per_variant[VARIANT_TILES[v]] = dict(launches=n_launch, event_pairs=n_events, ms_per_step=round(float(t), 4),
                                              gflop_per_step=round(fl / 1e9, 3),
                                              tflops=round(fl / (t * 1e-3) / 1e12, 3) if t > 0 else 0.0)
@@ -148,6 +150,7 @@ def conv_roofline(pipe, img, right, steps):
     # so its algorithmic rate may exceed the MFMA peak (`algorithmic_speedup`).
     FAMILY = {'stem6x6s2': 'st::stem_focus_conv_kernel', 'pw128': 'st::pw_conv_kernel', 'dc4x32': 'st::direct_conv3x3_kernel',
               'wino2x2': 'st::wino_conv3x3_kernel', 'wino2x2n': 'st::wino_conv3x3_kernel', 'skipped': None,
+              'wino2x2g': 'st::wino_conv3x3_kernel', 'wino2x2g+': 'st::wino_conv3x3_kernel',   # grouped launches
               'front3x3s2': 'st::front_s2_csp_kernel', 'pwres': 'st::pw_resident_kernel',
               'headpred': 'st::head_pred_kernel'}   # (a VALU reduction, listed with the conv ops it replaces)
     fam = {}
@@ -163,7 +166,7 @@ def conv_roofline(pipe, img, right, steps):
         e['instances'].append(name)
     # Durations: raw HIP-event times carry the event-pair overhead (two barrier packets, measured above on this stream:
     # `event_pair_overhead_us`); rocprofv3's kernel durations do not.  The overhead is subtracted per launch so that
-    # `achieved` / `avg_launch_us` reproduce from profiles/r03_kernel_stats_inflight1.csv (the raw figures are kept
+    # `achieved` / `avg_launch_us` reproduce from profiles/r04_kernel_stats_inflight1.csv (the raw figures are kept
     # next to them).  `frac` is a fraction of the INSTRUCTION peak: flops the matrix pipes execute / time / 157.3 - for
     # the Winograd family that is the direct-convolution count / 2.25 (F(2x2,3x3) issues 16 of every 36 multiplies),
     # which goes into `algorithmic_speedup`, never into `frac`.
@@ -187,21 +190,21 @@ def conv_roofline(pipe, img, right, steps):
     conv_fl = 2.0 * float(macs[kind == 1].sum() + agg_macs * sum(a[0] for a in agg.values()) / steps)
     conv_exec = sum(e['executed_gflop_per_step'] for e in fam.values()) * 1e9
     # HBM bytes per launch of the dominant family from this round's rocprofv3 PMC passes of this command (FETCH_SIZE x2
-    # gfx950 correction + WRITE_SIZE, separate passes; tools/profile_round.sh writes profiles/r03_hbm_traffic.json from
+    # gfx950 correction + WRITE_SIZE, separate passes; tools/profile_round.sh writes profiles/r04_hbm_traffic.json from
     # the SAME commit's library).  null when that file is absent: never a number from another round.
     traffic, traffic_src = None, None
-    tpath = os.path.join(ROOT, 'profiles', 'r03_hbm_traffic.json')
+    tpath = os.path.join(ROOT, 'profiles', 'r04_hbm_traffic.json')
     if os.path.exists(tpath):
         tj = json.load(open(tpath))
         tot_b, cov = 0.0, 0
         for kname, row in tj.items():
-            if kname.startswith(dom) and row.get('fetch_bytes_corrected_per_launch') is not None:
+            if (kname.startswith(dom) or (dom == WINO and 'wino_conv3x3_group_kernel' in kname)) and row.get('fetch_bytes_corrected_per_launch') is not None:
                 n = row.get('fetch_calls') or 0
                 tot_b += n * (row['fetch_bytes_corrected_per_launch'] + (row.get('write_bytes_per_launch') or 0))
                 cov += n
         if cov:
             traffic = int(tot_b / cov)
-            traffic_src = ('profiles/r03_hbm_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command '
+            traffic_src = ('profiles/r04_hbm_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command '
                            '(separate runs of tools/profile_round.sh), launch-weighted over %s*' % dom)
     roof = dict(bound='mfma', kernel=dom + ('<...> (all tile instances)' if dom == 'st::conv_igemm_kernel' else ''),
                 achieved=D['tflops'], peak=PEAK_FP32_MFMA_TFLOPS, unit='TFLOP/s', frac=D['frac'],
@@ -217,7 +220,7 @@ def conv_roofline(pipe, img, right, steps):
                            '/ summed kernel duration of the family in a serialized pass (HIP events on the launch '
                            'stream minus the measured event-pair overhead; an event-bracketed launch also carries its '
                            'dispatch latency, so these durations read ~4 % above the rocprofv3 kernel-trace durations '
-                           'of the same launches in profiles/r03_kernel_stats_inflight1.csv: `achieved` is a lower '
+                           'of the same launches in profiles/r04_kernel_stats_inflight1.csv: `achieved` is a lower '
                            'bound); frac = achieved / peak <= 1',
                 families=fam,
                 all_mfma_kernels=dict(ms_per_step=round(conv_ms, 4),

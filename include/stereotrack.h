@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define ST_VERSION 300
+#define ST_VERSION 400
 
 enum {
   ST_OK = 0,
@@ -307,6 +307,13 @@ int st_decode_nms(const StDecodeDesc* d, const float* head_out_dev, void* worksp
 int st_costvolume_softargmin(const float* featL_dev, const float* featR_dev, int N, int Hf,
                              int Wf, int C, int feat_ld, int D, float temperature,
                              float* out_cost_dev, float* out_disp_dev, st_stream_t stream);
+/* One 3-D aggregation layer on the materialised volume [N][Hf][Wf][D] (north_star: "its 3D/2D aggregation"; no
+ * reference function - the specification is oracle/st_oracle.c::oracle_agg3d, bit-exact): a single-channel 3x3x3
+ * convolution over (d, y, x), zero padded, out = act(bias + sum w[kD][kH][kW] * vol[d+kD-1, y+kH-1, x+kW-1]),
+ * act = SiLU (1) or none (0).  weight27_host: the 27 taps in (kD, kH, kW) order, HOST memory (they travel in the
+ * kernel arguments).  vol_in != vol_out, 16-byte aligned, D a multiple of 4 (<= 192). */
+int st_volume_agg3d(const float* vol_in_dev, float* vol_out_dev, int N, int Hf, int Wf, int D,
+                    const float* weight27_host, float bias, int act, st_stream_t stream);
 /* soft-argmin only, on an (aggregated) volume [N][Hf][Wf][D] */
 int st_softargmin(const float* cost_dev, int N, int Hf, int Wf, int D, float temperature,
                   float* out_disp_dev, st_stream_t stream);

@@ -104,3 +104,16 @@ def disp_upsample(lr, scale, valid_h, valid_w):
     lib.oracle_disp_upsample(_p(lr), C.c_int(N), C.c_int(Hf), C.c_int(Wf), C.c_int(scale), C.c_int(Hf * scale),
                              C.c_int(Wf * scale), C.c_int(valid_h), C.c_int(valid_w), _p(out))
     return out
+
+
+def agg3d(vol, weight, bias, act):
+    """One 3-D aggregation layer (oracle_agg3d): vol (N,Hf,Wf,D) float32, weight (3,3,3) in (kD,kH,kW) order (a Conv3d
+    (1,1,3,3,3) weight squeezed), bias scalar, act: SiLU or not -> (N,Hf,Wf,D)."""
+    lib = load()
+    vol = np.ascontiguousarray(vol, np.float32)
+    w = np.ascontiguousarray(np.asarray(weight, np.float32).reshape(27))
+    N, Hf, Wf, D = vol.shape
+    out = np.zeros_like(vol)
+    lib.oracle_agg3d(_p(vol), C.c_int(N), C.c_int(Hf), C.c_int(Wf), C.c_int(D), _p(w), C.c_float(float(bias)),
+                     C.c_int(int(bool(act))), _p(out))
+    return out

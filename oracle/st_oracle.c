@@ -314,3 +314,30 @@ int oracle_disp_upsample(const float* lr, int N, int Hf, int Wf, int scale, int 
       }
   return 0;
 }
+
+/* ---- 3-D aggregation of the cost volume (specification; north_star: "3D/2D aggregation") -------------------------
+ * One layer = a single-channel 3x3x3 convolution over (d, y, x) of the volume [N][Hf][Wf][D] with zero padding in all
+ * three dimensions, optional SiLU:
+ *   out[d,y,x] = act( b + sum_{j,k,i} w[i][j][k] * vol[d+i-1, y+j-1, x+k-1] )
+ * w = the Conv3d weight (1,1,3,3,3) in (kD, kH, kW) order.  Accumulation order (the kernel's, bit for bit): acc = b;
+ * for j (row), for k (column), for i (disparity): acc = fmaf(w[i][j][k], v, acc) with v = 0 outside the volume (the
+ * fmaf is executed for padded taps, too).  SiLU = v / (1 + st_expf(-v)). */
+int oracle_agg3d(const float* vol, int N, int Hf, int Wf, int D, const float* w27, float bias, int act, float* out) {
+  for (int n = 0; n < N; ++n)
+    for (int y = 0; y < Hf; ++y)
+      for (int x = 0; x < Wf; ++x)
+        for (int d = 0; d < D; ++d) {
+          float acc = bias;
+          for (int j = 0; j < 3; ++j)
+            for (int k = 0; k < 3; ++k)
+              for (int i = 0; i < 3; ++i) {
+                const int yy = y + j - 1, xx = x + k - 1, dd = d + i - 1;
+                const float v = (yy >= 0 && yy < Hf && xx >= 0 && xx < Wf && dd >= 0 && dd < D)
+                                    ? vol[(((size_t)n * Hf + yy) * Wf + xx) * D + dd] : 0.0f;
+                acc = fmaf(w27[(i * 3 + j) * 3 + k], v, acc);
+              }
+          if (act) acc = acc / (1.0f + st_expf(-acc));
+          out[(((size_t)n * Hf + y) * Wf + x) * D + d] = acc;
+        }
+  return 0;
+}

@@ -37,6 +37,8 @@ bool pw_chain_applicable(const StConvDesc& d, const StConvDesc& c);
 bool dc_conv_applicable(const StConvDesc& d);
 bool wino_conv_applicable(const StConvDesc& d);
 bool wino_shape_ok(int Cin, int Cout);
+bool wino_group_applicable(const StConvDesc* d, int n);
+int wino_group_launch(const StConvDesc* d, int n, hipStream_t stream);
 size_t wino_packed_floats(int Cout, int Cin);
 int wino_pack_weights(const float* packed, int Cout, int Cin, float* out);
 int pw_conv_launch(const StConvDesc& d, hipStream_t stream, const StConvDesc* chain);
@@ -153,6 +155,8 @@ struct Op {
   // PRED (head_pred.hip): per level the two tower outputs, the packed conv_cls / conv_reg|obj and the head rows
   TRef pred_cls[3], pred_reg[3], pred_out[3];
   int pred_pcc[3] = {-1, -1, -1}, pred_pcr[3] = {-1, -1, -1};
+  int wgroup = 0;           // > 0: consecutive ops with the same wgroup are INDEPENDENT 3x3 convs (head towers of the
+                            // three levels) and run as ONE grouped Winograd launch when all of them are tuned to it
   bool front_next2 = false; // this 3x3/s2 conv and the NEXT TWO ops (CSP main|short, blocks.0.conv1) are one launch
                             // of front_fused.hip (variant 45) whenever the three descriptors qualify
 };
@@ -189,6 +193,7 @@ struct StDetector {
   bool no_wino = false;            // keep the autotuner off the Winograd instance (exact-MFMA-order A/B runs)
   bool allow_chain = true;         // fuse CSP main_conv -> bottleneck conv1 when both run on the streaming kernel
   bool allow_front = true;         // fuse stage1.0 -> main|short -> conv1 (front_fused.hip)
+  bool allow_wgroup = true;        // head tower convs of the three levels as grouped Winograd launches
 #ifdef ST_ABLATION
   std::vector<char> skip;          // tools-only: ops whose launches are dropped (st_detector_set_skip)
 #endif
@@ -378,6 +383,7 @@ int StDetector::build() {
 #ifdef ST_ABLATION   // tools-only build: ST_NO_FUSED_STEM=1 forces the two-kernel path (A/B measurements)
   if (getenv("ST_NO_FUSED_STEM")) fused_stem = false;
   if (getenv("ST_NO_FUSED_FRONT")) allow_front = false;
+  if (getenv("ST_NO_WINO_GROUP")) allow_wgroup = false;
 #endif
   TRef packed_rgb, stem_rgb;
   if (fused_stem) {
@@ -502,15 +508,29 @@ int StDetector::build() {
 #endif
   Op pred;
   pred.type = Op::PRED; pred.phase = cur_phase; pred.variant = 47;
+  // The towers of the three levels are independent of each other: the ops are emitted DEPTH-major (conv0 of every
+  // level, then the second convs of every level) and tagged as groups, so that run_ops can put each depth into one
+  // grouped Winograd launch (wino_conv.hip: the small maps' workgroups ride in the big map's grid).
+  TRef t0s[3], clsfs[3], regfs[3];
   for (int l = 0; l < 3; ++l) {
     const std::string ls = std::to_string(l);
-    TRef t0 = new_tensor(N, F[l].H, F[l].W, 2 * feat);  // [cls_feat0 | reg_feat0]
+    t0s[l] = new_tensor(N, F[l].H, F[l].W, 2 * feat);  // [cls_feat0 | reg_feat0]
     const int pc0 = packed_convmodules({hp + "multi_level_cls_convs." + ls + ".0",
                                         hp + "multi_level_reg_convs." + ls + ".0"},
                                        outc, {feat, feat}, 3);
-    op_conv(pc0, F[l], 1, t0);
-    TRef clsf = convmodule(hp + "multi_level_cls_convs." + ls + ".1", t0.slice(0, feat), feat, 3, 1);
-    TRef regf = convmodule(hp + "multi_level_reg_convs." + ls + ".1", t0.slice(feat, feat), feat, 3, 1);
+    op_conv(pc0, F[l], 1, t0s[l]);
+    ops.back().wgroup = 1;
+  }
+  for (int l = 0; l < 3; ++l) {
+    const std::string ls = std::to_string(l);
+    clsfs[l] = convmodule(hp + "multi_level_cls_convs." + ls + ".1", t0s[l].slice(0, feat), feat, 3, 1);
+    ops.back().wgroup = 2;
+    regfs[l] = convmodule(hp + "multi_level_reg_convs." + ls + ".1", t0s[l].slice(feat, feat), feat, 3, 1);
+    ops.back().wgroup = 2;
+  }
+  for (int l = 0; l < 3; ++l) {
+    const std::string ls = std::to_string(l);
+    TRef clsf = clsfs[l], regf = regfs[l];
     TRef ho;
     ho.buf = BUF_HEAD; ho.N = N; ho.H = F[l].H; ho.W = F[l].W; ho.ld = 8; ho.base = lvl_off[l];
     const int pcc = packed_conv2d({hp + "multi_level_conv_cls." + ls}, feat, {nc});
@@ -755,6 +775,34 @@ int run_ops(StDetector* det, int phase_lo, int phase_hi, const float* const inpu
     Op& first = det->ops[oi];
     if (first.phase < phase_lo || first.phase > phase_hi) { ++oi; continue; }
     size_t oe = oi + 1;
+    if (first.group == 0 && first.wgroup > 0 && det->allow_wgroup && det->force_variant < 0) {
+      // a run of independent Winograd layers (one tower depth of the head over the three levels): ONE grouped launch
+      size_t we = oi;
+      StConvDesc wd[8];
+      bool ok = true;
+      while (we < nops && we - oi < 8 && det->ops[we].wgroup == first.wgroup && det->ops[we].phase == first.phase &&
+             det->ops[we].group == 0) {
+        const Op& o = det->ops[we];
+        ok = ok && o.type == Op::CONV && (o.tuned == 43 || o.tuned == 44);
+        if (ok) wd[we - oi] = conv_desc(det, o, 0, ws, head);
+        ++we;
+      }
+      const int nw = (int)(we - oi);
+#ifdef ST_ABLATION
+      for (size_t k = oi; k < we; ++k) ok = ok && !(k < det->skip.size() && det->skip[k]);
+#endif
+      if (ok && nw >= 2 && wino_group_applicable(wd, nw)) {
+        if (det->timing) ST_CHECK_HIP(hipEventRecord(det->events[ev_per_op * oi], stream));
+        ST_CHECK(wino_group_launch(wd, nw, stream));
+        for (size_t k = oi; k < we; ++k) {   // the first op carries the launch's duration, the riders ~0
+          if (det->timing && k > oi) ST_CHECK_HIP(hipEventRecord(det->events[ev_per_op * k], stream));
+          if (det->timing) ST_CHECK_HIP(hipEventRecord(det->events[ev_per_op * k + 1], stream));
+          det->ops[k].variant = k == oi ? 48 : 49;
+        }
+        oi = we;
+        continue;
+      }
+    }
     if (first.group > 0)
       while (oe < nops && det->ops[oe].group == first.group && det->ops[oe].phase == first.phase) ++oe;
     else if (first.chain_next && oe < nops && det->ops[oe].group == 0 && det->ops[oe].phase == first.phase)
@@ -990,10 +1038,10 @@ extern "C" int st_detector_autotune(StDetector* det, void* workspace_dev, size_t
 // id 40 = the fused Focus+stem kernel (stem_focus_conv.hip), reported with the conv ops
 // id 41 = the streaming 1x1 kernel for narrow layers (pointwise_conv.hip)
 extern "C" const char* st_conv_variant_name(int id) {
-  return id == 47 ? "headpred" : id == 46 ? "pwres" : id == 45 ? "front3x3s2" : id == 40 ? "stem6x6s2" : id == 41 ? "pw128" : id == 42 ? "dc4x32" : id == 43 ? "wino2x2" : id == 44 ? "wino2x2n" : conv_variant_name(id);
+  return id == 47 ? "headpred" : id == 46 ? "pwres" : id == 45 ? "front3x3s2" : id == 40 ? "stem6x6s2" : id == 41 ? "pw128" : id == 42 ? "dc4x32" : id == 43 ? "wino2x2" : id == 44 ? "wino2x2n" : id == 48 ? "wino2x2g" : id == 49 ? "wino2x2g+" : conv_variant_name(id);
 }
 extern "C" const char* st_conv_variant_signature(int id) {
-  return id == 47 ? "head_pred" : id == 46 ? "pw_resident" : id == 45 ? "front_s2_csp" : id == 40 ? "stem_focus_conv" : id == 41 ? "pw_conv" : id == 42 ? "direct_conv3x3" : id == 43 ? "wino_conv3x3" : id == 44 ? "wino_conv3x3 narrow"
+  return id == 47 ? "head_pred" : id == 46 ? "pw_resident" : id == 45 ? "front_s2_csp" : id == 40 ? "stem_focus_conv" : id == 41 ? "pw_conv" : id == 42 ? "direct_conv3x3" : id == 43 ? "wino_conv3x3" : id == 48 ? "wino_conv3x3 grouped launch" : id == 49 ? "wino_conv3x3 grouped launch (rider: computed by the preceding op's launch)" : id == 44 ? "wino_conv3x3 narrow"
                                                               : conv_variant_signature(id);
 }
 

@@ -117,7 +117,7 @@ __device__ __forceinline__ f32x4 wn_sub_mfma(f32x4 a, f32x4 b) {
 // KTAIL: Cin % 32 != 0 (the 48-level aggregation convs): the last K-chunk runs only the channel groups that exist
 // (g_last of 4) instead of multiplying zero-padded channels - a quarter of the layer's MFMAs at Cin = 48.
 template <int CBN, int LCBN, bool RES, bool KTAIL>
-__global__ __launch_bounds__(256, 2) void wino_conv3x3_kernel(const WinoArgs p) {
+__device__ __forceinline__ void wino_conv3x3_body(const WinoArgs& p, int b_) {
   constexpr int WN_CB = 32 * CBN;                       // couts per workgroup
   constexpr int WN_FRAG_FLOATS = LCBN * 64 * 4;         // one (kc, g, b) step in memory: LCBN cout blocks x 64 lanes x 4
   extern __shared__ float4 wn_smem4[];
@@ -125,7 +125,6 @@ __global__ __launch_bounds__(256, 2) void wino_conv3x3_kernel(const WinoArgs p) 
   const int tid = threadIdx.x, lane = tid & 63, a = tid >> 6;   // wave = transform row a
   const int i = lane & 31, h = lane >> 5;
   const int tyi = i >> 3, txi = i & 7;
-  int b_ = blockIdx.x;
   const int cb = b_ % p.ncb; b_ /= p.ncb;
   const int bx = b_ % p.tbx; b_ /= p.tbx;
   const int by = b_ % p.tby;
@@ -316,6 +315,34 @@ __global__ __launch_bounds__(256, 2) void wino_conv3x3_kernel(const WinoArgs p) 
 #endif
 }
 
+template <int CBN, int LCBN, bool RES, bool KTAIL>
+__global__ __launch_bounds__(256, 2) void wino_conv3x3_kernel(const WinoArgs p) {
+  wino_conv3x3_body<CBN, LCBN, RES, KTAIL>(p, (int)blockIdx.x);
+}
+
+// GROUPED launch: up to WN_GROUP_MAX independent layers of the same instance (same cout blocking, no residual) share
+// ONE grid - an array of problem descriptors in the kernel arguments, a workgroup finds its problem by the prefix of
+// block counts (a scalar search; every field of the chosen descriptor is wave-uniform and stays in SGPRs).  The YOLOX
+// head runs its towers level by level (mmyolo YOLOXHeadModule.forward, configs/_base_/yolox_s_8x8_mmyolo.py:40-51), but
+// the three levels are independent: the fused cls|reg conv0 of the 92x160, 46x80 and 23x40 maps are one launch, the
+// six second tower convs another.  The small maps' 144 / 288 / 480 workgroups (less than ONE round of the chip's 512
+// slots each) ride in the big map's grid instead of costing a launch round of their own: 11 + 12 rounds become 9.6 + 9.6.
+constexpr int WN_GROUP_MAX = 6;
+struct WinoGroupArgs {
+  WinoArgs p[WN_GROUP_MAX];
+  unsigned first[WN_GROUP_MAX + 1];   // first[k] = first block of problem k; first[n] = grid size
+  int n;
+};
+
+template <int CBN, int LCBN>
+__global__ __launch_bounds__(256, 2) void wino_conv3x3_group_kernel(const WinoGroupArgs g) {
+  const unsigned b = blockIdx.x;
+  int k = 0;
+#pragma unroll
+  for (int q = 1; q < WN_GROUP_MAX; ++q) k += (q < g.n && b >= g.first[q]) ? 1 : 0;
+  wino_conv3x3_body<CBN, LCBN, false, false>(g.p[k], (int)(b - g.first[k]));
+}
+
 }  // namespace
 
 // cout blocks of 32 per workgroup for a layer: 2 (64 couts) when Cout is a multiple of 64 or fits one padded block of
@@ -391,8 +418,7 @@ static int wino_launch_instance(const WinoArgs& a, unsigned blocks, hipStream_t 
   return ST_OK;
 }
 
-// narrow = true: 32-cout workgroups on a 64-cout layout (tile variant 44; only where the layout has 2 blocks)
-int wino_conv_launch(const StConvDesc& d, hipStream_t stream, bool narrow) {
+static int wino_fill_args(const StConvDesc& d, bool narrow, WinoArgs& a, long long* blocks_out) {
   ST_REQUIRE(wino_conv_applicable(d), "winograd conv: shape not supported (3x3 s1 p1, Cin % 4 == 0, Cout a multiple of 32 "
                                       "or <= 64, transformed weights required)");
   ST_REQUIRE(d.in_dev && d.bias_dev && d.out1_dev, "winograd conv: null pointer");
@@ -402,7 +428,6 @@ int wino_conv_launch(const StConvDesc& d, hipStream_t stream, bool narrow) {
   const int lcbn = wino_cbn(d.Cout);
   ST_REQUIRE(!narrow || (lcbn == 2 && d.Cout % 64 == 0), "winograd conv: the narrow instance needs Cout %% 64 == 0");
   const int cbn = narrow ? 1 : lcbn, CB = 32 * cbn;
-  WinoArgs a;
   a.in = d.in_dev; a.wino = d.wgt_wino_dev; a.bias = d.bias_dev; a.out = d.out1_dev; a.res = d.res_dev;
   a.N = d.N; a.H = d.Hi; a.W = d.Wi; a.Cin = d.Cin; a.in_ld = d.in_ld; a.in_off = d.in_off; a.Cout = d.Cout;
   a.out_ld = d.out1_ld; a.out_off = d.out1_off; a.res_ld = d.res_ld; a.res_off = d.res_off;
@@ -415,9 +440,20 @@ int wino_conv_launch(const StConvDesc& d, hipStream_t stream, bool narrow) {
   a.res_bytes = d.res_dev ? (unsigned)(M * d.res_ld * 4) : 0u;
   a.wino_bytes = (unsigned)(wino_packed_floats(d.Cout, d.Cin) * 4);
   a.g_last = 4 - (a.nkc * 32 - d.Cin) / 8;          // whole groups of 8 padded channels are skipped
-  const bool ktail = a.g_last < 4;
   const long long blocks = (long long)d.N * a.tbx * a.tby * a.ncb;
   ST_REQUIRE(blocks < (1ll << 31), "winograd conv: grid too large");
+  *blocks_out = blocks;
+  return ST_OK;
+}
+
+// narrow = true: 32-cout workgroups on a 64-cout layout (tile variant 44; only where the layout has 2 blocks)
+int wino_conv_launch(const StConvDesc& d, hipStream_t stream, bool narrow) {
+  WinoArgs a;
+  long long blocks = 0;
+  ST_CHECK(wino_fill_args(d, narrow, a, &blocks));
+  const int lcbn = wino_cbn(d.Cout);
+  const int cbn = narrow ? 1 : lcbn;
+  const bool ktail = a.g_last < 4;
   int rc;
   if (ktail && cbn == 2 && !d.res_dev) rc = wino_launch_instance<2, 2, false, true>(a, (unsigned)blocks, stream);
   else if (ktail && cbn == 1 && lcbn == 1 && !d.res_dev) rc = wino_launch_instance<1, 1, false, true>(a, (unsigned)blocks, stream);
@@ -428,6 +464,38 @@ int wino_conv_launch(const StConvDesc& d, hipStream_t stream, bool narrow) {
   else rc = d.res_dev ? wino_launch_instance<1, 1, true>(a, (unsigned)blocks, stream)
                       : wino_launch_instance<1, 1, false>(a, (unsigned)blocks, stream);
   ST_CHECK(rc);
+  ST_CHECK_HIP(hipGetLastError());
+  return ST_OK;
+}
+
+// Can these layers share one grouped launch?  The wide instance <2, 2>, no residual, no K tail, at most WN_GROUP_MAX.
+bool wino_group_applicable(const StConvDesc* d, int n) {
+  if (n < 2 || n > WN_GROUP_MAX) return false;
+  for (int k = 0; k < n; ++k)
+    if (!wino_conv_applicable(d[k]) || d[k].res_dev || d[k].Cout % 64 != 0 || d[k].Cin % 32 != 0) return false;
+  return true;
+}
+
+int wino_group_launch(const StConvDesc* d, int n, hipStream_t stream) {
+  ST_REQUIRE(wino_group_applicable(d, n), "winograd group: layers do not qualify (3x3 s1 p1, Cout %% 64 == 0, Cin %% 32 "
+                                          "== 0, no residual, 2..%d layers)", WN_GROUP_MAX);
+  WinoGroupArgs g;
+  std::memset(&g, 0, sizeof(g));
+  g.n = n;
+  long long total = 0;
+  for (int k = 0; k < n; ++k) {
+    long long blocks = 0;
+    ST_CHECK(wino_fill_args(d[k], false, g.p[k], &blocks));
+    g.first[k] = (unsigned)total;
+    total += blocks;
+    ST_REQUIRE(total < (1ll << 31), "winograd group: grid too large");
+  }
+  for (int k = n; k <= WN_GROUP_MAX; ++k) g.first[k] = (unsigned)total;
+  constexpr int lds = wn_lds_floats(2) * (int)sizeof(float);
+  static int lds_set = 0;
+  auto kern = wino_conv3x3_group_kernel<2, 2>;
+  ST_ENSURE_DYNAMIC_LDS(kern, lds, lds_set);
+  hipLaunchKernelGGL(kern, dim3((unsigned)total), dim3(256), lds, stream, g);
   ST_CHECK_HIP(hipGetLastError());
   return ST_OK;
 }

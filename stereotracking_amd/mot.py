@@ -358,7 +358,7 @@ class OCSORT_Disparity(nn.Module):
                 score_thr=cfg.get('score_thr', 0.01), iou_thr=nms.get('iou_threshold', 0.65), max_det=self.max_det,
                 baseline=self.baseline, focal_length=self.focal_length,
                 pad_size_divisor=getattr(self.data_preprocessor, 'pad_size_divisor', 32) or 32,
-                agg_layers=sm.agg_layers if stereo else 0)
+                agg_layers=sm.agg_layers if stereo else 0, agg3d_layers=sm.agg3d_layers if stereo else 0)
             ent = self._dense[key] = [runner, None]
         ver = self._weights_version()
         if ent[1] != ver:

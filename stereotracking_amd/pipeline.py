@@ -92,7 +92,7 @@ class StereoDensePipeline:
 
     def __init__(self, batch, ori_shape=(720, 1280), widen_factor=0.5, deepen_factor=0.33, num_classes=1,
                  stereo=True, max_disp=192, feat_stride=4, temperature=32.0, score_thr=0.01, iou_thr=0.5,
-                 max_det=1000, baseline=0.25, focal_length=640, pad_size_divisor=32, agg_layers=0):
+                 max_det=1000, baseline=0.25, focal_length=640, pad_size_divisor=32, agg_layers=0, agg3d_layers=0):
         """max_det: rows of the fixed-size detection buffer per frame.  The reference applies NO cap on the
         kept boxes (yolox_style=True => max_per_img = len(results)), so this is a
         capacity, not a threshold: `run()` reports `overflow` whenever a frame kept more boxes than fit, and
@@ -104,8 +104,10 @@ class StereoDensePipeline:
         self.height = (self.ori_h + d - 1) // d * d
         self.width = (self.ori_w + d - 1) // d * d
         self.stereo = bool(stereo)
-        self.stereo_module = StereoCostVolume(max_disp, feat_stride, temperature, agg_layers if stereo else 0)
+        self.stereo_module = StereoCostVolume(max_disp, feat_stride, temperature, agg_layers if stereo else 0,
+                                              agg3d_layers if stereo else 0)
         self.agg_layers = self.stereo_module.agg_layers
+        self.agg3d_layers = self.stereo_module.agg3d_layers
         self.max_disp, self.feat_stride = int(max_disp), int(feat_stride)
         self.D = self.stereo_module.levels
         self.temperature = float(temperature)
@@ -135,6 +137,7 @@ class StereoDensePipeline:
         key = (f'v{self.det.lib.st_version()}_b{self.batch}_{self.height}x{self.width}_w{self.det.widen_factor:g}'
                f'_d{self.det.deepen_factor:g}_s{int(self.stereo)}_a{self.agg_layers}_D{self.D}'
                f'_ops{self.det.lib.st_detector_num_ops(self.det.handle)}_{_device_tag()}')
+        # (the 3-D aggregation layers run on a kernel of their own: no tile choice, not part of the key)
         sources = []
         if tuning_cache is not False:
             explicit = tuning_cache or os.environ.get('ST_TUNE_CACHE')
@@ -243,7 +246,8 @@ class InflightPipelines:
     Consecutive batches are independent (the dense path is stateless per frame), so batch i+1 may start while
     batch i is still running: the tail of every kernel launch (the last partial wave of workgroups) and the
     latency-bound decode / NMS / per-box-depth kernels of one batch are filled by the convs of the next.
-    Measured on MI355X (bench workload): 1 context 1100, 2 contexts 1204, 3 contexts 1259 pairs/s.
+    Measured on MI355X (bench workload, round 3 library, one hardware queue per context): 1 context 1538-1568 pairs/s,
+    3 contexts 1811, 4 contexts 1839-1843.
 
     submit() returns (out, event): `out` is that context's result dict (device tensors, overwritten when the same
     context is reused `n` submits later), `event` is recorded on the context's stream after the batch.
@@ -260,7 +264,7 @@ class InflightPipelines:
         return len(self.pipes)
 
     def __getattr__(self, name):   # geometry / thresholds of the (identical) contexts: batch, max_det, stereo, ...
-        if name in ('batch', 'max_det', 'stereo', 'height', 'width', 'ori_h', 'ori_w', 'agg_layers'):
+        if name in ('batch', 'max_det', 'stereo', 'height', 'width', 'ori_h', 'ori_w', 'agg_layers', 'agg3d_layers'):
             return getattr(self.pipes[0], name)
         raise AttributeError(name)
 

@@ -10,7 +10,10 @@ Specification (frozen; the executable spec is oracle/st_oracle.c + oracle/stereo
   features   F_L, F_R = stem+stage1 of the detector's RGB branch on left / right (C x H/4 x W/4),
              shared weights, computed as one stacked batch of 2N
   cost       cost[d,y,x] = (1/C) sum_c F_L[c,y,x] * F_R[c,y,x-d], d in [0, max_disp/4); 0 where x-d < 0
-  aggregate  `agg_layers` 2-D convolutions over d-as-channels: cost <- conv3x3(cost; W_l, b_l), SiLU after
+  aggregate  3-D: `agg3d_layers` single-channel 3x3x3 convolutions over (d, y, x) of the volume, zero padded, SiLU
+             after every layer but the last (parameters `agg3d.{l}.weight` (1,1,3,3,3), `agg3d.{l}.bias` (1,);
+             csrc/agg3d.hip, bit-exact against oracle_agg3d); then
+             2-D: `agg_layers` convolutions over d-as-channels: cost <- conv3x3(cost; W_l, b_l), SiLU after
              every layer but the last (parameters `agg.{l}.weight` (D',D',3,3), `agg.{l}.bias` (D',))
   disparity  d_lr = sum_d d * softmax_d(temperature * cost);  disp = 4 * bilinear_x4(d_lr)
              inside the original image, 0 in the padding
@@ -30,7 +33,7 @@ class StereoCostVolume(nn.Module):
     """Parameter holder + launcher (like the detector modules: no CPU forward).  Parameters are named
     `agg.{l}.weight` / `agg.{l}.bias`, so under the MOT shell a checkpoint carries `stereo.agg.{l}.*`."""
 
-    def __init__(self, max_disp=192, feat_stride=4, temperature=32.0, agg_layers=0):
+    def __init__(self, max_disp=192, feat_stride=4, temperature=32.0, agg_layers=0, agg3d_layers=0):
         super().__init__()
         if feat_stride != 4:
             raise NotImplementedError('only feat_stride=4 (stage1 features) is wired up')
@@ -38,21 +41,28 @@ class StereoCostVolume(nn.Module):
             raise ValueError('max_disp must be a multiple of feat_stride')
         self.max_disp, self.feat_stride = int(max_disp), int(feat_stride)
         self.levels = self.max_disp // self.feat_stride
-        if self.levels % 4 and agg_layers:
+        if self.levels % 4 and (agg_layers or agg3d_layers):
             raise ValueError('aggregation needs max_disp / feat_stride to be a multiple of 4')
         self.temperature = float(temperature)
         self.agg_layers = int(agg_layers)
+        self.agg3d_layers = int(agg3d_layers)
         D = self.levels
+        self.agg3d = nn.ModuleList(nn.Conv3d(1, 1, 3, padding=1) for _ in range(self.agg3d_layers))
         self.agg = nn.ModuleList(nn.Conv2d(D, D, 3, padding=1) for _ in range(self.agg_layers))
         with torch.no_grad():   # identity until a checkpoint is loaded: behaves like agg_layers=0
             for conv in self.agg:
                 conv.weight.zero_()
                 conv.weight[torch.arange(D), torch.arange(D), 1, 1] = 1.0
                 conv.bias.zero_()
+            for conv in self.agg3d:
+                conv.weight.zero_()
+                conv.weight[0, 0, 1, 1, 1] = 1.0
+                conv.bias.zero_()
         for p in self.parameters():
             p.requires_grad_(False)
         self.lib = _lib.load()
         self._packed = None    # (device, weights version, [(wgt, bias)])
+        self._taps3d = None    # (weights version, [(27 host floats as a ctypes array, bias)])
         self._vol = None
         self.variant = -1      # conv tile variant of the aggregation layers (-1 = library default, or autotune())
         self.timing = False    # record events around every aggregation conv (bench.py roofline accounting)
@@ -66,8 +76,18 @@ class StereoCostVolume(nn.Module):
     def param_table(self):
         return [(n, tuple(p.shape)) for n, p in self.named_parameters()]
 
+    def _pack3d(self):
+        ver = tuple(p._version for p in self.agg3d.parameters())
+        if self._taps3d is None or self._taps3d[0] != ver:
+            taps = []
+            for conv in self.agg3d:
+                w = conv.weight.detach().to('cpu', torch.float32).reshape(27).tolist()   # (kD, kH, kW) order
+                taps.append(((C.c_float * 27)(*w), float(conv.bias.detach().to('cpu', torch.float32).reshape(-1)[0])))
+            self._taps3d = (ver, taps)
+        return self._taps3d[1]
+
     def _pack(self, dev):
-        ver = tuple(p._version for p in self.parameters())
+        ver = tuple(p._version for p in self.agg.parameters())
         if self._packed is not None and self._packed[0] == dev and self._packed[1] == ver:
             return self._packed[2]
         D = self.levels
@@ -179,7 +199,7 @@ class StereoCostVolume(nn.Module):
         if self.timing:
             cv0, cv1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             cv0.record()
-        if self.agg_layers == 0:
+        if self.agg_layers == 0 and self.agg3d_layers == 0:
             check(self.lib.st_costvolume_softargmin(C.c_void_p(fl), C.c_void_p(fr), N, Hf, Wf, Cf, ld, D,
                                                     self.temperature, ptr(cost_out), ptr(disp_lr), stream),
                   'st_costvolume_softargmin')
@@ -196,6 +216,10 @@ class StereoCostVolume(nn.Module):
             if self.timing:
                 cv1.record()
                 self._cv_events.append((cv0, cv1))
+            for l, (w27, b3) in enumerate(self._pack3d()):      # 3-D aggregation over (d, y, x)
+                check(self.lib.st_volume_agg3d(ptr(va), ptr(vb), N, Hf, Wf, D, w27, b3,
+                                               1 if l < self.agg3d_layers - 1 else 0, stream), 'st_volume_agg3d')
+                va, vb = vb, va
             for l, (wp, bp, wn) in enumerate(packed):
                 d = self._agg_desc(l, va, vb, wp, bp, wn)
                 if self.timing:

@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol(stlib):
     for n in names:
         assert hasattr(stlib, n), f'{n} declared in include/stereotrack.h but not exported'
         assert n in _lib._PROTOS, f'{n} has no ctypes prototype'
-    assert stlib.st_version() == 300      # ST_VERSION of include/stereotrack.h (also keys the tuning cache)
+    assert stlib.st_version() == 400      # ST_VERSION of include/stereotrack.h (also keys the tuning cache)
 
 
 def test_struct_sizes_match_the_library(stlib):
@@ -356,3 +356,22 @@ def test_oracle_backbone_reproduces_the_reference_docstring_example():
         outs = small(dict(img=torch.rand(1, 3, 64, 96), disp_postp=torch.rand(1, 3, 64, 96)))
     assert [tuple(o.shape) for o in outs] == [(1, 128, 8, 12), (1, 256, 4, 6), (1, 512, 2, 3)]
     assert len([m for m in small.stage2.modules() if type(m).__name__ == 'DarknetBottleneck']) == 3   # round(9 * 0.33)
+
+
+def test_oracle_agg3d_equals_conv3d():
+    """oracle_agg3d (the 3-D aggregation's specification, oracle/st_oracle.c) against torch.nn.functional.conv3d in
+    float64 on the same taps: the restatement IS a zero-padded single-channel 3x3x3 convolution + SiLU."""
+    import torch.nn.functional as F
+    from oracle import c_oracle
+    rng = np.random.RandomState(3)
+    vol = rng.randn(2, 5, 7, 12).astype(np.float32)
+    w = rng.randn(3, 3, 3).astype(np.float32)
+    for act in (0, 1):
+        got = c_oracle.agg3d(vol, w, 0.3, act)
+        x = torch.from_numpy(vol).double().permute(0, 3, 1, 2)[:, None]              # (N, 1, D, H, W)
+        ref = F.conv3d(x, torch.from_numpy(w).double()[None, None], torch.tensor([0.3], dtype=torch.float64), padding=1)
+        ref = (F.silu(ref) if act else ref)[:, 0].permute(0, 2, 3, 1).numpy()
+        assert np.abs(got - ref).max() <= 1e-5
+    ident = np.zeros((3, 3, 3), np.float32)
+    ident[1, 1, 1] = 1.0
+    assert np.array_equal(c_oracle.agg3d(vol, ident, 0.0, 0), vol)

@@ -257,3 +257,86 @@ def test_stereo_module_with_aggregation_matches_oracle(agg_layers, tuned, cuda):
     assert rel_err(got, ref_out) <= 1e-3
     assert (got[:, :, H:, :] == 0).all() and (got[:, :, :, W:] == 0).all()
     assert got.min() >= 0.0 and got.max() <= D          # soft-argmin is a convex combination of the levels
+
+
+# ---- 3-D aggregation (north_star: "its 3D/2D aggregation"; csrc/agg3d.hip) -----------------------------------------
+@pytest.mark.parametrize('N,Hf,Wf,D,act', [(2, 5, 70, 48, 1), (1, 3, 130, 16, 0), (1, 4, 64, 48, 1), (1, 1, 1, 4, 1),
+                                           (1, 7, 65, 96, 0), (2, 2, 200, 12, 1)])
+def test_agg3d_layer_bit_exact(N, Hf, Wf, D, act, cuda):
+    """One single-channel 3x3x3 layer over (d, y, x), zero padded in all three dimensions: BIT-EXACT against
+    oracle_agg3d (same fmaf order, SiLU through the shared exp polynomial); ragged row segments (Wf not a multiple of
+    the 64-pixel tile), one-pixel volumes and D = 4 (every quad is a border quad) included."""
+    lib = _lib.load()
+    rng = np.random.RandomState(7 * D + Wf)
+    vol = rng.normal(0, 1.5, (N, Hf, Wf, D)).astype(np.float32)
+    w = rng.normal(0, 0.4, (3, 3, 3)).astype(np.float32)
+    bias = 0.125
+    ref = c_oracle.agg3d(vol, w, bias, act)
+    src = torch.from_numpy(vol).to(cuda)
+    dst = torch.full_like(src, float('nan'))
+    w27 = (C.c_float * 27)(*w.reshape(-1).tolist())
+    check(lib.st_volume_agg3d(ptr(src), ptr(dst), N, Hf, Wf, D, w27, bias, act, current_stream()), 'st_volume_agg3d')
+    torch.cuda.synchronize()
+    got = dst.cpu().numpy()
+    assert np.array_equal(got.view(np.uint32), ref.view(np.uint32)), np.abs(got - ref).max()
+    # argument checks: in place, D not a multiple of 4
+    assert lib.st_volume_agg3d(ptr(src), ptr(src), N, Hf, Wf, D, w27, bias, act, current_stream()) != 0
+    assert lib.st_volume_agg3d(ptr(src), ptr(dst), N, Hf, Wf, 6, w27, bias, act, current_stream()) != 0
+
+
+@pytest.mark.parametrize('agg3d_layers,agg_layers', [(1, 0), (2, 0), (2, 1)])
+def test_stereo_module_with_3d_aggregation_matches_oracle(agg3d_layers, agg_layers, cuda):
+    """The stereo module with the 3-D stage (cost volume -> `agg3d_layers` 3x3x3 layers -> `agg_layers` 2-D convs ->
+    soft-argmin -> upsample) against oracle/stereo.py on the GPU's own features.  Without 2-D layers every stage is
+    bit-exact, so the aggregated volume and both disparities are compared BIT FOR BIT; with a 2-D conv (float MFMA
+    kernel) the usual 1e-3 applies.  Identity-initialised 3-D layers leave the disparity unchanged."""
+    from oracle import stereo as ostereo
+    from stereotracking_amd.pipeline import StereoDensePipeline
+    from stereotracking_amd.synthetic import synthetic_batch, synthetic_state_dict
+    N, H, W, D = 2, 88, 152, 32
+    pipe = StereoDensePipeline(N, (H, W), 0.375, 0.33, 1, stereo=True, max_disp=D, max_det=32,
+                               agg_layers=agg_layers, agg3d_layers=agg3d_layers)
+    table = pipe.param_table()
+    names = [n for n, _ in table]
+    assert f'stereo.agg3d.{agg3d_layers - 1}.weight' in names and dict(table)['stereo.agg3d.0.weight'] == (1, 1, 3, 3, 3)
+    sd = synthetic_state_dict(table, seed=1)
+    g = torch.Generator().manual_seed(5)      # generic 3-D taps (the synthetic fan-in rule would make them tiny)
+    for l in range(agg3d_layers):
+        sd[f'stereo.agg3d.{l}.weight'] = torch.randn(1, 1, 3, 3, 3, generator=g) * 0.25
+        sd[f'stereo.agg3d.{l}.bias'] = torch.randn(1, generator=g) * 0.1
+    batch = synthetic_batch([3, 4], H, W, D)
+    img, right = batch['img'].to(cuda), batch['right'].to(cuda)
+    Hf, Wf, Dl = pipe.height // 4, pipe.width // 4, D // 4
+
+    def run():
+        vol = torch.full((N, Hf, Wf, Dl), float('nan'), device=cuda)
+        lr = torch.full((N, Hf, Wf), float('nan'), device=cuda)
+        out = torch.full((N, 3, pipe.height, pipe.width), float('nan'), device=cuda)
+        pipe.stereo_module.compute(pipe.det, img, right, (H, W), lr, out, cost_out=vol)
+        torch.cuda.synchronize()
+        return vol.cpu().numpy(), lr.cpu().numpy(), out.cpu().numpy()
+
+    sd_id = dict(sd)                                          # the same weights with IDENTITY 3-D layers
+    for l in range(agg3d_layers):
+        ident = torch.zeros(1, 1, 3, 3, 3)
+        ident[0, 0, 1, 1, 1] = 1.0
+        sd_id[f'stereo.agg3d.{l}.weight'], sd_id[f'stereo.agg3d.{l}.bias'] = ident, torch.zeros(1)
+    pipe.load_state_dict(sd_id, autotune=False)
+    vol_id, lr_id, _ = run()
+    feat = pipe.det.tap('stage1_rgb').cpu().numpy()
+    Cf = feat.shape[-1]
+    plain = ostereo.disparity(feat[:N], feat[N:], Cf, Dl, pipe.temperature, sd, agg_layers, valid_hw=(H, W))
+    if agg_layers == 0:
+        assert np.array_equal(vol_id, plain[0]) and np.array_equal(lr_id, plain[1])
+    pipe.load_state_dict(sd, autotune=False)
+    vol, lr, out = run()
+    ref_vol, ref_lr, ref_out = ostereo.disparity(feat[:N], feat[N:], Cf, Dl, pipe.temperature, sd, agg_layers,
+                                                 valid_hw=(H, W), agg3d_layers=agg3d_layers)
+    assert not np.array_equal(ref_lr, plain[1])               # the layers do something
+    if agg_layers == 0:
+        assert np.array_equal(vol.view(np.uint32), ref_vol.view(np.uint32))
+        assert np.array_equal(lr.view(np.uint32), ref_lr.view(np.uint32))
+        assert np.array_equal(out.view(np.uint32), ref_out.view(np.uint32))
+    else:
+        assert rel_err(vol, ref_vol) <= 1e-3 and rel_err(lr, ref_lr) <= 1e-3 and rel_err(out, ref_out) <= 1e-3
+    assert (out[:, :, H:, :] == 0).all() and (out[:, :, :, W:] == 0).all()
