@@ -153,13 +153,20 @@ __global__ __launch_bounds__(128) void costvolume_tiled_kernel(const float* __re
                                                                const float* __restrict__ featR, int Hf, int Wf,
                                                                int C, int ld, int D, float temperature, int rowL,
                                                                int rowR, float* __restrict__ out_cost,
-                                                               float* __restrict__ out_disp, int dbase) {
+                                                               float* __restrict__ out_disp, int dbase, int gx,
+                                                               int total, int per_xcd) {
   // dbase: first disparity of this launch's slab [dbase, dbase + 4*DG) - wide volumes (D > 128) are materialised
   // slab by slab (the fused soft-argmin needs all of D in one launch: out_disp must be null when dbase > 0)
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int bufsz = CVT_CC * (rowL + rowR);   // two buffers: [CVT_CC][rowL] + [CVT_CC][rowR] each
-  const int x0 = blockIdx.x * CVT_TX;
-  const int y = blockIdx.y, n = blockIdx.z;
+  // XCD-aware tile order: workgroups are dealt round-robin to the 8 XCDs (each with an L2 of its own), so the
+  // linear id is re-read as (xcd, slot) and every XCD walks a CONTIGUOUS range of tiles - the 4*DG-pixel R halo two
+  // neighbouring row segments share is then fetched from memory once, by the L2 both of them sit behind (it was
+  // fetched twice: 1.22x the algorithmic bytes, profiles/r03_hbm_traffic.txt).
+  const int w = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
+  if (w >= total) return;                    // uniform
+  const int x0 = (w % gx) * CVT_TX;
+  const int y = (w / gx) % Hf, n = w / (gx * Hf);
   const size_t rowbase = ((size_t)n * Hf + y) * Wf;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int dg = lane >> 4, pgi = lane & 15;
@@ -468,7 +475,11 @@ extern "C" int st_costvolume_softargmin(const float* featL_dev, const float* fea
   if (dgt <= 32 && (out_cost_dev == nullptr || (reinterpret_cast<uintptr_t>(out_cost_dev) & 15) == 0)) {
     const int rowLt = cvt_row(CVT_TX), rowRt = cvt_row(CVT_TX + 4 * dgt);
     const size_t ldst = ((size_t)2 * CVT_CC * (rowLt + rowRt) + rowRt) * sizeof(float);   // + the prefetch slack row
-    const dim3 gridt((Wf + CVT_TX - 1) / CVT_TX, Hf, N), blockt(128);
+    const int gxt = (Wf + CVT_TX - 1) / CVT_TX;
+    const long long totalt = (long long)gxt * Hf * N;
+    ST_REQUIRE(totalt + 8 < (1ll << 31), "st_costvolume_softargmin: grid too large");
+    const int per_xcd = (int)((totalt + 7) / 8);
+    const dim3 gridt((unsigned)(8 * per_xcd)), blockt(128);
 #define ST_CVT_LAUNCH(DGV)                                                                                    \
   do {                                                                                                         \
     auto kern = costvolume_tiled_kernel<DGV>;                                                                  \
@@ -476,7 +487,8 @@ extern "C" int st_costvolume_softargmin(const float* featL_dev, const float* fea
     ST_ENSURE_DYNAMIC_LDS(kern, ldst, lds_set);                                                                \
     for (int sl = 0; sl < slabs; ++sl)                                                                         \
       hipLaunchKernelGGL(kern, gridt, blockt, ldst, stream, featL_dev, featR_dev, Hf, Wf, C, feat_ld, D,       \
-                         temperature, rowLt, rowRt, out_cost_dev, out_disp_dev, sl * 4 * DGV);                 \
+                         temperature, rowLt, rowRt, out_cost_dev, out_disp_dev, sl * 4 * DGV, gxt,             \
+                         (int)totalt, per_xcd);                                                                \
   } while (0)
     switch (dgt) {
       case 4: ST_CVT_LAUNCH(4); break;

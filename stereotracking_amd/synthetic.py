@@ -78,6 +78,12 @@ def synthetic_state_dict(param_table, seed=0, img_stats=(127.5, 73.9), disp_stat
             w[idx, idx, shape[2] // 2, shape[3] // 2] += 1.0
             sd[name] = w
             sd[name[:-len('.weight')] + '.bias'] = randn((shape[0],), 0.01)
+        elif '.agg3d.' in '.' + name and name.endswith('.weight') and len(shape) == 5:
+            # 3-D aggregation layer (1,1,3,3,3): centre tap passes the volume through, small random neighbours
+            w = randn(shape, 0.03)
+            w[0, 0, 1, 1, 1] += 1.0
+            sd[name] = w
+            sd[name[:-len('.weight')] + '.bias'] = randn((1,), 0.01)
         elif name.endswith('.weight') and len(shape) == 4:  # bare prediction Conv2d
             fan_in = shape[1] * shape[2] * shape[3]
             prefix = name[:-len('.weight')]

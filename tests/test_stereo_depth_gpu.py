@@ -289,7 +289,7 @@ def test_stereo_module_with_3d_aggregation_matches_oracle(agg3d_layers, agg_laye
     """The stereo module with the 3-D stage (cost volume -> `agg3d_layers` 3x3x3 layers -> `agg_layers` 2-D convs ->
     soft-argmin -> upsample) against oracle/stereo.py on the GPU's own features.  Without 2-D layers every stage is
     bit-exact, so the aggregated volume and both disparities are compared BIT FOR BIT; with a 2-D conv (float MFMA
-    kernel) the usual 1e-3 applies.  Identity-initialised 3-D layers leave the disparity unchanged."""
+    kernel) the usual 1e-3 applies.  One identity-initialised 3-D layer leaves the disparity unchanged."""
     from oracle import stereo as ostereo
     from stereotracking_amd.pipeline import StereoDensePipeline
     from stereotracking_amd.synthetic import synthetic_batch, synthetic_state_dict
@@ -326,7 +326,7 @@ def test_stereo_module_with_3d_aggregation_matches_oracle(agg3d_layers, agg_laye
     feat = pipe.det.tap('stage1_rgb').cpu().numpy()
     Cf = feat.shape[-1]
     plain = ostereo.disparity(feat[:N], feat[N:], Cf, Dl, pipe.temperature, sd, agg_layers, valid_hw=(H, W))
-    if agg_layers == 0:
+    if agg_layers == 0 and agg3d_layers == 1:      # ONE identity layer is the identity (more layers put a SiLU between)
         assert np.array_equal(vol_id, plain[0]) and np.array_equal(lr_id, plain[1])
     pipe.load_state_dict(sd, autotune=False)
     vol, lr, out = run()
