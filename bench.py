@@ -46,6 +46,8 @@ def parse():
     ap.add_argument('--shell-inflight', type=int, default=3,
                     help='contexts of the MOT shell in the test_step leg (a synchronous call fills and drains them: '
                          '3 is faster than 4 there)')
+    ap.add_argument('--split-bf16', action='store_true',
+                    help='let the autotuner pick the split-operand (bf16x3) conv instances (default: exact-fp32 MFMA only)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-test-step', action='store_true',
                     help='skip the second leg through Config.fromfile -> MODELS.build -> model.test_step')
@@ -526,7 +528,8 @@ def main():
     # `inflight` contexts (own workspace + HIP stream each): step i runs on context i % inflight, so the launch
     # tails and the latency-bound decode / NMS / depth kernels of one batch overlap the convs of the next
     runner = InflightPipelines(max(1, args.inflight), B, (720, 1280), 0.5, 0.33, 1, stereo=True,
-                               max_disp=args.max_disp, max_det=args.max_det, agg_layers=args.agg_layers)
+                               max_disp=args.max_disp, max_det=args.max_det, agg_layers=args.agg_layers,
+                               split_bf16=True if args.split_bf16 else None)
     pipe = runner.pipes[0]
     sd = synthetic_state_dict(runner.param_table(), seed=0)
     runner.load_state_dict(sd)   # plan from pipeline.default_tuning_cache() (committed), measured when absent

@@ -462,6 +462,270 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(ConvKArgs p) {
   conv_epilogue<TM, TN>(p, acc, m0, n0, wm, wn, l31, lh, BM, BN);
 }
 
+// ---- split-operand instance ("bf16x3"): the same implicit GEMM on the BF16 matrix pipes ------------------------------
+// fp32 operands are split into three bf16 terms, x = hi + mid + lo (3 x 8 = 24 mantissa bits: the split is error-free),
+// and the product is assembled from 6 of the 9 term products (hi.hi, hi.mid, mid.hi, hi.lo, lo.hi, mid.mid; the dropped
+// ones are below 2^-24 relative), every term product exact in the fp32 accumulator of v_mfma_f32_32x32x16_bf16.  gfx950
+// runs that instruction at 16x the rate of v_mfma_f32_32x32x2_f32 per multiply-add, so 6 of them per 16 k replace 8 of
+// the fp32-input form at a quarter of the cycles: 2.67x the fp32 matrix rate.  Inputs, weights, accumulators and
+// outputs stay fp32; measured on MI355X (tools/micro/bf16x3_gemm.hip, profiles/r04_bf16x3_microbench.txt) the result
+// is CLOSER to a float64 evaluation than the fp32-input MFMA's (max error 3.2e-7 vs 5.2e-7 of the output scale).
+// Structure = the register-staged kernel above: the split happens once per staged element on the way into LDS (three
+// bf16 images per tile, rows of 32 k padded to 80 bytes: conflict-free 16-byte fragment reads), weights included -
+// the packed fp32 weights are used as they are.  One LDS buffer (61 KB for a 128 x 128 tile: two workgroups per CU),
+// the next chunk's global loads in flight during the MFMAs of the current one.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+// x = hi + mid + lo by TRUNCATION: hi = the top 16 bits of x (a bf16 with x's leading 8 significant bits), r = x - hi
+// (exact), mid = the top 16 bits of r, lo = the top 16 bits of r - mid: every step removes at least 8 significant bits,
+// so the three terms carry all 24 of an fp32 value.  Written with the instructions it should compile to (from the
+// generic casts the compiler emitted ~12 vector instructions per element, which made the kernel VALU-bound): per
+// pair of elements 2 v_and + 2 v_sub per level and one v_perm_b32 per packed pair - 4.5 per element.
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned sp_pack_hi16(float x1, float x0) {   // [top16(x1) : top16(x0)]
+  return __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, x1), __builtin_bit_cast(unsigned, x0), 0x07060302u);
+}
+__device__ __forceinline__ float sp_trunc16(float x) {
+  return __builtin_bit_cast(float, __builtin_bit_cast(unsigned, x) & 0xFFFF0000u);
+}
+__device__ __forceinline__ void split3_f32x4(const f32x4 x, u32x2& hi, u32x2& mid, u32x2& lo) {
+  float r[4], r2[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) r[e] = x[e] - sp_trunc16(x[e]);
+#pragma unroll
+  for (int e = 0; e < 4; ++e) r2[e] = r[e] - sp_trunc16(r[e]);
+  hi = u32x2{sp_pack_hi16(x[1], x[0]), sp_pack_hi16(x[3], x[2])};
+  mid = u32x2{sp_pack_hi16(r[1], r[0]), sp_pack_hi16(r[3], r[2])};
+  lo = u32x2{sp_pack_hi16(r2[1], r2[0]), sp_pack_hi16(r2[3], r2[2])};
+}
+
+// SBK = k per chunk: 32 (two k16 steps, one workgroup of 128 x 128 per CU) or 16 (one step, half the LDS: two
+// co-resident workgroups cover each other's barrier and fragment-read latency)
+template <int TM, int TN, int WM, int WN, int PW, int SBK>
+__global__ __launch_bounds__(64 * WM * WN, (SBK == 16 ? 2 : 1)) void conv_split_kernel(ConvKArgs p) {
+  constexpr int NT = 64 * WM * WN;
+  constexpr int BM = 32 * TM * WM;
+  constexpr int BN = 32 * TN * WN;
+  constexpr int KQ = SBK / 4;          // 16-byte staging groups per row
+  constexpr int SP_LDK = SBK + 8;      // bf16 per LDS row: 80 B (SBK 32) / 48 B (SBK 16), conflict-free 16-byte reads
+  constexpr int NSTEP = SBK / 16;
+  constexpr int ROWS = NT / KQ;
+  constexpr int AP = BM / ROWS;
+  constexpr int BP = BN / ROWS;
+  static_assert(BM % ROWS == 0 && BN % ROWS == 0, "tile/thread mismatch");
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  __bf16* As = reinterpret_cast<__bf16*>(smem);   // [2 buffers]{[3 parts][BM][SP_LDK] | [3 parts][BN][SP_LDK]}
+  __bf16* Bs = As + 3 * BM * SP_LDK;
+
+  const int nblk = gridDim.x, bid = blockIdx.x;   // XCD-aware tile order (as above)
+  const int q = nblk >> 3, r8 = nblk & 7, xcd = bid & 7, slot = bid >> 3;
+  const int logical = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + slot;
+  const int mt = logical / p.n_tiles;
+  const int nt = logical - mt * p.n_tiles;
+  const int m0 = mt * BM, n0 = nt * BN;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave - wm * WN;
+  const int l31 = lane & 31, lh = lane >> 5;
+  const int r0 = tid / KQ, kq = tid % KQ;
+  const __amdgpu_buffer_rsrc_t rsrcA =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in), 0, p.in_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrcB =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.wgt), 0, p.wgt_bytes, 0x00020000);
+  int rowoff[AP];
+  unsigned vmask[AP];
+#pragma unroll
+  for (int a = 0; a < AP; ++a) {
+    const int m = m0 + r0 + a * ROWS;
+    const bool vm = m < p.M;
+    const int mm = vm ? m : 0;
+    if (PW) {
+      rowoff[a] = (mm * p.in_ld + p.in_off) * 4;
+      vmask[a] = vm ? 1u : 0u;
+      continue;
+    }
+    const int n = mm / p.HoWo;
+    const int rem = mm - n * p.HoWo;
+    const int oy = rem / p.Wo;
+    const int ox = rem - oy * p.Wo;
+    const int iy0 = oy * p.stride - p.pad, ix0 = ox * p.stride - p.pad;
+    rowoff[a] = (((n * p.Hi + iy0) * p.Wi + ix0) * p.in_ld + p.in_off) * 4;
+    unsigned msk = 0;
+    for (int kh = 0; kh < p.KH; ++kh)
+      for (int kw = 0; kw < p.KW; ++kw)
+        if (vm && (unsigned)(iy0 + kh) < (unsigned)p.Hi && (unsigned)(ix0 + kw) < (unsigned)p.Wi)
+          msk |= 1u << (kh * p.KW + kw);
+    vmask[a] = msk;
+  }
+  unsigned woff[BP];
+#pragma unroll
+  for (int b = 0; b < BP; ++b) woff[b] = ((unsigned)(n0 + r0 + b * ROWS) * (unsigned)p.Kpad + kq * 4) * 4u;
+  int kc_c = kq * 4, kc_kh = 0, kc_kw = 0, kc_k = kq * 4;
+  if (!PW) {
+    while (kc_c >= p.Cin) {
+      kc_c -= p.Cin;
+      if (++kc_kw == p.KW) { kc_kw = 0; ++kc_kh; }
+    }
+  }
+  int kc_tap = PW ? 0 : kc_kh * p.KW + kc_kw;
+  int kc_off = PW ? kc_k * 4 : ((kc_kh * p.Wi + kc_kw) * p.in_ld + kc_c) * 4;
+
+  // Pipeline, distance 2: during the MFMAs of chunk kc the lane (1) issues the global loads of chunk kc + 2 into the
+  // register set chunk kc was staged from, and (2) splits chunk kc + 1 (loaded one chunk ago: landed) into its three
+  // bf16 images and writes them to the OTHER LDS buffer, one 16-byte item per MFMA slot - the bf16 MFMA leaves the
+  // vector issue free for 24 of its 32 cycles, so the ~22 vector instructions of an item ride beside the 6 MFMAs of
+  // a slot.  One barrier per chunk.
+  constexpr int NI = AP + BP;
+  f32x4 stg[2][NI];
+  auto load_chunk = [&](int kc, int set) {
+    const bool vk = kc_k < p.K;
+#pragma unroll
+    for (int a = 0; a < AP; ++a) {
+      const bool v = vk && ((vmask[a] >> kc_tap) & 1u);
+      const unsigned off = v ? (unsigned)(rowoff[a] + kc_off) : 0x80000000u;
+      stg[set][a] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrcA, off, 0, 0));
+    }
+#pragma unroll
+    for (int b = 0; b < BP; ++b)
+      stg[set][AP + b] =
+          __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrcB, woff[b], kc * (SBK * 4), 0));
+    kc_k += SBK;   // advance this lane's (kh, kw, c) to the next K-chunk
+    if (PW) {
+      kc_off += SBK * 4;
+    } else {
+      kc_c += SBK;
+      while (kc_c >= p.Cin) {
+        kc_c -= p.Cin;
+        if (++kc_kw == p.KW) { kc_kw = 0; ++kc_kh; }
+      }
+      kc_tap = kc_kh * p.KW + kc_kw;
+      kc_off = ((kc_kh * p.Wi + kc_kw) * p.in_ld + kc_c) * 4;
+    }
+  };
+  constexpr int IMG = 3 * (BM + BN) * SP_LDK;   // bf16 elements of one LDS buffer (A images, then W images)
+  auto store_item = [&](int it, int set, int buf) {   // split one staged 4-float group into its three bf16 images
+    u32x2 h, m, l;
+    split3_f32x4(stg[set][it], h, m, l);
+    if (it < AP) {
+      __bf16* d = As + buf * IMG + (r0 + it * ROWS) * SP_LDK + kq * 4;
+      *reinterpret_cast<u32x2*>(d) = h;
+      *reinterpret_cast<u32x2*>(d + BM * SP_LDK) = m;
+      *reinterpret_cast<u32x2*>(d + 2 * BM * SP_LDK) = l;
+    } else {
+      __bf16* d = Bs + buf * IMG + (r0 + (it - AP) * ROWS) * SP_LDK + kq * 4;
+      *reinterpret_cast<u32x2*>(d) = h;
+      *reinterpret_cast<u32x2*>(d + BN * SP_LDK) = m;
+      *reinterpret_cast<u32x2*>(d + 2 * BN * SP_LDK) = l;
+    }
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int nchunks = p.Kpad / SBK;
+  load_chunk(0, 0);
+  if (nchunks > 1) load_chunk(1, 1);
+#pragma unroll
+  for (int it = 0; it < NI; ++it) store_item(it, 0, 0);
+  __syncthreads();
+  constexpr int NSLOT = NSTEP * TM * TN;
+  constexpr int IPS = (NI + NSLOT - 1) / NSLOT;   // staging items per MFMA slot
+  constexpr int VPG = (22 * IPS + 5) / 6;         // vector instructions per MFMA gap (an item's split is ~22)
+  // MORE1 / MORE2 ("chunk kc + 1 / kc + 2 exists") are compile-time tags: the body is straight-line code, so the
+  // scheduler may weave the staging work between the MFMAs (a branch would split the scheduling region)
+  auto do_chunk = [&](int kc, auto set_tag, auto more1_tag, auto more2_tag) {
+    constexpr int SET = decltype(set_tag)::value;   // register set chunk kc was staged from = kc & 1 = LDS buffer
+    constexpr bool more1 = decltype(more1_tag)::value, more2 = decltype(more2_tag)::value;
+    if (more2) load_chunk(kc + 2, SET);
+    const __bf16* Ab = As + SET * IMG + (wm * 32 * TM + l31) * SP_LDK + 8 * lh;
+    const __bf16* Bb = Bs + SET * IMG + (wn * 32 * TN + l31) * SP_LDK + 8 * lh;
+#pragma unroll
+    for (int st = 0; st < NSTEP; ++st) {   // k16 steps of the chunk; lane (row, lh) holds k = 16 st + 8 lh .. + 7
+      bf16x8 fa[TM][3], fb[TN][3];
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int pt = 0; pt < 3; ++pt)
+          fa[i][pt] = *reinterpret_cast<const bf16x8*>(Ab + (pt * BM + i * 32) * SP_LDK + 16 * st);
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int pt = 0; pt < 3; ++pt)
+          fb[j][pt] = *reinterpret_cast<const bf16x8*>(Bb + (pt * BN + j * 32) * SP_LDK + 16 * st);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {   // smallest terms first, the leading product last
+          f32x16 c = acc[i][j];
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][1], fb[j][1], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][2], fb[j][0], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][2], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][1], fb[j][0], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][1], c, 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][0], c, 0, 0, 0);
+          if (more1) {
+            const int slot = (st * TM + i) * TN + j;
+#pragma unroll
+            for (int it = 0; it < NI; ++it)
+              if ((it * NSLOT) / NI == slot) store_item(it, SET ^ 1, SET ^ 1);
+          }
+          // issue order of this slot: the six MFMAs are a dependent chain, and an in-order wave cannot reach the vector
+          // instructions behind them until the last one has issued - so the split is woven BETWEEN them: one MFMA,
+          // then four vector instructions, six times (then the LDS writes).  The compiler clusters the MFMAs otherwise.
+#pragma unroll
+          for (int r = 0; r < 6; ++r) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // 1 MFMA
+            __builtin_amdgcn_sched_group_barrier(0x002, VPG, 0);   // VALU
+          }
+          __builtin_amdgcn_sched_group_barrier(0x200, 3 * IPS, 0);   // the item's LDS writes
+        }
+    }
+    __syncthreads();   // chunk kc + 1's images are complete, and every wave is done reading chunk kc's buffer
+  };
+  using T = std::true_type;
+  using F = std::false_type;
+  using S0 = std::integral_constant<int, 0>;
+  using S1 = std::integral_constant<int, 1>;
+  int kc = 0;
+  for (; kc + 3 < nchunks; kc += 2) {   // steady state: both look-aheads exist for kc and kc + 1
+    do_chunk(kc, S0{}, T{}, T{});
+    do_chunk(kc + 1, S1{}, T{}, T{});
+  }
+  for (; kc < nchunks; ++kc) {          // the last one to three chunks
+    const bool m1 = kc + 1 < nchunks, m2 = kc + 2 < nchunks;
+    if (kc & 1) {
+      if (m2) do_chunk(kc, S1{}, T{}, T{}); else if (m1) do_chunk(kc, S1{}, T{}, F{}); else do_chunk(kc, S1{}, F{}, F{});
+    } else {
+      if (m2) do_chunk(kc, S0{}, T{}, T{}); else if (m1) do_chunk(kc, S0{}, T{}, F{}); else do_chunk(kc, S0{}, F{}, F{});
+    }
+  }
+  conv_epilogue<TM, TN>(p, acc, m0, n0, wm, wn, l31, lh, BM, BN);
+}
+
+template <int TM, int TN, int WM, int WN, int PW, int SBK>
+static int launch_split(const ConvKArgs& a, int m_tiles, hipStream_t stream) {
+  constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
+  constexpr size_t lds = (size_t)2 * 3 * (BM + BN) * (SBK + 8) * 2;   // two buffers of three bf16 images
+  static bool attr_set = false;
+  auto kern = conv_split_kernel<TM, TN, WM, WN, PW, SBK>;
+  if (!attr_set) {
+    ST_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_set = true;
+  }
+  dim3 grid((unsigned)(m_tiles * a.n_tiles)), block(64 * WM * WN);
+  hipLaunchKernelGGL(kern, grid, block, lds, stream, a);
+  ST_CHECK_HIP(hipGetLastError());
+  return ST_OK;
+}
+
 #ifdef ST_ABLATION   // measured-negative experiment: tools-only build, not in the product library
 // ---- wave-specialised variant ---------------------------------------------------------------------------
 // WM*WN MFMA waves + ONE loader wave per block.  The ablations (tools/conv_ablation.py) show that what the
@@ -779,6 +1043,24 @@ int conv2d_launch(const StConvDesc& d, hipStream_t stream, int force_variant, in
   a.act = d.act;
 
   const int cout_pad = round_up(d.Cout, 32);
+  if (force_variant >= 50 && force_variant <= 55) {   // split-operand (bf16x3) instances of the same implicit GEMM
+    // 50 128x128 k32 | 51 64x64 k32 | 52 128x64 k32 | 53 128x128 k16 | 54 64x64 k16 | 55 128x64 k16
+    static const int sbm[3] = {128, 64, 128}, sbn[3] = {128, 64, 64};
+    const int vi = (force_variant - 50) % 3, k16 = (force_variant - 50) / 3;
+    ST_REQUIRE(cout_pad % sbn[vi] == 0, "conv: split variant %d does not divide Cout=%d", force_variant, d.Cout);
+    if (picked_variant) *picked_variant = force_variant;
+    a.n_tiles = cout_pad / sbn[vi];
+    const int m_tiles = ceil_div(a.M, sbm[vi]);
+    const bool pw = d.KH == 1 && d.KW == 1 && d.stride == 1 && d.pad == 0;
+    switch (vi + 3 * k16) {
+      case 0: return pw ? launch_split<2, 2, 2, 2, 1, 32>(a, m_tiles, stream) : launch_split<2, 2, 2, 2, 0, 32>(a, m_tiles, stream);
+      case 1: return pw ? launch_split<1, 1, 2, 2, 1, 32>(a, m_tiles, stream) : launch_split<1, 1, 2, 2, 0, 32>(a, m_tiles, stream);
+      case 2: return pw ? launch_split<1, 2, 4, 1, 1, 32>(a, m_tiles, stream) : launch_split<1, 2, 4, 1, 0, 32>(a, m_tiles, stream);
+      case 3: return pw ? launch_split<2, 2, 2, 2, 1, 16>(a, m_tiles, stream) : launch_split<2, 2, 2, 2, 0, 16>(a, m_tiles, stream);
+      case 4: return pw ? launch_split<1, 1, 2, 2, 1, 16>(a, m_tiles, stream) : launch_split<1, 1, 2, 2, 0, 16>(a, m_tiles, stream);
+      default: return pw ? launch_split<1, 2, 4, 1, 1, 16>(a, m_tiles, stream) : launch_split<1, 2, 4, 1, 0, 16>(a, m_tiles, stream);
+    }
+  }
   int pick = -1;
   if (force_variant >= 0) {
     ST_REQUIRE(conv_variant_valid(force_variant % 100, d.Cout), "conv: variant %d does not divide Cout=%d",

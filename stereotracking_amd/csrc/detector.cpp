@@ -194,6 +194,7 @@ struct StDetector {
   bool allow_chain = true;         // fuse CSP main_conv -> bottleneck conv1 when both run on the streaming kernel
   bool allow_front = true;         // fuse stage1.0 -> main|short -> conv1 (front_fused.hip)
   bool allow_wgroup = true;        // head tower convs of the three levels as grouped Winograd launches
+  bool allow_split = false;        // autotune may pick the split-operand (bf16x3) instances 50-52 (st_detector_set_split)
 #ifdef ST_ABLATION
   std::vector<char> skip;          // tools-only: ops whose launches are dropped (st_detector_set_skip)
 #endif
@@ -998,9 +999,12 @@ extern "C" int st_detector_autotune(StDetector* det, void* workspace_dev, size_t
     probe.bias_dev = det->wgt_dev + det->convs[so.pc].bias_off;
     probe.split = so.split; probe.out2_off = so.out2.off;
     const bool pr_ok = pwr_conv_applicable(probe);   // + variant 46: 1x1 with LDS-resident weights (pointwise_resident.hip)
-    for (int vi = 0; vi <= ncand + 4 && rc == ST_OK; ++vi) {
-      const int v = vi < ncand ? vi : vi == ncand + 4 ? 46 : 41 + (vi - ncand);
-      if (v == 46 ? !pr_ok : v == 41 ? !pw_ok : v == 42 ? !dc_ok : v == 43 ? !wn_ok : v == 44 ? !wn_narrow_ok
+    const int cout_pad_s = round_up(det->convs[so.pc].cout, 32);
+    for (int vi = 0; vi <= ncand + 10 && rc == ST_OK; ++vi) {
+      const int v = vi < ncand ? vi : vi > ncand + 4 ? 50 + (vi - ncand - 5) : vi == ncand + 4 ? 46 : 41 + (vi - ncand);
+      if (v >= 50) {   // split-operand instances: only when the caller allowed them; tiles must divide Cout
+        if (!det->allow_split || cout_pad_s % ((v - 50) % 3 == 0 ? 128 : 64) != 0) continue;
+      } else if (v == 46 ? !pr_ok : v == 41 ? !pw_ok : v == 42 ? !dc_ok : v == 43 ? !wn_ok : v == 44 ? !wn_narrow_ok
                                                                   : !conv_variant_valid(v, det->convs[saved[oi].pc].cout))
         continue;
       det->force_variant = v;
@@ -1035,13 +1039,20 @@ extern "C" int st_detector_autotune(StDetector* det, void* workspace_dev, size_t
   return rc;
 }
 
+// Allow (1) / forbid (0, default) the split-operand (bf16x3) instances in st_detector_autotune's search.
+extern "C" int st_detector_set_split(StDetector* det, int allow) {
+  if (!det) return set_error(ST_ERR_INVALID, "st_detector_set_split: null detector");
+  det->allow_split = allow != 0;
+  return ST_OK;
+}
+
 // id 40 = the fused Focus+stem kernel (stem_focus_conv.hip), reported with the conv ops
 // id 41 = the streaming 1x1 kernel for narrow layers (pointwise_conv.hip)
 extern "C" const char* st_conv_variant_name(int id) {
-  return id == 47 ? "headpred" : id == 46 ? "pwres" : id == 45 ? "front3x3s2" : id == 40 ? "stem6x6s2" : id == 41 ? "pw128" : id == 42 ? "dc4x32" : id == 43 ? "wino2x2" : id == 44 ? "wino2x2n" : id == 48 ? "wino2x2g" : id == 49 ? "wino2x2g+" : conv_variant_name(id);
+  return id == 47 ? "headpred" : id == 46 ? "pwres" : id == 45 ? "front3x3s2" : id == 40 ? "stem6x6s2" : id == 41 ? "pw128" : id == 42 ? "dc4x32" : id == 43 ? "wino2x2" : id == 44 ? "wino2x2n" : id == 48 ? "wino2x2g" : id == 49 ? "wino2x2g+" : id == 50 ? "split128x128" : id == 51 ? "split64x64" : id == 52 ? "split128x64" : id == 53 ? "split128x128k16" : id == 54 ? "split64x64k16" : id == 55 ? "split128x64k16" : conv_variant_name(id);
 }
 extern "C" const char* st_conv_variant_signature(int id) {
-  return id == 47 ? "head_pred" : id == 46 ? "pw_resident" : id == 45 ? "front_s2_csp" : id == 40 ? "stem_focus_conv" : id == 41 ? "pw_conv" : id == 42 ? "direct_conv3x3" : id == 43 ? "wino_conv3x3" : id == 48 ? "wino_conv3x3 grouped launch" : id == 49 ? "wino_conv3x3 grouped launch (rider: computed by the preceding op's launch)" : id == 44 ? "wino_conv3x3 narrow"
+  return id == 47 ? "head_pred" : id == 46 ? "pw_resident" : id == 45 ? "front_s2_csp" : id == 40 ? "stem_focus_conv" : id == 41 ? "pw_conv" : id == 42 ? "direct_conv3x3" : id >= 50 && id <= 55 ? "conv_split (bf16x3 operands)" : id == 43 ? "wino_conv3x3" : id == 48 ? "wino_conv3x3 grouped launch" : id == 49 ? "wino_conv3x3 grouped launch (rider: computed by the preceding op's launch)" : id == 44 ? "wino_conv3x3 narrow"
                                                               : conv_variant_signature(id);
 }
 
@@ -1061,6 +1072,11 @@ extern "C" int st_detector_set_tuning(StDetector* det, const int* variants, int 
     const Op& o = det->ops[i];
     if (variants[i] < 0 || o.type != Op::CONV) continue;
     if (variants[i] >= 41 && variants[i] <= 46) continue;   // own applicability checks run at launch
+    if (variants[i] >= 50 && variants[i] <= 55) {           // split-operand instances: the tile must divide Cout
+      ST_REQUIRE(round_up(det->convs[o.pc].cout, 32) % ((variants[i] - 50) % 3 == 0 ? 128 : 64) == 0,
+                 "st_detector_set_tuning: split variant %d invalid for op %d", variants[i], i);
+      continue;
+    }
     ST_REQUIRE(conv_variant_valid(variants[i], det->convs[o.pc].cout), "st_detector_set_tuning: variant %d invalid for op %d",
                variants[i], i);
   }

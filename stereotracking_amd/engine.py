@@ -101,6 +101,10 @@ class HipDetector:
               'st_detector_autotune')
         torch.cuda.synchronize(device)
 
+    def set_split(self, allow):
+        """Allow / forbid (default) the split-operand (bf16x3) conv instances 50-52 in the autotune search."""
+        check(self.lib.st_detector_set_split(self.handle, int(bool(allow))), 'st_detector_set_split')
+
     def get_tuning(self):
         n = self.lib.st_detector_num_ops(self.handle)
         arr = (C.c_int * n)()

@@ -273,7 +273,7 @@ class OCSORT_Disparity(nn.Module):
 
     def __init__(self, detector=None, tracker=None, motion=None, data_preprocessor=None, init_cfg=None,
                  baseline=0.25, focal_length=640, stereo=None, dense_batch=8, inflight=3, max_det=1000,
-                 results_device='cpu', autotune=True, tuning_cache=None, results_csv=None):
+                 results_device='cpu', autotune=True, tuning_cache=None, results_csv=None, split_bf16=None):
         super().__init__()
         self.data_preprocessor = MODELS.build(data_preprocessor) if data_preprocessor is not None else None
         self.detector = MODELS.build(detector) if detector is not None else None
@@ -288,6 +288,7 @@ class OCSORT_Disparity(nn.Module):
             raise ValueError("results_device must be 'cpu' or 'input'")
         self.results_device = results_device
         self.autotune, self.tuning_cache = bool(autotune), tuning_cache
+        self.split_bf16 = split_bf16      # None: $ST_SPLIT_BF16; True: the autotuner may pick the split-operand conv instances
         # the reference decorates predict with save_prediction_results('results.csv') unconditionally
         # (ocsort_disparity.py:49); here the side effect is opt-in: results_csv='results.csv' reproduces it
         self.results_csv = results_csv
@@ -358,7 +359,8 @@ class OCSORT_Disparity(nn.Module):
                 score_thr=cfg.get('score_thr', 0.01), iou_thr=nms.get('iou_threshold', 0.65), max_det=self.max_det,
                 baseline=self.baseline, focal_length=self.focal_length,
                 pad_size_divisor=getattr(self.data_preprocessor, 'pad_size_divisor', 32) or 32,
-                agg_layers=sm.agg_layers if stereo else 0, agg3d_layers=sm.agg3d_layers if stereo else 0)
+                agg_layers=sm.agg_layers if stereo else 0, agg3d_layers=sm.agg3d_layers if stereo else 0,
+                split_bf16=self.split_bf16)
             ent = self._dense[key] = [runner, None]
         ver = self._weights_version()
         if ent[1] != ver:

@@ -92,7 +92,8 @@ class StereoDensePipeline:
 
     def __init__(self, batch, ori_shape=(720, 1280), widen_factor=0.5, deepen_factor=0.33, num_classes=1,
                  stereo=True, max_disp=192, feat_stride=4, temperature=32.0, score_thr=0.01, iou_thr=0.5,
-                 max_det=1000, baseline=0.25, focal_length=640, pad_size_divisor=32, agg_layers=0, agg3d_layers=0):
+                 max_det=1000, baseline=0.25, focal_length=640, pad_size_divisor=32, agg_layers=0, agg3d_layers=0,
+                 split_bf16=None):
         """max_det: rows of the fixed-size detection buffer per frame.  The reference applies NO cap on the
         kept boxes (yolox_style=True => max_per_img = len(results)), so this is a
         capacity, not a threshold: `run()` reports `overflow` whenever a frame kept more boxes than fit, and
@@ -108,6 +109,13 @@ class StereoDensePipeline:
                                               agg3d_layers if stereo else 0)
         self.agg_layers = self.stereo_module.agg_layers
         self.agg3d_layers = self.stereo_module.agg3d_layers
+        # split_bf16: the autotuner may pick the split-operand (bf16x3) conv instances (fp32 operands as three bf16 terms,
+        # six exact products on the bf16 MFMA, fp32 accumulate: 2.67x the fp32 matrix rate, error vs float64 below the
+        # fp32-input MFMA's).  Off by default: the default plan is exact-fp32 MFMA only.
+        if split_bf16 is None:
+            import os
+            split_bf16 = os.environ.get('ST_SPLIT_BF16', '0') == '1'
+        self.split_bf16 = bool(split_bf16)
         self.max_disp, self.feat_stride = int(max_disp), int(feat_stride)
         self.D = self.stereo_module.levels
         self.temperature = float(temperature)
@@ -136,7 +144,8 @@ class StereoDensePipeline:
         import os
         key = (f'v{self.det.lib.st_version()}_b{self.batch}_{self.height}x{self.width}_w{self.det.widen_factor:g}'
                f'_d{self.det.deepen_factor:g}_s{int(self.stereo)}_a{self.agg_layers}_D{self.D}'
-               f'_ops{self.det.lib.st_detector_num_ops(self.det.handle)}_{_device_tag()}')
+               f'_ops{self.det.lib.st_detector_num_ops(self.det.handle)}_{_device_tag()}'
+               + ('_split' if self.split_bf16 else ''))
         # (the 3-D aggregation layers run on a kernel of their own: no tile choice, not part of the key)
         sources = []
         if tuning_cache is not False:
@@ -151,11 +160,14 @@ class StereoDensePipeline:
                         self.stereo_module.variant = int(cache[key + '_agg'])
                     self.tuning_source = path
                     return
+        self.det.set_split(self.split_bf16)
         self.det.autotune()
         if self.agg_layers:
             s = self.feat_stride
             dev = torch.device('cuda', torch.cuda.current_device())
-            self.stereo_module.autotune(dev, self.batch, self.height // s, self.width // s)
+            extra = (50, 51, 52) if self.split_bf16 else ()
+            self.stereo_module.autotune(dev, self.batch, self.height // s, self.width // s,
+                                        candidates=tuple(range(22)) + (42, 43) + extra)
         self.tuning_source = 'measured'
         if tuning_cache is not False:
             upd = {key: self.det.get_tuning()}
@@ -264,7 +276,7 @@ class InflightPipelines:
         return len(self.pipes)
 
     def __getattr__(self, name):   # geometry / thresholds of the (identical) contexts: batch, max_det, stereo, ...
-        if name in ('batch', 'max_det', 'stereo', 'height', 'width', 'ori_h', 'ori_w', 'agg_layers', 'agg3d_layers'):
+        if name in ('batch', 'max_det', 'stereo', 'height', 'width', 'ori_h', 'ori_w', 'agg_layers', 'agg3d_layers', 'split_bf16'):
             return getattr(self.pipes[0], name)
         raise AttributeError(name)
 

@@ -3,7 +3,7 @@
 # MFMA-pipe utilisation and HBM traffic per kernel.  Outputs under gpurun_out/prof_$1; summaries are then copied to
 # profiles/ by hand.  rocprofv3 gets the program itself after `--` (no wrapper), counters in their own passes.
 set -e
-TAG=${1:-r03}
+TAG=${1:-r04}
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
 # the plan every entry point shares: the committed configs/tuning/mi355x.json (measured here when absent)
