@@ -360,7 +360,8 @@ def test_step_leg(args, sd, batch_cpu, dev, pairs_target):
     cfg.model.stereo['agg_layers'] = args.agg_layers
     B, F = args.batch, max(args.batch, args.frames_per_call)
     model = MODELS.build(dict(cfg.model, dense_batch=B, inflight=max(1, args.shell_inflight), max_det=args.max_det,
-                              tuning_cache=os.environ.get('ST_TUNE_CACHE')))
+                              tuning_cache=os.environ.get('ST_TUNE_CACHE'),
+                              split_bf16=True if args.split_bf16 else None))
     model.detector.load_state_dict({k: v for k, v in sd.items() if not k.startswith('stereo.')}, strict=False)
     model.stereo.load_state_dict({k[len('stereo.'):]: v for k, v in sd.items() if k.startswith('stereo.')})
     left = [batch_cpu['img'][i % B:i % B + 1, :, :720].to(torch.uint8).to(dev) for i in range(F)]

@@ -476,27 +476,30 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(ConvKArgs p) {
 // the next chunk's global loads in flight during the MFMAs of the current one.
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
-// x = hi + mid + lo by TRUNCATION: hi = the top 16 bits of x (a bf16 with x's leading 8 significant bits), r = x - hi
-// (exact), mid = the top 16 bits of r, lo = the top 16 bits of r - mid: every step removes at least 8 significant bits,
-// so the three terms carry all 24 of an fp32 value.  Written with the instructions it should compile to (from the
-// generic casts the compiler emitted ~12 vector instructions per element, which made the kernel VALU-bound): per
-// pair of elements 2 v_and + 2 v_sub per level and one v_perm_b32 per packed pair - 4.5 per element.
+// x = hi + mid + lo, every term ROUNDED to nearest-even bf16 (v_cvt_pk_bf16_f32, two values per instruction): hi =
+// bf16(x), r = x - hi (exact), mid = bf16(r), lo = bf16(r - mid).  Rounding (not truncation) keeps the representation
+// error of the triple unbiased - a truncating split was measured 1.3x further from float64 end to end than the fp32
+// plan on the white-noise sequence (its residuals all have the sign of x and add up along K).  Written with the
+// instructions it should compile to (from generic casts the compiler emitted ~12 vector instructions per element,
+// which made the kernel VALU-bound): per PAIR of elements 3 v_cvt_pk + 4 shift/mask + 4 v_sub = 5.5 per element.
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ unsigned sp_pack_hi16(float x1, float x0) {   // [top16(x1) : top16(x0)]
-  return __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, x1), __builtin_bit_cast(unsigned, x0), 0x07060302u);
+__device__ __forceinline__ unsigned sp_cvt_pk_bf16(float lo, float hi) {   // [bf16(hi) : bf16(lo)], round to nearest even
+  unsigned r;
+  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+  return r;
 }
-__device__ __forceinline__ float sp_trunc16(float x) {
-  return __builtin_bit_cast(float, __builtin_bit_cast(unsigned, x) & 0xFFFF0000u);
-}
+__device__ __forceinline__ float sp_lo_f32(unsigned pk) { return __builtin_bit_cast(float, pk << 16); }
+__device__ __forceinline__ float sp_hi_f32(unsigned pk) { return __builtin_bit_cast(float, pk & 0xFFFF0000u); }
 __device__ __forceinline__ void split3_f32x4(const f32x4 x, u32x2& hi, u32x2& mid, u32x2& lo) {
-  float r[4], r2[4];
 #pragma unroll
-  for (int e = 0; e < 4; ++e) r[e] = x[e] - sp_trunc16(x[e]);
-#pragma unroll
-  for (int e = 0; e < 4; ++e) r2[e] = r[e] - sp_trunc16(r[e]);
-  hi = u32x2{sp_pack_hi16(x[1], x[0]), sp_pack_hi16(x[3], x[2])};
-  mid = u32x2{sp_pack_hi16(r[1], r[0]), sp_pack_hi16(r[3], r[2])};
-  lo = u32x2{sp_pack_hi16(r2[1], r2[0]), sp_pack_hi16(r2[3], r2[2])};
+  for (int e = 0; e < 2; ++e) {
+    const float x0 = x[2 * e], x1 = x[2 * e + 1];
+    const unsigned h = sp_cvt_pk_bf16(x0, x1);
+    const float r0 = x0 - sp_lo_f32(h), r1 = x1 - sp_hi_f32(h);        // exact
+    const unsigned m = sp_cvt_pk_bf16(r0, r1);
+    const float q0 = r0 - sp_lo_f32(m), q1 = r1 - sp_hi_f32(m);        // exact
+    hi[e] = h; mid[e] = m; lo[e] = sp_cvt_pk_bf16(q0, q1);
+  }
 }
 
 // SBK = k per chunk: 32 (two k16 steps, one workgroup of 128 x 128 per CU) or 16 (one step, half the LDS: two
@@ -721,6 +724,7 @@ static int launch_split(const ConvKArgs& a, int m_tiles, hipStream_t stream) {
     attr_set = true;
   }
   dim3 grid((unsigned)(m_tiles * a.n_tiles)), block(64 * WM * WN);
+  note_bf16_mfma_launch();   // kernels with v_pk_fma_f32 op_sel broadcasts switch to scalar FMAs from now on (st_common.cpp)
   hipLaunchKernelGGL(kern, grid, block, lds, stream, a);
   ST_CHECK_HIP(hipGetLastError());
   return ST_OK;

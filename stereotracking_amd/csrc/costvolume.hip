@@ -148,7 +148,11 @@ static inline int cvt_row(int n) {  // >= n, multiple of 4, (row / 4) odd
   return r;
 }
 
-template <int DG>
+// PK: diagonal accumulator pairs on v_pk_fma_f32 with the R operand broadcast by op_sel (see below).  PK = false
+// evaluates the same fmaf chains with scalar v_fma_f32 - bit-identical, ~7 % slower - and is what the launcher picks once
+// a kernel issuing BF16 MFMAs has been launched in this process: v_pk_fma_f32 with op_sel returns wrong sums while
+// bf16 MFMAs of another wave execute on the same SIMD (measured: tools/cv_stress.py).
+template <int DG, bool PK>
 __global__ __launch_bounds__(128) void costvolume_tiled_kernel(const float* __restrict__ featL,
                                                                const float* __restrict__ featR, int Hf, int Wf,
                                                                int C, int ld, int D, float temperature, int rowL,
@@ -274,7 +278,8 @@ __global__ __launch_bounds__(128) void costvolume_tiled_kernel(const float* __re
           for (int k = 0; k < DG - 1; ++k) {
             const int i = DG + 2 * q - k;   // window index of x + 2q - d0 - k (= that of x + 2q + 1 - d0 - (k + 1))
             const float r = rv[h][i >> 2][i & 3];
-            accd[q][k] = __builtin_elementwise_fma(lpair, f32x2{r, r}, accd[q][k]);
+            if (PK) accd[q][k] = __builtin_elementwise_fma(lpair, f32x2{r, r}, accd[q][k]);
+            else accd[q][k] = f32x2{fmaf(lpair[0], r, accd[q][k][0]), fmaf(lpair[1], r, accd[q][k][1])};
           }
           constexpr int ilo = 1, ihi = DG + 1;   // + 2q: windows of (p = 2q, k = DG-1) and (p = 2q+1, k = 0)
           accs[q][0] = fmaf(lpair[0], rv[h][(ilo + 2 * q) >> 2][(ilo + 2 * q) & 3], accs[q][0]);
@@ -480,9 +485,14 @@ extern "C" int st_costvolume_softargmin(const float* featL_dev, const float* fea
     ST_REQUIRE(totalt + 8 < (1ll << 31), "st_costvolume_softargmin: grid too large");
     const int per_xcd = (int)((totalt + 7) / 8);
     const dim3 gridt((unsigned)(8 * per_xcd)), blockt(128);
+    const bool scalar_fma = bf16_mfma_in_use();
 #define ST_CVT_LAUNCH(DGV)                                                                                    \
   do {                                                                                                         \
-    auto kern = costvolume_tiled_kernel<DGV>;                                                                  \
+    if (scalar_fma) ST_CVT_LAUNCH_I(DGV, false); else ST_CVT_LAUNCH_I(DGV, true);                              \
+  } while (0)
+#define ST_CVT_LAUNCH_I(DGV, PKV)                                                                             \
+  do {                                                                                                         \
+    auto kern = costvolume_tiled_kernel<DGV, PKV>;                                                             \
     static int lds_set = 0;                                                                                    \
     ST_ENSURE_DYNAMIC_LDS(kern, ldst, lds_set);                                                                \
     for (int sl = 0; sl < slabs; ++sl)                                                                         \
@@ -501,6 +511,7 @@ extern "C" int st_costvolume_softargmin(const float* featL_dev, const float* fea
       default: ST_CVT_LAUNCH(32); break;
     }
 #undef ST_CVT_LAUNCH
+#undef ST_CVT_LAUNCH_I
     ST_CHECK_HIP(hipGetLastError());
     return ST_OK;
   }

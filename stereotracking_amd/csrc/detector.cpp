@@ -194,7 +194,7 @@ struct StDetector {
   bool allow_chain = true;         // fuse CSP main_conv -> bottleneck conv1 when both run on the streaming kernel
   bool allow_front = true;         // fuse stage1.0 -> main|short -> conv1 (front_fused.hip)
   bool allow_wgroup = true;        // head tower convs of the three levels as grouped Winograd launches
-  bool allow_split = false;        // autotune may pick the split-operand (bf16x3) instances 50-52 (st_detector_set_split)
+  int allow_split = 0;             // bit i: autotune may pick the split-operand (bf16x3) instance 50 + i (st_detector_set_split)
 #ifdef ST_ABLATION
   std::vector<char> skip;          // tools-only: ops whose launches are dropped (st_detector_set_skip)
 #endif
@@ -1003,7 +1003,7 @@ extern "C" int st_detector_autotune(StDetector* det, void* workspace_dev, size_t
     for (int vi = 0; vi <= ncand + 10 && rc == ST_OK; ++vi) {
       const int v = vi < ncand ? vi : vi > ncand + 4 ? 50 + (vi - ncand - 5) : vi == ncand + 4 ? 46 : 41 + (vi - ncand);
       if (v >= 50) {   // split-operand instances: only when the caller allowed them; tiles must divide Cout
-        if (!det->allow_split || cout_pad_s % ((v - 50) % 3 == 0 ? 128 : 64) != 0) continue;
+        if (!((det->allow_split >> (v - 50)) & 1) || cout_pad_s % ((v - 50) % 3 == 0 ? 128 : 64) != 0) continue;
       } else if (v == 46 ? !pr_ok : v == 41 ? !pw_ok : v == 42 ? !dc_ok : v == 43 ? !wn_ok : v == 44 ? !wn_narrow_ok
                                                                   : !conv_variant_valid(v, det->convs[saved[oi].pc].cout))
         continue;
@@ -1042,7 +1042,7 @@ extern "C" int st_detector_autotune(StDetector* det, void* workspace_dev, size_t
 // Allow (1) / forbid (0, default) the split-operand (bf16x3) instances in st_detector_autotune's search.
 extern "C" int st_detector_set_split(StDetector* det, int allow) {
   if (!det) return set_error(ST_ERR_INVALID, "st_detector_set_split: null detector");
-  det->allow_split = allow != 0;
+  det->allow_split = allow == 1 ? 0x3F : (allow & 0x3F);   // 1 = all six instances; otherwise a mask (bit i = variant 50 + i)
   return ST_OK;
 }
 

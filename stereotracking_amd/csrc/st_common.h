@@ -13,6 +13,9 @@ namespace st {
 std::string& last_error();
 int set_error(int code, const char* fmt, ...);
 
+void note_bf16_mfma_launch();   // a kernel issuing BF16 MFMAs is about to be launched (st_common.cpp)
+bool bf16_mfma_in_use();
+
 inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 inline int round_up(int a, int b) { return ceil_div(a, b) * b; }
 

@@ -103,7 +103,9 @@ class HipDetector:
 
     def set_split(self, allow):
         """Allow / forbid (default) the split-operand (bf16x3) conv instances 50-52 in the autotune search."""
-        check(self.lib.st_detector_set_split(self.handle, int(bool(allow))), 'st_detector_set_split')
+        import os
+        mask = int(os.environ.get('ST_SPLIT_MASK', '0x3F'), 0) if allow else 0   # tools: restrict the instances searched
+        check(self.lib.st_detector_set_split(self.handle, mask), 'st_detector_set_split')
 
     def get_tuning(self):
         n = self.lib.st_detector_num_ops(self.handle)

@@ -145,7 +145,7 @@ class StereoDensePipeline:
         key = (f'v{self.det.lib.st_version()}_b{self.batch}_{self.height}x{self.width}_w{self.det.widen_factor:g}'
                f'_d{self.det.deepen_factor:g}_s{int(self.stereo)}_a{self.agg_layers}_D{self.D}'
                f'_ops{self.det.lib.st_detector_num_ops(self.det.handle)}_{_device_tag()}'
-               + ('_split' if self.split_bf16 else ''))
+               + ('_split' + os.environ.get('ST_SPLIT_MASK', '') if self.split_bf16 else ''))
         # (the 3-D aggregation layers run on a kernel of their own: no tile choice, not part of the key)
         sources = []
         if tuning_cache is not False:

@@ -1,0 +1,84 @@
+#!/usr/bin/env python
+"""Numerics of the split-operand conv instances 50-55 at the FULL layer shapes of the path, against the exact-fp32
+instance of the same layer (tolerance 1e-4 of the output scale), three repetitions each (a race would show as
+run-to-run differences)."""
+import ctypes as C
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from stereotracking_amd import _lib  # noqa: E402
+from stereotracking_amd._lib import StConvDesc, check, ptr  # noqa: E402
+
+lib = _lib.load()
+dev = torch.device('cuda:0')
+
+
+def run(name, N, H, W, Cin, Cout, k=1, stride=1, res=False, up=False, split=None):
+    torch.manual_seed(1)
+    x = torch.randn(N, H, W, Cin, device=dev) * torch.randn(N, H, W, Cin, device=dev).abs()
+    w = torch.randn(Cout, Cin, k, k) / (k * Cin ** 0.5)
+    b = torch.randn(Cout) * 0.1
+    wp = torch.empty(lib.st_conv_packed_floats(Cout, Cin, k, k))
+    bp = torch.empty((Cout + 31) // 32 * 32)
+    check(lib.st_conv_pack_weights(ptr(w), ptr(b), None, None, None, None, 0.0, Cout, Cin, k, k, ptr(wp), ptr(bp)))
+    wpd, bpd = wp.to(dev), bp.to(dev)
+    Ho, Wo = (H + 2 * (k // 2) - k) // stride + 1, (W + 2 * (k // 2) - k) // stride + 1
+    r = torch.randn(N, Ho, Wo, Cout, device=dev) if res else None
+
+    def conv(v):
+        out = torch.full((N, Ho, Wo, Cout), float('nan'), device=dev)
+        upb = torch.full((N, 2 * Ho, 2 * Wo, Cout), float('nan'), device=dev) if up else None
+        d = StConvDesc()
+        d.in_dev = x.data_ptr(); d.N, d.Hi, d.Wi, d.Cin, d.in_ld, d.in_off = N, H, W, Cin, Cin, 0
+        d.wgt_dev = wpd.data_ptr(); d.bias_dev = bpd.data_ptr()
+        d.Cout, d.KH, d.KW, d.stride, d.pad = Cout, k, k, stride, k // 2
+        d.out1_dev = out.data_ptr(); d.out1_ld, d.out1_off, d.split = Cout, 0, Cout
+        if up:
+            d.up_dev = upb.data_ptr(); d.up_ld, d.up_off = Cout, 0
+        if res:
+            d.res_dev = r.data_ptr(); d.res_ld, d.res_off = Cout, 0
+        d.post_scale, d.act = (0.5 if res else 1.0), 1
+        rc = lib.st_conv2d_nhwc_variant(C.byref(d), _lib.current_stream(), v)
+        torch.cuda.synchronize()
+        return (out, upb) if rc == 0 else None
+    ref = conv(3 if Cout % 64 == 0 else 0)
+    scale = ref[0].abs().max().item()
+    for v in (50, 51, 52, 53, 54, 55):
+        worst, nondet = 0.0, False
+        first = None
+        for rep in range(3):
+            got = conv(v)
+            if got is None:
+                break
+            e = (got[0] - ref[0]).abs().max().item() / scale
+            if up:
+                e = max(e, (got[1] - ref[1]).abs().max().item() / scale)
+            if e != e:
+                e = float('inf')
+            worst = max(worst, e)
+            if first is None:
+                first = got[0].clone()
+            elif not torch.equal(first, got[0]):
+                nondet = True
+        else:
+            flag = 'FAIL' if worst > 1e-4 or nondet else 'ok'
+            print(f'{name:36s} variant {v}: max err {worst:.2e} of scale {scale:.2f} {"NONDETERMINISTIC " if nondet else ""}{flag}', flush=True)
+
+
+run('op13 3x3s2 64->128 @184x320', 8, 184, 320, 64, 128, 3, 2)
+run('op22 3x3s2 128->256 @92x160', 8, 92, 160, 128, 256, 3, 2)
+run('op31 3x3s2 256->512 @46x80', 8, 46, 80, 256, 512, 3, 2)
+run('op54 3x3s2 256->256 @46x80', 8, 46, 80, 256, 256, 3, 2)
+run('op34 1x1 1024->512 @23x40', 8, 23, 40, 1024, 512)
+run('op39 1x1 512->256 @23x40 +up', 8, 23, 40, 512, 256, up=True)
+run('op44 1x1 256->128 @46x80 +up', 8, 46, 80, 256, 128, up=True)
+run('op40 1x1 512->256 @46x80', 8, 46, 80, 512, 256)
+run('op24 1x1 128->128 @46x80', 8, 46, 80, 128, 128)
+run('op45 1x1 256->128 @92x160', 8, 92, 160, 256, 128)
+run('op63 3x3 128->128 @92x160', 8, 92, 160, 128, 128, 3, 1)
+run('op25 3x3 128->128 @46x80 +res', 8, 46, 80, 128, 128, 3, 1, res=True)
+run('agg 3x3 48->48 @184x320', 8, 184, 320, 48, 48, 3, 1)
+run('op2 3x3s2 32->64 @368x640', 16, 368, 640, 32, 64, 3, 2)
