@@ -48,6 +48,8 @@ def parse():
                          '3 is faster than 4 there)')
     ap.add_argument('--split-bf16', action='store_true',
                     help='let the autotuner pick the split-operand (bf16x3) conv instances (default: exact-fp32 MFMA only)')
+    ap.add_argument('--split-leg', action='store_true',
+                    help='also time the workload with the split-operand instances allowed (secondary line)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-test-step', action='store_true',
                     help='skip the second leg through Config.fromfile -> MODELS.build -> model.test_step')
@@ -342,6 +344,37 @@ def cpu_baseline(sd, batch_cpu, max_disp, seconds, agg_layers, max_det=1000):
                 sample=f'{n} x 1 synthetic 1280x720 pair (D={max_disp}, {agg_layers} aggregation convs, full YOLOX-s '
                        'two-branch), CPU oracle '
                        f'(PyTorch fp32 + C oracle), {dt:.1f} s', host_cpus=os.cpu_count())
+
+
+def split_leg(args, sd, img, right, headline):
+    """SECONDARY line, never `value`: the same workload with the split-operand conv instances allowed in the plan (fp32
+    operands as three bf16 terms, six exact products on v_mfma_f32_32x32x16_bf16, fp32 accumulate; off by default).
+    A plan of its own is autotuned (and remembered in the user cache), the K steps are timed exactly like the headline."""
+    from stereotracking_amd.pipeline import InflightPipelines
+    try:
+        runner = InflightPipelines(max(1, args.inflight), args.batch, (720, 1280), 0.5, 0.33, 1, stereo=True,
+                                   max_disp=args.max_disp, max_det=args.max_det, agg_layers=args.agg_layers,
+                                   split_bf16=True)
+        runner.load_state_dict(sd)
+        for _ in range(args.warmup):
+            runner.submit(img, right)
+        runner.synchronize()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            runner.submit(img, right)
+        runner.synchronize()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        plan = runner.pipes[0].det.get_tuning()
+        v = args.batch * args.steps / dt
+        return dict(value=round(v, 3), unit='stereo frame-pairs/s', ms_per_step=round(dt / args.steps * 1e3, 4),
+                    vs_headline=round(v / headline, 4), ops_on_split_instances=sum(1 for t in plan if 50 <= t <= 55),
+                    conv_ops=sum(1 for t in plan if t >= 0),
+                    note='NOT the headline: plan with split-operand (bf16x3) conv instances; outputs differ from the '
+                         'exact-fp32 plan by fp32-level noise (head 3e-4 relative), parity record in DESIGN.md')
+    except Exception as e:   # a secondary line must never cost the headline
+        return dict(error=repr(e))
 
 
 def test_step_leg(args, sd, batch_cpu, dev, pairs_target):
@@ -646,6 +679,8 @@ def main():
             if line['test_step'].get('long_call'):
                 line['test_step']['long_call']['vs_pipeline'] = round(line['test_step']['long_call']['value'] / line['value'], 4)
         line['tracker_cpu'] = tracker_cost()
+        if world == 1 and args.split_leg and not args.split_bf16:
+            line['secondary_split_bf16x3'] = split_leg(args, sd, img, right, line['value'])
         if world == 1:
             line['batched_gpu_association'] = batched_association_line(dev)
         if world == 1 and not args.no_cpu_baseline:
