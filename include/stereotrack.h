@@ -208,8 +208,8 @@ int st_detector_set_param(StDetector* det, const char* name, const float* host, 
 int st_detector_finalize(StDetector* det);
 
 size_t st_detector_workspace_bytes(const StDetector* det);
-/* head output layout: for level l (stride 8,16,32): float[N][H_l*W_l][8],
- * channel 0 = cls logit, 1..4 = reg (x,y,w,h), 5 = obj logit, 6,7 unused;
+/* head output layout: for level l (stride 8,16,32): float[N][H_l*W_l][8] rows of
+ * [cls logits (num_classes = 1..3) | reg x,y,w,h | obj logit | unused up to 8];
  * levels concatenated.  st_detector_head_floats = total float count. */
 size_t st_detector_head_floats(const StDetector* det);
 int st_detector_num_levels(const StDetector* det);
@@ -232,8 +232,10 @@ int st_detector_forward_phase(StDetector* det, int phase, const float* img_dev,
                               size_t workspace_bytes, st_stream_t stream, float* head_out_dev);
 /* Per-op timing for bench.py / profiling.  When enabled every op (focus pack, conv, spp) of the
  * following forwards is bracketed by hipEvents on the caller's stream; st_detector_op_times
- * synchronises on them and returns, per op: elapsed ms, kind (0 focus, 1 conv, 2 spp), conv tile
- * variant (0: 128x128, 1: 128x64, 2: 128x32, 3: 64x64, 4: 64x32; -1 otherwise), conv MACs, phase. */
+ * synchronises on them and returns, per op: elapsed ms, kind (0 focus, 1 conv, 2 spp), the kernel
+ * instance that ran it (0..21 implicit-GEMM tiles, 40 fused stem, 41 streaming 1x1, 42 direct 3x3,
+ * 43 / 44 Winograd, 45 fused front, 46 resident 1x1, 47 head prediction, 48 / 49 grouped Winograd launch
+ * and its riders, 50..55 split-operand instances; names: st_conv_variant_name; -1 otherwise), conv MACs, phase. */
 int st_detector_set_timing(StDetector* det, int enable);
 int st_detector_num_ops(const StDetector* det);
 int st_detector_op_times(StDetector* det, int cap, float* ms, int* kind, int* variant, double* macs,
