@@ -161,6 +161,12 @@ int st_stem_focus_conv(const float* img_nchw_dev, int N, int H, int W, int used_
 int st_pack_raw_inputs(const unsigned char* img_u8_dev, const unsigned short* disp_u16_dev, int N, int h, int w,
                        int H, int W, float img_pad, float* img_out_dev, float* disp_postp_out_dev,
                        float* disp_mask_out_dev, st_stream_t stream);
+/* The image half of st_pack_raw_inputs for frames in SEPARATE allocations (one contiguous (3, h, w) uint8 tensor per
+ * frame, as a dataloader hands them over - reference formatting_disparity.py:139-338 packs one frame per sample):
+ * frames_u8_dev_ptrs_host = HOST array of N device pointers (N <= 32; they travel in the kernel arguments), w and W
+ * multiples of 4.  No concatenated staging copy. */
+int st_pack_raw_frames(const unsigned char* const* frames_u8_dev_ptrs_host, int N, int h, int w, int H, int W,
+                       float img_pad, float* img_out_dev, st_stream_t stream);
 
 /* SPP: out[..., 0:C]=x, [C:2C]=maxpool5, [2C:3C]=maxpool9, [3C:4C]=maxpool13
  * (stride 1, same pad, -inf padding).  x may alias out channels [0,C).

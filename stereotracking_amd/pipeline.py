@@ -117,6 +117,7 @@ class StereoDensePipeline:
             split_bf16 = os.environ.get('ST_SPLIT_BF16', '0') == '1'
         self.split_bf16 = bool(split_bf16)
         self.max_disp, self.feat_stride = int(max_disp), int(feat_stride)
+        self.disp_buffers, self.disp_guard, self.disp_slot, self._disp_turn = 1, [None], 0, 0
         self.D = self.stereo_module.levels
         self.temperature = float(temperature)
         self.score_thr, self.iou_thr, self.max_det = float(score_thr), float(iou_thr), int(max_det)
@@ -177,13 +178,21 @@ class StereoDensePipeline:
 
     # ---- buffers -----------------------------------------------------------------------------------
     def _buffers(self, dev):
-        if self._bufs is None or self._bufs['dev'] != dev:
+        if (self._bufs is None or self._bufs['dev'] != dev or
+                len(self._bufs['disp_ring']) != max(1, int(self.disp_buffers))):
             N, H, W, M = self.batch, self.height, self.width, self.max_det
             f32 = dict(dtype=torch.float32, device=dev)
             b = dict(dev=dev)
             b['head'] = torch.empty(self.det.head_floats, **f32)
             b['disp_lr'] = torch.empty(N, H // self.feat_stride, W // self.feat_stride, **f32)
-            b['disp_postp'] = torch.empty(N, 3, H, W, **f32)
+            # disp_buffers > 1: the stereo module's output alternates between that many buffers, so a consumer may keep
+            # reading run k's disparity (the MOT shell's track-box depth, on a side stream) while run k+1 writes the
+            # next one; `disp_guard[i]` = event the consumer records after its last read of buffer i (waited on before
+            # buffer i is rewritten)
+            b['disp_ring'] = [torch.empty(N, 3, H, W, **f32) for _ in range(max(1, int(self.disp_buffers)))]
+            b['disp_postp'] = b['disp_ring'][0]
+            self.disp_guard = [None] * len(b['disp_ring'])
+            self._disp_turn = 0
             b['depth'] = torch.empty(N, M, **f32)       # rows past the count are written as 0 by st_box_depth
             b['scales'] = torch.empty(N, M, **f32)
             b['scaled_boxes'] = torch.empty(N, M, 4, **f32)
@@ -197,8 +206,15 @@ class StereoDensePipeline:
         """Stereo module: stem+stage1 features of left/right -> cost volume -> soft-argmin ->
         bilinear x4 -> disp_postp (N,3,H,W) in pixels, 0 outside the original image."""
         b = self._buffers(img.device)
-        self.stereo_module.compute(self.det, img, right, (self.ori_h, self.ori_w), b['disp_lr'], b['disp_postp'])
-        return b['disp_postp']
+        k = self._disp_turn % len(b['disp_ring'])
+        self._disp_turn += 1
+        self.disp_slot = k
+        if self.disp_guard[k] is not None:
+            torch.cuda.current_stream(img.device).wait_event(self.disp_guard[k])
+            self.disp_guard[k] = None
+        out = b['disp_postp'] = b['disp_ring'][k]
+        self.stereo_module.compute(self.det, img, right, (self.ori_h, self.ori_w), b['disp_lr'], out)
+        return out
 
     def box_depth(self, disp_postp, boxes, counts, out=None):
         """bbox_postp_depth (ocsort_disparity.py:113-130) on device -> depth, scales, scaled boxes."""
@@ -214,7 +230,8 @@ class StereoDensePipeline:
         """img (N,3,H,W) fp32 CUDA; stereo: right (N,3,H,W); mono: disp_postp (N,3,H,W).
         Returns a dict of device tensors (no host sync; the context's PERSISTENT buffers, overwritten by its next run): boxes (N,M,4) unscaled xyxy, scores, labels,
         prior_idx, counts (TRUE number kept per frame), overflow (N,) bool = counts > M, depth, scales,
-        scaled_boxes, disp_postp, head.  Rows past min(counts, M) are zero (prior_idx -1)."""
+        scaled_boxes, disp_postp, head.  Rows past min(counts, M) are zero (prior_idx -1).  With disp_buffers > 1 the
+        stereo module's disp_postp is buffer `self.disp_slot` of the ring (see _buffers)."""
         _require_cuda(img, 'img')
         b = self._buffers(img.device)
         if self.stereo:

@@ -253,3 +253,45 @@ def test_frames_without_detections_and_ragged_calls(cuda):
             assert set(o.pred_track_instances.keys()) >= {'bboxes', 'labels', 'scores', 'scales', 'depth', 'gt_depth',
                                                           'instances_id'}
             assert o.metainfo['batch_input_shape'] == (96, 160) and o.metainfo['pad_shape'] == ori
+
+
+@pytest.mark.parametrize('frames_per_call,inflight,queue_depth', [(12, 3, 2), (4, 2, 1), (9, 3, 2), (30, 1, 2), (8, 2, 3)])
+def test_primed_loop_equals_per_call_test_step(frames_per_call, inflight, queue_depth, cuda):
+    """model.test_steps(iterable) - contexts kept primed across calls: call k+1's first chunks are submitted while call
+    k drains - returns, call by call, exactly what model.test_step returns for the same calls (boxes, scores, ids,
+    track depth: bit-equal), over a 2-video stream whose calls are ragged against the dense batch."""
+    from stereotracking_amd.structures import TrackDataSample
+    model, _, _ = build_model(CFG_STEREO, cuda, autotune=False)
+    model.dense_batch, model.inflight, model.queue_depth = 4, inflight, queue_depth
+    ori = (80, 160)
+    T = 30
+    fr = synthetic_batch(list(range(200, 200 + T)), ori[0], ori[1], 32)
+    left = [fr['img'][i:i + 1, :, :ori[0]].to(torch.uint8).to(cuda) for i in range(T)]
+    right = [fr['right'][i:i + 1, :, :ori[0]].to(torch.uint8).to(cuda) for i in range(T)]
+
+    def calls():
+        for lo in range(0, T, frames_per_call):
+            hi = min(T, lo + frames_per_call)
+            # two videos: frame ids restart at frame 17 (the tracker resets on frame_id 0)
+            samples = [TrackDataSample(dict(frame_id=t if t < 17 else t - 17, ori_shape=ori, scale_factor=(1.0, 1.0)))
+                       for t in range(lo, hi)]
+            yield dict(inputs=dict(img=left[lo:hi], right=right[lo:hi]), data_samples=samples)
+
+    ref = [model.test_step(d) for d in calls()]
+    torch.cuda.synchronize()
+    model.tracker.reset()
+    got = list(model.test_steps(calls()))
+    torch.cuda.synchronize()
+    assert [len(c) for c in got] == [len(c) for c in ref]
+    n_tracks = 0
+    for ca, cb in zip(got, ref):
+        for a, b in zip(ca, cb):
+            assert a.metainfo['frame_id'] == b.metainfo['frame_id']
+            assert torch.equal(a.pred_det_instances.bboxes, b.pred_det_instances.bboxes)
+            assert torch.equal(a.pred_det_instances.scores, b.pred_det_instances.scores)
+            ta, tb = a.pred_track_instances, b.pred_track_instances
+            assert ta.instances_id.tolist() == tb.instances_id.tolist()
+            for k in ('bboxes', 'scores', 'depth', 'gt_depth', 'scales'):
+                assert torch.equal(ta[k], tb[k]), k
+            n_tracks += len(ta)
+    assert n_tracks > 0

@@ -223,6 +223,26 @@ def test_pack_raw_inputs_matches_reference_pipeline(h, w, cuda):
     assert np.array_equal(out['disp_mask'].cpu().numpy(), ref_mask)
 
 
+@pytest.mark.parametrize('h,w,B,n', [(48, 72, 4, 4), (64, 96, 8, 5), (720, 1280, 8, 8)])
+def test_raw_frames_chunk_pointer_table(h, w, B, n, cuda):
+    """RawFrames.chunk (st_pack_raw_frames: the frames stay in their own allocations, pointers in the kernel
+    arguments) == cast + pad-114 of the concatenated frames (data_preprocessor_disparity_v1.py:38-51), bit-exact,
+    the last frame repeated up to the batch size; a non-contiguous frame takes the torch.cat route, same values."""
+    from stereotracking_amd.mot import RawFrames
+    rng = np.random.RandomState(11)
+    frames = [torch.from_numpy(rng.randint(0, 256, (1, 3, h, w)).astype(np.uint8)).to(cuda) for _ in range(n)]
+    H, W = (h + 31) // 32 * 32, (w + 31) // 32 * 32
+    ref = torch.full((B, 3, H, W), 114.0, device=cuda)
+    for i in range(B):
+        ref[i, :, :h, :w] = frames[min(i, n - 1)][0].float()
+    out = RawFrames(frames, (H, W), 114.0).chunk(0, n, B)
+    assert torch.equal(out, ref)
+    strided = list(frames)
+    strided[1] = torch.stack([frames[1][0], frames[1][0]], 1)[:, 0][None]      # a non-contiguous view of frame 1
+    assert not strided[1].is_contiguous() and torch.equal(strided[1], frames[1])
+    assert torch.equal(RawFrames(strided, (H, W), 114.0).chunk(0, n, B), ref)
+
+
 @pytest.mark.parametrize('agg_layers,tuned', [(1, False), (2, False), (2, True)])
 def test_stereo_module_with_aggregation_matches_oracle(agg_layers, tuned, cuda):
     """Full stereo module (stage-1 features of both views -> cost volume -> `agg_layers` 3x3 convs over
