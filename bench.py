@@ -455,7 +455,7 @@ def test_step_leg(args, sd, batch_cpu, dev, pairs_target):
                                       after_last_chunk_left_the_gpu=round(tm['tail_s'] / calls * 1e3, 3)),
                 tracks_last_frame=int(len(outs[-1].pred_track_instances)),
                 detections_last_frame=int(len(outs[-1].pred_det_instances)),
-                note='includes the preprocessor (uint8 -> fp32, pad, stack), the dense path on the model\'s in-flight '
+                note='includes the preprocessor (uint8 frames; the cast + pad happens inside the stem kernels), the dense path on the model\'s in-flight '
                      'contexts, one D2H of the detection records per 8-frame chunk, the CPU OC-SORT association with the '
                      'shipped thresholds and one batched depth launch for the tracks per chunk')
 

@@ -151,6 +151,14 @@ int st_stem_pack_weights(const float* w, const float* conv_bias, /* may be NULL 
 int st_stem_focus_conv(const float* img_nchw_dev, int N, int H, int W, int used_planes, const float* wgt_dev,
                        const float* bias_dev, int Cout, float* out_nhwc_dev, int out_ld, int out_off,
                        int act /* 1 = SiLU */, st_stream_t stream);
+/* The same stem reading RAW frames: N separate uint8 [3][h][w] device frames (HOST array of N <= 32 device pointers,
+ * 4-byte aligned, w % 4 == 0), converted to fp32 and padded to H x W with pad_value (integral, 0..255) while the input
+ * windows are staged - TrackDataPreprocessor_Disparity_V1's cast + stack_batch pad (reference
+ * data_preprocessor_disparity_v1.py:38-51, utils/misc.py:13-64) fused into the stem; same values as st_pack_raw_frames
+ * followed by st_stem_focus_conv. */
+int st_stem_focus_conv_u8(const unsigned char* const* frames_u8_dev_ptrs_host, int N, int h, int w, int H, int W,
+                          float pad_value, const float* wgt_dev, const float* bias_dev, int Cout, float* out_dev,
+                          int out_ld, int out_off, int act, st_stream_t stream);
 
 /* Raw input packing: uint8 image (N,3,h,w) -> fp32 (N,3,H,W) padded with img_pad;
  * uint16 disparity PNG codes (N,h,w) -> disp_postp fp32 px = code/16 (65535 -> 0) x3 channels padded with
@@ -236,6 +244,12 @@ double st_detector_macs(const StDetector* det);
 int st_detector_forward_phase(StDetector* det, int phase, const float* img_dev,
                               const float* disp_dev, const float* right_dev, void* workspace_dev,
                               size_t workspace_bytes, st_stream_t stream, float* head_out_dev);
+/* Phase 0 from RAW frames (see st_stem_focus_conv_u8): left / right = HOST arrays of `batch` device pointers to uint8
+ * [3][h][w] frames; the detector's height x width is the padded size.  Requires the fused stem (always the case for the
+ * shipped widths).  Results are bit-identical to st_pack_raw_frames + st_detector_forward_phase(det, 0, ...). */
+int st_detector_forward_phase0_raw(StDetector* det, const unsigned char* const* left_frames_host,
+                                   const unsigned char* const* right_frames_host, int h, int w, float pad_value,
+                                   void* workspace_dev, size_t workspace_bytes, st_stream_t stream);
 /* Per-op timing for bench.py / profiling.  When enabled every op (focus pack, conv, spp) of the
  * following forwards is bracketed by hipEvents on the caller's stream; st_detector_op_times
  * synchronises on them and returns, per op: elapsed ms, kind (0 focus, 1 conv, 2 spp), the kernel

@@ -67,6 +67,8 @@ _vp, _i, _f, _sz = C.c_void_p, C.c_int, C.c_float, C.c_size_t
 _PROTOS = {
     'st_version': (C.c_int, []),
     'st_png_unfilter': (_i, [_vp, _i, _i, _i, _vp]),
+    'st_stem_focus_conv_u8': (_i, [_vp, _i, _i, _i, _i, _i, _f, _vp, _vp, _i, _vp, _i, _i, _i, _vp]),
+    'st_detector_forward_phase0_raw': (_i, [_vp, _vp, _vp, _i, _i, _f, _vp, _sz, _vp]),
     'st_pack_raw_frames': (_i, [_vp, _i, _i, _i, _i, _i, _f, _vp, _vp]),
     'st_detector_set_split': (_i, [_vp, _i]),
     'st_volume_agg3d': (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _f, _i, _vp]),

@@ -57,7 +57,7 @@ const char* conv_variant_signature(int id);
 int focus_pack_launch(const float* img, int N, int C, int H, int W, float* out, hipStream_t stream);
 int stem_focus_conv_launch(const float* in, int N, int H, int W, int used_planes, const float* wgt,
                            const float* bias, int Cout, float* out, int out_ld, int out_off, int act,
-                           hipStream_t stream);
+                           hipStream_t stream, const StemRawInput* raw);
 int spp_pool_launch(const float* x, int x_ld, int x_off, int N, int H, int W, int C, float* out,
                     int out_ld, int out_off, hipStream_t stream);
 struct HeadPredLevel {
@@ -184,6 +184,7 @@ struct StDetector {
   int lvl_h[3]{}, lvl_w[3]{}, lvl_stride[3]{};
   size_t lvl_off[3]{};
   size_t head_floats = 0;
+  StemRawInput raw_inputs[3] = {{nullptr, 0, 0, 0.f}, {nullptr, 0, 0, 0.f}, {nullptr, 0, 0, 0.f}};   // set for the duration of st_detector_forward_phase_raw
   std::map<std::string, TRef> taps;
   int cur_phase = 0;
   // optional per-op timing (bench/profiling only): events on the caller's stream around every op
@@ -714,18 +715,19 @@ int launch_op(StDetector* det, Op& o, int img0, const float* const inputs[3], fl
   switch (o.type) {
     case Op::FOCUS: {
       const float* src = inputs[o.focus_input];
-      ST_REQUIRE(src != nullptr, "detector: input %d not provided", o.focus_input);
+      ST_REQUIRE(src != nullptr, "detector: input %d not provided (raw uint8 frames need the fused stem)", o.focus_input);
       float* dst = resolve(det, o.out1, ws, head) + (size_t)o.focus_batch_off * o.out1.H * o.out1.W * o.out1.ld;
       return focus_pack_launch(src, det->cfg.batch, 3, det->cfg.height, det->cfg.width, dst, stream);
     }
     case Op::STEM: {
       const float* src = inputs[o.focus_input];
-      ST_REQUIRE(src != nullptr, "detector: input %d not provided", o.focus_input);
+      const StemRawInput* raw = det->raw_inputs[o.focus_input].frames ? &det->raw_inputs[o.focus_input] : nullptr;
+      ST_REQUIRE(src != nullptr || raw != nullptr, "detector: input %d not provided", o.focus_input);
       const PackedConv& pc = det->convs[o.pc];
       float* dst = resolve(det, o.out1, ws, head) + (size_t)o.focus_batch_off * o.out1.H * o.out1.W * o.out1.ld;
       return stem_focus_conv_launch(src, det->cfg.batch, det->cfg.height, det->cfg.width, pc.stem_planes,
                                     det->wgt_dev + pc.wgt_off, det->wgt_dev + pc.bias_off, pc.cout, dst, o.out1.ld,
-                                    o.out1.off, 1, stream);
+                                    o.out1.off, 1, stream, raw);
     }
     case Op::SPP: {
       float* x = resolve(det, o.in, ws, head, img0);
@@ -897,6 +899,29 @@ extern "C" int st_detector_forward_phase(StDetector* det, int phase, const float
   const float* inputs[3] = {img_dev, disp_dev, right_dev};
   return run_ops(det, phase, phase, inputs, static_cast<float*>(workspace_dev), head_out_dev,
                  static_cast<hipStream_t>(stream));
+}
+
+// Phase 0 of the stereo configuration from RAW frames: the left (and right) images are N separate uint8 [3][h][w]
+// device frames; the fused stem converts and pads them (to height x width, with pad_value) while it stages its input
+// windows, so the cast + pad of the data preprocessor costs no pass over HBM and no fp32 copy of the images exists.
+extern "C" int st_detector_forward_phase0_raw(StDetector* det, const unsigned char* const* left_frames_host,
+                                              const unsigned char* const* right_frames_host, int h, int w,
+                                              float pad_value, void* workspace_dev, size_t workspace_bytes,
+                                              st_stream_t stream) {
+  if (!det) return set_error(ST_ERR_INVALID, "st_detector_forward_phase0_raw: null detector");
+  if (!det->finalized) return set_error(ST_ERR_STATE, "st_detector_forward_phase0_raw: call st_detector_finalize first");
+  ST_REQUIRE(workspace_dev != nullptr && left_frames_host != nullptr, "st_detector_forward_phase0_raw: null pointer");
+  ST_REQUIRE(!det->cfg.with_right_branch || right_frames_host != nullptr,
+             "st_detector_forward_phase0_raw: right frames required");
+  if (workspace_bytes < det->ws_floats * sizeof(float))
+    return set_error(ST_ERR_WORKSPACE, "st_detector_forward_phase0_raw: workspace %zu < required %zu", workspace_bytes,
+                     det->ws_floats * sizeof(float));
+  det->raw_inputs[0] = StemRawInput{left_frames_host, h, w, pad_value};
+  det->raw_inputs[2] = StemRawInput{right_frames_host, h, w, pad_value};
+  const float* inputs[3] = {nullptr, nullptr, nullptr};
+  const int rc = run_ops(det, 0, 0, inputs, static_cast<float*>(workspace_dev), nullptr, static_cast<hipStream_t>(stream));
+  det->raw_inputs[0] = det->raw_inputs[2] = StemRawInput{nullptr, 0, 0, 0.f};
+  return rc;
 }
 
 // Per-op timing for bench.py / profiling: when enabled, every op of the next forward is bracketed

@@ -13,6 +13,13 @@ namespace st {
 std::string& last_error();
 int set_error(int code, const char* fmt, ...);
 
+// Raw uint8 input of the fused stem (stem_focus_conv.hip): N separate [3][h][w] frames, padded on the fly to H x W.
+struct StemRawInput {
+  const unsigned char* const* frames;   // HOST array of N device pointers
+  int h, w;
+  float pad_value;
+};
+
 void note_bf16_mfma_launch();   // a kernel issuing BF16 MFMAs is about to be launched (st_common.cpp)
 bool bf16_mfma_in_use();
 

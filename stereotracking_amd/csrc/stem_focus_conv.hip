@@ -48,6 +48,8 @@ constexpr int stem_tile4(int cin) { return cin * STEM_IH * STEM_ROW4; }         
 constexpr int stem_ndma(int cin) { return (stem_tile4(cin) + 255) / 256; }        // 8 wave-instructions of 1 KiB
 constexpr int stem_buf(int cin) { return stem_ndma(cin) * 256 * 4; }              // floats per window buffer (padded)
 
+constexpr int STEM_MAX_FRAMES = 32;
+
 struct StemArgs {
   const float* in;     // [N][3][H][W] planar fp32
   const float* wgt;    // [108][CoutPad]
@@ -57,6 +59,12 @@ struct StemArgs {
   int tiles_x, tiles_y;
   int planes;          // planes per image in memory (3); the kernel reads the first CIN of them
   unsigned out_bytes;  // bytes addressable through `out` (range check of the epilogue stores)
+  // raw-input form (U8 kernels): the N images are separate uint8 [3][h][w] frames (h <= H, w <= W, w % 4 == 0); the
+  // window is converted while it is staged, pixels of the padded H x W image outside h x w read `pad_u8` - the cast +
+  // pad of the data preprocessor (data_preprocessor_disparity_v1.py:38-51) without an fp32 copy of the image in HBM
+  const unsigned char* frames[STEM_MAX_FRAMES];
+  int h, w;
+  unsigned pad4;       // pad value replicated into 4 bytes
 };
 
 __device__ __forceinline__ float stem_silu(float v) { return v * __builtin_amdgcn_rcpf(1.0f + __expf(-v)); }
@@ -90,9 +98,43 @@ __device__ __forceinline__ void stem_dma(const StemArgs& p, int t, int tid, floa
 #endif
 }
 
+// The same window from uint8 frames: 4 pixels (one dword) per float4 slot into registers ...
+template <int CIN>
+__device__ __forceinline__ void stem_fetch_u8(const StemArgs& p, int t, int tid, unsigned (&q)[stem_ndma(CIN)]) {
+  const int tx = t % p.tiles_x;
+  const int t2 = t / p.tiles_x;
+  const int ty = t2 % p.tiles_y, n = t2 / p.tiles_y;
+  const int iy0 = 2 * ty * STEM_TH - 2, ix0 = 2 * tx * STEM_TW - 4;
+  const unsigned char* __restrict__ f = p.frames[n];     // uniform: scalar load from the kernel arguments
+#pragma unroll
+  for (int j = 0; j < stem_ndma(CIN); ++j) {
+    const int idx = tid + 256 * j;
+    const int rowc = idx / STEM_ROW4, col4 = idx - rowc * STEM_ROW4;
+    const int c = rowc / STEM_IH, row = rowc - c * STEM_IH;
+    const int gy = iy0 + row, gx = ix0 + 4 * col4;
+    const bool in_pad = idx < stem_tile4(CIN) && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;   // else conv zero padding
+    const bool in_img = in_pad && gy < p.h && gx < p.w;
+    unsigned v = in_pad ? p.pad4 : 0u;
+    if (in_img) v = *reinterpret_cast<const unsigned*>(f + ((size_t)(c * p.h + gy) * p.w + gx));
+    q[j] = v;
+  }
+}
+
+// ... and, converted to fp32, into the LDS window (same layout the LDS-DMA produces)
+template <int CIN>
+__device__ __forceinline__ void stem_commit_u8(const unsigned (&q)[stem_ndma(CIN)], int tid, float* dst) {
+#pragma unroll
+  for (int j = 0; j < stem_ndma(CIN); ++j) {
+    const unsigned v = q[j];
+    f32x4 o;
+    o[0] = (float)(v & 0xffu); o[1] = (float)((v >> 8) & 0xffu); o[2] = (float)((v >> 16) & 0xffu); o[3] = (float)(v >> 24);
+    *reinterpret_cast<f32x4*>(dst + (size_t)(tid + 256 * j) * 4) = o;
+  }
+}
+
 // Persistent workgroups (grid = resident slots) with two window buffers: the window of tile t+grid streams into
 // LDS while tile t runs its MFMAs, and the weights are staged once per workgroup instead of once per tile.
-template <int NB, bool VEC, int CIN>
+template <int NB, bool VEC, int CIN, bool U8>
 __global__ __launch_bounds__(256, NB == 1 ? 2 : 1) void stem_focus_conv_kernel(const StemArgs p) {
   extern __shared__ float4 stem_smem4[];
   float* smem = reinterpret_cast<float*>(stem_smem4);
@@ -104,7 +146,13 @@ __global__ __launch_bounds__(256, NB == 1 ? 2 : 1) void stem_focus_conv_kernel(c
   int t = blockIdx.x;
   if (t >= total) return;   // uniform per workgroup
 
-  stem_dma<CIN>(p, t, tid, smem);
+  unsigned q[stem_ndma(CIN)];
+  if (U8) {
+    stem_fetch_u8<CIN>(p, t, tid, q);
+    stem_commit_u8<CIN>(q, tid, smem);
+  } else {
+    stem_dma<CIN>(p, t, tid, smem);
+  }
   for (int idx = tid; idx < 2 * STEM_KP * NB * 32; idx += 256) wl[idx] = p.wgt[idx];
   const float* wbase = wl + half * (NB * 32) + l31;   // B operand of lane = (co = l31, k = 2s + half)
   // operands are swapped (A = weights, B = pixels), so the accumulator is C[co][pixel]: lane = pixel l31 of the
@@ -191,7 +239,10 @@ __global__ __launch_bounds__(256, NB == 1 ? 2 : 1) void stem_focus_conv_kernel(c
 
   while (true) {
     const int tn = t + gridDim.x;
-    if (tn < total) stem_dma<CIN>(p, tn, tid, smem + (cur ^ 1) * STEM_BUF);   // lands during the MFMA phase
+    if (tn < total) {   // lands during the MFMA phase
+      if (U8) stem_fetch_u8<CIN>(p, tn, tid, q);
+      else stem_dma<CIN>(p, tn, tid, smem + (cur ^ 1) * STEM_BUF);
+    }
     const float* win = smem + cur * STEM_BUF;
 
     // ---- STEM_WB pixel blocks per wave: rows (WB/2)*wave + (i >> 1), x blocks i & 1.
@@ -232,6 +283,7 @@ __global__ __launch_bounds__(256, NB == 1 ? 2 : 1) void stem_focus_conv_kernel(c
       }
       __builtin_amdgcn_sched_barrier(0);
     }
+    if (U8 && tn < total) stem_commit_u8<CIN>(q, tid, smem + (cur ^ 1) * STEM_BUF);   // nobody reads that buffer now
     // next window landed (vmcnt(0)) and every wave is done reading this one
     __syncthreads();
 #pragma unroll
@@ -252,8 +304,19 @@ __global__ __launch_bounds__(256, NB == 1 ? 2 : 1) void stem_focus_conv_kernel(c
 
 int stem_focus_conv_launch(const float* in, int N, int H, int W, int used_planes, const float* wgt,
                            const float* bias, int Cout, float* out, int out_ld, int out_off, int act,
-                           hipStream_t stream) {
-  ST_REQUIRE(in && wgt && bias && out, "stem_focus_conv: null pointer");
+                           hipStream_t stream, const StemRawInput* raw) {
+  ST_REQUIRE((in || raw) && wgt && bias && out, "stem_focus_conv: null pointer");
+  if (raw) {
+    ST_REQUIRE(used_planes == 3 && N <= STEM_MAX_FRAMES, "stem_focus_conv: raw frames need the 3-plane stem and N <= %d",
+               STEM_MAX_FRAMES);
+    ST_REQUIRE(raw->h > 0 && raw->h <= H && raw->w > 0 && raw->w <= W && raw->w % 4 == 0,
+               "stem_focus_conv: raw frame %dx%d does not fit the padded %dx%d image (w %% 4 == 0)", raw->h, raw->w, H, W);
+    ST_REQUIRE(raw->pad_value >= 0.f && raw->pad_value <= 255.f && raw->pad_value == (float)(int)raw->pad_value,
+               "stem_focus_conv: raw frames need an integral pad value in 0..255 (got %g)", (double)raw->pad_value);
+    for (int i = 0; i < N; ++i)
+      ST_REQUIRE(raw->frames[i] && (reinterpret_cast<uintptr_t>(raw->frames[i]) & 3) == 0,
+                 "stem_focus_conv: raw frame %d null or not 4-byte aligned", i);
+  }
   ST_REQUIRE(used_planes == 3 || used_planes == 1, "stem_focus_conv: used_planes must be 3 or 1 (got %d)",
              used_planes);
   ST_REQUIRE(N > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 4 == 0,
@@ -261,8 +324,11 @@ int stem_focus_conv_launch(const float* in, int N, int H, int W, int used_planes
   ST_REQUIRE((long long)3 * H * W * 4 < (1ll << 31), "stem_focus_conv: image exceeds 2 GiB");
   ST_REQUIRE(Cout > 0 && Cout <= 64, "stem_focus_conv: Cout must be in 1..64 (got %d)", Cout);
   ST_REQUIRE(out_off >= 0 && out_off + Cout <= out_ld, "stem_focus_conv: output slice exceeds out_ld");
-  ST_REQUIRE((reinterpret_cast<uintptr_t>(in) & 15) == 0, "stem_focus_conv: input must be 16-byte aligned");
+  ST_REQUIRE(raw || (reinterpret_cast<uintptr_t>(in) & 15) == 0, "stem_focus_conv: input must be 16-byte aligned");
   StemArgs a;
+  for (int i = 0; i < STEM_MAX_FRAMES; ++i) a.frames[i] = raw && i < N ? raw->frames[i] : nullptr;
+  a.h = raw ? raw->h : H; a.w = raw ? raw->w : W;
+  a.pad4 = raw ? 0x01010101u * (unsigned)(int)raw->pad_value : 0u;
   a.in = in; a.wgt = wgt; a.bias = bias; a.out = out;
   a.N = N; a.H = H; a.W = W; a.Ho = H / 2; a.Wo = W / 2; a.Cout = Cout; a.CoutPad = round_up(Cout, 32);
   a.out_ld = out_ld; a.out_off = out_off; a.act = act; a.planes = 3;
@@ -288,12 +354,15 @@ int stem_focus_conv_launch(const float* in, int N, int H, int W, int used_planes
 #endif
   const bool vec = ((out_ld | out_off | Cout) & 3) == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0;
   using Kern = void (*)(const StemArgs);
-  static const Kern kerns[8] = {stem_focus_conv_kernel<1, false, 3>, stem_focus_conv_kernel<1, true, 3>,
-                                stem_focus_conv_kernel<2, false, 3>, stem_focus_conv_kernel<2, true, 3>,
-                                stem_focus_conv_kernel<1, false, 1>, stem_focus_conv_kernel<1, true, 1>,
-                                stem_focus_conv_kernel<2, false, 1>, stem_focus_conv_kernel<2, true, 1>};
-  const int ki = (used_planes == 1 ? 4 : 0) + (nb - 1) * 2 + (vec ? 1 : 0);
-  static bool attr_set[8] = {false, false, false, false, false, false, false, false};
+  static const Kern kerns[12] = {
+      stem_focus_conv_kernel<1, false, 3, false>, stem_focus_conv_kernel<1, true, 3, false>,
+      stem_focus_conv_kernel<2, false, 3, false>, stem_focus_conv_kernel<2, true, 3, false>,
+      stem_focus_conv_kernel<1, false, 1, false>, stem_focus_conv_kernel<1, true, 1, false>,
+      stem_focus_conv_kernel<2, false, 1, false>, stem_focus_conv_kernel<2, true, 1, false>,
+      stem_focus_conv_kernel<1, false, 3, true>,  stem_focus_conv_kernel<1, true, 3, true>,
+      stem_focus_conv_kernel<2, false, 3, true>,  stem_focus_conv_kernel<2, true, 3, true>};
+  const int ki = (raw ? 8 : used_planes == 1 ? 4 : 0) + (nb - 1) * 2 + (vec ? 1 : 0);
+  static bool attr_set[12] = {false, false, false, false, false, false, false, false, false, false, false, false};
   if (!attr_set[ki]) {
     ST_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kerns[ki]),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -355,5 +424,14 @@ extern "C" int st_stem_focus_conv(const float* img_dev, int N, int H, int W, int
                                   const float* wgt_dev, const float* bias_dev, int Cout, float* out_dev, int out_ld,
                                   int out_off, int act, st_stream_t stream) {
   return st::stem_focus_conv_launch(img_dev, N, H, W, used_planes, wgt_dev, bias_dev, Cout, out_dev, out_ld, out_off,
-                                    act, static_cast<hipStream_t>(stream));
+                                    act, static_cast<hipStream_t>(stream), nullptr);
+}
+
+extern "C" int st_stem_focus_conv_u8(const unsigned char* const* frames_u8_dev_ptrs_host, int N, int h, int w, int H, int W,
+                                     float pad_value, const float* wgt_dev, const float* bias_dev, int Cout,
+                                     float* out_dev, int out_ld, int out_off, int act, st_stream_t stream) {
+  ST_REQUIRE(frames_u8_dev_ptrs_host != nullptr, "st_stem_focus_conv_u8: null frame table");
+  const st::StemRawInput raw{frames_u8_dev_ptrs_host, h, w, pad_value};
+  return st::stem_focus_conv_launch(nullptr, N, H, W, 3, wgt_dev, bias_dev, Cout, out_dev, out_ld, out_off, act,
+                                    static_cast<hipStream_t>(stream), &raw);
 }

@@ -21,6 +21,40 @@ def _require_cuda(t, name):
         raise RuntimeError(f'{name} must be contiguous float32')
 
 
+class RawChunk:
+    """One batch of RAW frames for the fused stem: `frames` = list of B contiguous uint8 CUDA tensors (3,h,w) or
+    (1,3,h,w) in allocations of their own, converted (cast + pad to the detector's H x W with `pad_value`) inside the
+    stem kernel's window staging (st_detector_forward_phase0_raw) - no fp32 copy of the images in HBM."""
+
+    def __init__(self, frames, pad_value):
+        self.frames, self.pad_value = list(frames), float(pad_value)
+        f0 = self.frames[0]
+        self.hw = (int(f0.shape[-2]), int(f0.shape[-1]))
+        self.device = f0.device
+        for f in self.frames:
+            if not (f.is_cuda and f.dtype == torch.uint8 and f.is_contiguous() and f.numel() == 3 * self.hw[0] * self.hw[1]
+                    and tuple(f.shape[-2:]) == self.hw):
+                raise RuntimeError('RawChunk: frames must be contiguous uint8 CUDA tensors (3,h,w) of one size')
+
+    def __len__(self):
+        return len(self.frames)
+
+    @staticmethod
+    def supported(frames, pad_value):
+        """The stem's raw form needs: width % 4 == 0, 4-byte aligned contiguous frames, an integral pad value."""
+        f0 = frames[0]
+        return (float(pad_value) == int(pad_value) and 0 <= pad_value <= 255 and f0.shape[-1] % 4 == 0 and len(frames) <= 32
+                and all(f.is_cuda and f.dtype == torch.uint8 and f.is_contiguous() and f.data_ptr() % 4 == 0 and
+                        f.shape[-3:] == f0.shape[-3:] and f.shape[-3] == 3 for f in frames))
+
+    def record_stream(self, stream):
+        for f in self.frames:
+            f.record_stream(stream)
+
+    def table(self):
+        return (C.c_void_p * len(self.frames))(*[f.data_ptr() for f in self.frames])
+
+
 class HipDetector:
     """Two-branch YOLOX detector context for a fixed (batch, H, W).
 
@@ -149,6 +183,17 @@ class HipDetector:
                                                  ws.numel(), current_stream(), ptr(head_out)),
               'st_detector_forward_phase')
         return head_out
+
+    def forward_phase0_raw(self, left, right=None):
+        """Phase 0 from RawChunk inputs (uint8 frames; cast + pad inside the stem kernel)."""
+        if len(left) != self.batch or (right is not None and len(right) != self.batch):
+            raise ValueError(f'raw chunk of {len(left)} frames for a batch-{self.batch} context')
+        if right is not None and (right.hw != left.hw or right.pad_value != left.pad_value):
+            raise ValueError('left and right raw chunks differ in size / pad value')
+        ws = self._workspace(left.device)
+        check(self.lib.st_detector_forward_phase0_raw(self.handle, left.table(), right.table() if right is not None else None,
+                                                      left.hw[0], left.hw[1], left.pad_value, ptr(ws), ws.numel(),
+                                                      current_stream()), 'st_detector_forward_phase0_raw')
 
     def tap(self, name):
         """Internal NHWC activation as a strided torch view (N,H,W,C) into the workspace."""

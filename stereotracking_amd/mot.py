@@ -172,6 +172,17 @@ class RawFrames:
                                      current_stream()), 'st_pack_raw_inputs')
         return out
 
+    def raw_chunk(self, s, e, B, runner):
+        """frames [s, e) (+ the last one repeated up to B) as an engine.RawChunk - the stem kernel casts + pads them while it
+        stages its input windows (st_detector_forward_phase0_raw), no fp32 image exists - or None when the frames do
+        not qualify (width % 4, alignment, non-integral pad value, padded size of another plan)."""
+        from .engine import RawChunk
+        fr = self.frames[s:e]
+        fr = fr + [fr[-1]] * (B - len(fr))
+        if self.pad_hw != (runner.height, runner.width) or not RawChunk.supported(fr, self.pad_value):
+            return None
+        return RawChunk(fr, self.pad_value)
+
     def dense(self):
         """The (N,1,3,H,W) fp32 tensor the preprocessor would have produced (for callers that want it)."""
         return self.chunk(0, len(self.frames), len(self.frames))[:, None]
@@ -298,6 +309,7 @@ class OCSORT_Disparity(nn.Module):
         # current one finished (the device never waits for the host's refill); the per-context staging buffers and the
         # disparity ring have queue_depth + 1 slots: one being consumed by the host + queue_depth behind it
         self.queue_depth = max(1, int(queue_depth))
+        self.raw_stem = True      # uint8 frames go to the stem kernels as they are (False: st_pack_raw_frames first)
         if results_device not in ('cpu', 'input'):
             raise ValueError("results_device must be 'cpu' or 'input'")
         self.results_device = results_device
@@ -524,7 +536,11 @@ class OCSORT_Disparity(nn.Module):
         ci = st['submitted']
         st['submitted'] += 1
         s, e = st['chunks'][ci]
-        a, b = self._padded(st['img'], s, e, B), self._padded(st['second'], s, e, B)
+        a = b = None
+        if stereo and self.raw_stem and isinstance(st['img'], RawFrames) and isinstance(st['second'], RawFrames):
+            a, b = st['img'].raw_chunk(s, e, B, runner), st['second'].raw_chunk(s, e, B, runner)
+        if a is None or b is None:      # fp32 tensors (or frames the stem cannot read raw): cast + pad as a pass of its own
+            a, b = self._padded(st['img'], s, e, B), self._padded(st['second'], s, e, B)
         holder = {}
         # staging buffers of a context alternate: it is resubmitted before the chunk it just finished is consumed
         turns = self._staging.setdefault(('ctx_turns', id(runner)), [0] * len(runner))

@@ -15,7 +15,7 @@ import torch
 
 from . import _lib
 from ._lib import check, current_stream, ptr
-from .engine import HipDetector, _require_cuda
+from .engine import HipDetector, RawChunk, _require_cuda
 from .stereo import StereoCostVolume
 
 
@@ -227,12 +227,17 @@ class StereoDensePipeline:
         return depth, scales, sboxes
 
     def run(self, img, right=None, disp_postp=None):
-        """img (N,3,H,W) fp32 CUDA; stereo: right (N,3,H,W); mono: disp_postp (N,3,H,W).
+        """img (N,3,H,W) fp32 CUDA; stereo: right (N,3,H,W); mono: disp_postp (N,3,H,W).  Stereo also takes img and
+        right as two engine.RawChunk (N uint8 frames each): the stem kernels cast + pad them while staging their windows.
         Returns a dict of device tensors (no host sync; the context's PERSISTENT buffers, overwritten by its next run): boxes (N,M,4) unscaled xyxy, scores, labels,
         prior_idx, counts (TRUE number kept per frame), overflow (N,) bool = counts > M, depth, scales,
         scaled_boxes, disp_postp, head.  Rows past min(counts, M) are zero (prior_idx -1).  With disp_buffers > 1 the
         stereo module's disp_postp is buffer `self.disp_slot` of the ring (see _buffers)."""
-        _require_cuda(img, 'img')
+        if isinstance(img, RawChunk):
+            if not (self.stereo and isinstance(right, RawChunk)):
+                raise ValueError('raw uint8 chunks feed the stereo pipeline (left and right)')
+        else:
+            _require_cuda(img, 'img')
         b = self._buffers(img.device)
         if self.stereo:
             if right is None:
@@ -312,7 +317,8 @@ class InflightPipelines:
     def submit(self, img, right=None, disp_postp=None, post=None):
         """Enqueue one batch on the next context's stream (after everything already enqueued on the caller's
         current stream, where the inputs were produced).  `post(out)` runs under that stream too."""
-        _require_cuda(img, 'img')
+        if not isinstance(img, RawChunk):
+            _require_cuda(img, 'img')
         if self.streams is None:
             self.streams = [torch.cuda.Stream(device=img.device) for _ in self.pipes]
         j = self._next % len(self.pipes)

@@ -25,6 +25,7 @@ from torch import nn
 
 from . import _lib
 from ._lib import StConvDesc, check, current_stream, ptr
+from .engine import RawChunk
 from .registry import MODELS
 
 
@@ -177,7 +178,7 @@ class StereoCostVolume(nn.Module):
 
     # ---- compute ------------------------------------------------------------------------------------------
     def compute(self, engine, img, right, valid_hw, disp_lr=None, disp_postp=None, cost_out=None):
-        """engine: a HipDetector built with stereo=True.  img/right: (N,3,H,W) fp32 CUDA.
+        """engine: a HipDetector built with stereo=True.  img/right: (N,3,H,W) fp32 CUDA, or two RawChunk (uint8 frames).
         Runs phase 0 (features of left+right) then cost volume (+ aggregation) + soft-argmin + upsample.
         Returns disp_postp (N,3,H,W); phase-0 activations stay in the engine workspace for phase 1."""
         if not engine.stereo:
@@ -186,7 +187,10 @@ class StereoCostVolume(nn.Module):
         s = self.feat_stride
         dev = img.device
         D = self.levels
-        engine.forward_phase(0, img=img, right=right)
+        if isinstance(img, RawChunk):      # uint8 frames: the stem converts + pads them itself
+            engine.forward_phase0_raw(img, right)
+        else:
+            engine.forward_phase(0, img=img, right=right)
         feat = engine.tap('stage1_rgb')  # (2N, H/4, W/4, C): [left | right]
         Hf, Wf, Cf, ld = feat.shape[1], feat.shape[2], feat.shape[3], feat.stride(2)
         fl = feat.data_ptr()

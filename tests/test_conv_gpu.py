@@ -299,6 +299,45 @@ def test_fused_focus_stem_matches_torch(N, H, W, cout, act, planes, cuda):
     assert torch.all(got[..., :off] == -777.0) and torch.all(got[..., off + cout:] == -777.0)
 
 
+@pytest.mark.parametrize('N,h,w,H,W,cout,pad', [
+    (2, 50, 72, 64, 96, 32, 114.0),      # padded bottom + right, ragged tiles
+    (3, 64, 96, 64, 96, 24, 0.0),        # no padding, Cout < 32
+    (8, 720, 1280, 736, 1280, 32, 114.0),   # the bench / AirDrone geometry
+    (33, 30, 132, 32, 160, 64, 7.0),     # first 32 frames only are legal: see below
+])
+def test_fused_stem_raw_uint8_frames_equal_pack_then_stem(N, h, w, H, W, cout, pad, cuda):
+    """st_stem_focus_conv_u8 (uint8 frames in allocations of their own; cast + pad inside the window staging) ==
+    st_pack_raw_frames (data_preprocessor_disparity_v1.py:38-51: cast, pad to H x W with pad_value) followed by
+    st_stem_focus_conv, bit for bit; more than 32 frames per launch is refused."""
+    import ctypes as C
+    lib = _lib.load()
+    torch.manual_seed(3)
+    frames = [torch.randint(0, 256, (3, h, w), dtype=torch.uint8).to(cuda) for _ in range(N)]
+    wgt = torch.randn(cout, 12, 3, 3) / 200.0
+    gamma, beta, mean, var = torch.rand(cout) + 0.5, torch.randn(cout) * 0.2, torch.randn(cout) * 0.5, torch.rand(cout) + 0.5
+    wp = torch.empty(lib.st_stem_packed_floats(cout), dtype=torch.float32)
+    bp = torch.empty((cout + 31) // 32 * 32, dtype=torch.float32)
+    check(lib.st_stem_pack_weights(ptr(wgt), None, ptr(gamma), ptr(beta), ptr(mean), ptr(var), 1e-3, cout, 3, ptr(wp), ptr(bp)))
+    wd, bd = wp.to(cuda), bp.to(cuda)
+    table = (C.c_void_p * N)(*[f.data_ptr() for f in frames])
+    if N > 32:
+        got = torch.zeros(N, H // 2, W // 2, cout, device=cuda)
+        assert lib.st_stem_focus_conv_u8(table, N, h, w, H, W, pad, ptr(wd), ptr(bd), cout, ptr(got), cout, 0, 1, None) != 0
+        N = 32
+    x = torch.empty(N, 3, H, W, device=cuda)
+    check(lib.st_pack_raw_frames(table, N, h, w, H, W, pad, ptr(x), None))
+    ref = torch.full((N, H // 2, W // 2, cout), -7.0, device=cuda)
+    got = torch.full((N, H // 2, W // 2, cout), -7.0, device=cuda)
+    check(lib.st_stem_focus_conv(ptr(x), N, H, W, 3, ptr(wd), ptr(bd), cout, ptr(ref), cout, 0, 1, None))
+    check(lib.st_stem_focus_conv_u8(table, N, h, w, H, W, pad, ptr(wd), ptr(bd), cout, ptr(got), cout, 0, 1, None))
+    torch.cuda.synchronize()
+    assert torch.equal(got, ref)
+    assert float(ref.abs().max()) > 0.1 and not bool((ref == -7.0).any())
+    # refused: non-integral pad value, width not a multiple of 4 (callers fall back to the pack pass)
+    assert lib.st_stem_focus_conv_u8(table, N, h, w, H, W, 113.5, ptr(wd), ptr(bd), cout, ptr(got), cout, 0, 1, None) != 0
+    assert lib.st_stem_focus_conv_u8(table, N, h, w - 2, H, W, pad, ptr(wd), ptr(bd), cout, ptr(got), cout, 0, 1, None) != 0
+
+
 def test_fused_stem_rejects_bad_arguments(cuda):
     lib = _lib.load()
     x = torch.zeros(1, 3, 32, 32, device=cuda)

@@ -259,7 +259,8 @@ def test_frames_without_detections_and_ragged_calls(cuda):
 def test_primed_loop_equals_per_call_test_step(frames_per_call, inflight, queue_depth, cuda):
     """model.test_steps(iterable) - contexts kept primed across calls: call k+1's first chunks are submitted while call
     k drains - returns, call by call, exactly what model.test_step returns for the same calls (boxes, scores, ids,
-    track depth: bit-equal), over a 2-video stream whose calls are ragged against the dense batch."""
+    track depth: bit-equal), over a 2-video stream whose calls are ragged against the dense batch.  The two runs also
+    differ in how the uint8 frames reach the stems (a cast + pad pass vs the stem's own raw staging): same bits."""
     from stereotracking_amd.structures import TrackDataSample
     model, _, _ = build_model(CFG_STEREO, cuda, autotune=False)
     model.dense_batch, model.inflight, model.queue_depth = 4, inflight, queue_depth
@@ -277,9 +278,11 @@ def test_primed_loop_equals_per_call_test_step(frames_per_call, inflight, queue_
                        for t in range(lo, hi)]
             yield dict(inputs=dict(img=left[lo:hi], right=right[lo:hi]), data_samples=samples)
 
+    model.raw_stem = False       # per-call test_step through st_pack_raw_frames (cast + pad as a pass of its own) ...
     ref = [model.test_step(d) for d in calls()]
     torch.cuda.synchronize()
     model.tracker.reset()
+    model.raw_stem = True        # ... against the primed loop with the uint8 frames read by the stem kernels directly
     got = list(model.test_steps(calls()))
     torch.cuda.synchronize()
     assert [len(c) for c in got] == [len(c) for c in ref]

@@ -1,5 +1,7 @@
 #!/usr/bin/env python
-"""Micro-benchmark of the fused Focus+stem kernel on the bench geometry (8 x 3 x 736 x 1280 -> 32 ch)."""
+"""Fused stem at the bench geometry (8 x 720 x 1280 uint8 frames -> 736 x 1280 -> 32 ch @ 368 x 640):
+fp32 input via LDS-DMA (+ the st_pack_raw_frames pass that produces it) vs the raw uint8 staging."""
+import ctypes as C
 import os
 import sys
 
@@ -9,27 +11,35 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from stereotracking_amd import _lib  # noqa: E402
 from stereotracking_amd._lib import check, ptr  # noqa: E402
 
-lib = _lib.load()
-N, H, W, C = 8, 736, 1280, 32
-dev = torch.device('cuda:0')
-x = torch.rand(N, 3, H, W, device=dev) * 255
-w = torch.randn(C, 12, 3, 3) / 200
-wp = torch.empty(lib.st_stem_packed_floats(C))
-bp = torch.empty(32)
-planes = int(sys.argv[2]) if len(sys.argv) > 2 else 3
-check(lib.st_stem_pack_weights(ptr(w), None, None, None, None, None, 0.0, C, planes, ptr(wp), ptr(bp)))
-wd, bd = wp.to(dev), bp.to(dev)
-out = torch.empty(N, H // 2, W // 2, C, device=dev)
-reps = int(sys.argv[1]) if len(sys.argv) > 1 else 20
-for _ in range(3):
-    check(lib.st_stem_focus_conv(ptr(x), N, H, W, planes, ptr(wd), ptr(bd), C, ptr(out), C, 0, 1, None))
-torch.cuda.synchronize()
-e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-e0.record()
-for _ in range(reps):
-    check(lib.st_stem_focus_conv(ptr(x), N, H, W, planes, ptr(wd), ptr(bd), C, ptr(out), C, 0, 1, None))
-e1.record()
-torch.cuda.synchronize()
-us = e0.elapsed_time(e1) / reps * 1e3
-gf = 2.0 * N * (H // 2) * (W // 2) * 36 * planes * C / 1e9
-print(f'stem_focus_conv: {us:.1f} us  {gf / us * 1e-3:.1f} TF/s  ({gf:.2f} GFLOP)')
+
+def timeit(fn, n=50):
+    for _ in range(5):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n * 1e3
+
+
+def main():
+    lib = _lib.load()
+    dev = torch.device('cuda', 0)
+    N, h, w, H, W, cout = 8, 720, 1280, 736, 1280, 32
+    frames = [torch.randint(0, 256, (3, h, w), dtype=torch.uint8, device=dev) for _ in range(N)]
+    table = (C.c_void_p * N)(*[f.data_ptr() for f in frames])
+    wp = torch.randn(lib.st_stem_packed_floats(cout), device=dev) / 100
+    bp = torch.zeros(32, device=dev)
+    x = torch.empty(N, 3, H, W, device=dev)
+    out = torch.empty(N, H // 2, W // 2, cout, device=dev)
+    t_pack = timeit(lambda: check(lib.st_pack_raw_frames(table, N, h, w, H, W, 114.0, ptr(x), None)))
+    t_f32 = timeit(lambda: check(lib.st_stem_focus_conv(ptr(x), N, H, W, 3, ptr(wp), ptr(bp), cout, ptr(out), cout, 0, 1, None)))
+    t_u8 = timeit(lambda: check(lib.st_stem_focus_conv_u8(table, N, h, w, H, W, 114.0, ptr(wp), ptr(bp), cout, ptr(out), cout, 0, 1, None)))
+    print(f'pack {t_pack:.1f} us   stem(fp32, LDS-DMA) {t_f32:.1f} us   stem(uint8 frames) {t_u8:.1f} us')
+
+
+if __name__ == '__main__':
+    main()
