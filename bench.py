@@ -688,6 +688,7 @@ def main():
             del runner   # its three workspaces are not needed any more
             line['test_step'] = test_step_leg(args, sd, batch_cpu, dev, B * args.steps)
             line['test_step']['vs_pipeline'] = round(line['test_step']['value'] / line['value'], 4)
+            line['test_step']['primed_loop']['vs_pipeline'] = round(line['test_step']['primed_loop']['value'] / line['value'], 4)
             if line['test_step'].get('long_call'):
                 line['test_step']['long_call']['vs_pipeline'] = round(line['test_step']['long_call']['value'] / line['value'], 4)
         line['tracker_cpu'] = tracker_cost()

@@ -44,7 +44,14 @@ def run(name, N, H, W, Cin, Cout, k=1, stride=1, res=False, up=False, split=None
         rc = lib.st_conv2d_nhwc_variant(C.byref(d), _lib.current_stream(), v)
         torch.cuda.synchronize()
         return (out, upb) if rc == 0 else None
-    ref = conv(3 if Cout % 64 == 0 else 0)
+    ref = None
+    for v_ref in (3, 0) + tuple(range(1, 22)):      # the first exact-fp32 implicit-GEMM tile that accepts this Cout
+        ref = conv(v_ref)
+        if ref is not None:
+            break
+    if ref is None:
+        print(f'{name:36s} no exact-fp32 reference instance for Cout={Cout}', flush=True)
+        return
     scale = ref[0].abs().max().item()
     for v in (50, 51, 52, 53, 54, 55):
         worst, nondet = 0.0, False
