@@ -634,12 +634,23 @@ def main():
     sustained = None
     if args.sustain_seconds > 0:     # a longer region for the eye of a GPU-busy sampler; `value` stays the K-step figure
         n_s, t1 = 0, time.perf_counter()
-        while time.perf_counter() - t1 < args.sustain_seconds:
+        while True:
             for _ in range(args.steps):
                 out = step()
             n_s += args.steps
             torch.cuda.synchronize()
+            go_on = time.perf_counter() - t1 < args.sustain_seconds
+            if world > 1:   # every step carries a collective: the ranks must agree on how many more rounds they run
+                flag = torch.tensor([1 if go_on else 0], device=cdev, dtype=torch.int32)
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                go_on = bool(flag.item())
+            if not go_on:
+                break
         dts = time.perf_counter() - t1
+        if world > 1:
+            t = torch.tensor([dts], device=cdev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dts = float(t.item())
         sustained = dict(seconds=round(dts, 3), steps=n_s, value=round(world * B * n_s / dts, 3))
 
     counts = out['counts'].cpu().tolist()

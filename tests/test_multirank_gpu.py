@@ -67,7 +67,7 @@ def test_bench_multirank_path_world2(cuda):
     collective rehearsed over gloo: the barrier / max-over-ranks timing, the per-step all-gather of the frame records
     from the context streams and the record-vs-local-count check all run; rank 0 prints ONE JSON line."""
     outs = _json_lines(_launch(2, [os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '4', '--warmup', '2',
-                                   '--no-cpu-baseline', '--no-test-step', '--sustain-seconds', '0'],
+                                   '--no-cpu-baseline', '--no-test-step', '--sustain-seconds', '0.4'],
                                dict(ST_BENCH_BACKEND='gloo')))
     assert len(outs) == 1
     line = outs[0]
