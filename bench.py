@@ -21,6 +21,7 @@ import time
 
 os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')   # one hardware queue per in-flight context (stereotracking_amd/__init__.py)
 os.environ.setdefault('HIP_FORCE_DEV_KERNARG', '1')   # kernel arguments in device memory (same file)
+os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')   # RCCL across processes needs dmabuf IPC on this driver stack
 
 import torch  # noqa: E402
 

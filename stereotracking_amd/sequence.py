@@ -142,8 +142,15 @@ class RawFrameUploader:
     own, ordered against the pack kernels by events, so the upload of batch i+1 overlaps the dense work of batch i
     and the host never waits for the device unless it is two batches ahead."""
 
-    def __init__(self, batch, ori_hw, device, use_right=True, slots=2):
+    def __init__(self, batch, ori_hw, device, use_right=True, slots=2, raw_stem=None):
         self.B, (self.h, self.w) = int(batch), (int(ori_hw[0]), int(ori_hw[1]))
+        # raw_stem (stereo only; default on when the geometry allows): the uploaded uint8 frames are handed to the
+        # pipeline as engine.RawChunk pairs - the stem kernels cast + pad them while staging their windows, no pack
+        # pass and no fp32 image in HBM.  Each batch then gets device byte buffers of its own (the stems read them
+        # later, on a context's stream), the page-locked staging slots still alternate.
+        self.raw_stem = bool(use_right and self.w % 4 == 0 and int(batch) <= 32) if raw_stem is None else bool(raw_stem)
+        if self.raw_stem and not (use_right and self.w % 4 == 0 and int(batch) <= 32):
+            raise ValueError('raw_stem needs the stereo form, width % 4 == 0 and batch <= 32')
         self.H, self.W = (self.h + 31) // 32 * 32, (self.w + 31) // 32 * 32
         self.dev, self.use_right = torch.device(device), bool(use_right)
         self.copy_stream = torch.cuda.Stream(device=self.dev)
@@ -188,7 +195,7 @@ class RawFrameUploader:
 
     def upload(self, frames):
         """frames: list of <= B frame dicts, or (HostSequence, start, stop).  -> dict(img[, right | disp_postp]) fp32
-        (B,3,H,W) device tensors, produced on the CURRENT stream (a fresh allocation per batch: safe to hand to an
+        (B,3,H,W) device tensors (raw_stem: two engine.RawChunk of uint8 frames), produced on the CURRENT stream (a fresh allocation per batch: safe to hand to an
         in-flight context)."""
         from ._lib import check, current_stream, load, ptr
         sl = self.slots[self._k % len(self.slots)]
@@ -213,6 +220,21 @@ class RawFrameUploader:
                 sl['uploaded'].synchronize()      # the H2D copy that last read this staging slot has finished
             srcs = self._stage(sl, list(frames))
         cur = torch.cuda.current_stream(self.dev)
+        if self.raw_stem:
+            from .engine import RawChunk
+            dev_bytes = {}
+            for src, name in zip(srcs, ('left', 'right')):
+                dev_bytes[name] = torch.empty((self.B, 3, self.h, self.w), dtype=torch.uint8, device=self.dev)
+                dev_bytes[name].record_stream(self.copy_stream)
+            self.copy_stream.wait_stream(cur)     # a recycled block's last reader was enqueued before this point
+            with torch.cuda.stream(self.copy_stream):
+                for src, name in zip(srcs, ('left', 'right')):
+                    dev_bytes[name].copy_(src, non_blocking=True)
+                    self.bytes_uploaded += src.numel() * src.element_size()
+                sl['uploaded'].record(self.copy_stream)
+            cur.wait_event(sl['uploaded'])
+            sl['used'] = True
+            return dict(img=RawChunk(list(dev_bytes['left']), 114.0), right=RawChunk(list(dev_bytes['right']), 114.0))
         with torch.cuda.stream(self.copy_stream):
             if sl['used']:
                 self.copy_stream.wait_event(sl['consumed'])   # the pack kernel that last read the device bytes is done

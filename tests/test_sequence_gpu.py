@@ -140,7 +140,7 @@ def test_config2_full_size_64_frame_sequence(cuda):
     two-branch detector + 2 aggregation convs, detector + disparity feeding the (CPU) association, on one GPU.
     Batched execution (8 frames per launch plan on 3 in-flight contexts) gives bit-identical detections and the same
     track ids / boxes as the strictly sequential frame-by-frame run (batch 1, one context); the measured rates go
-    into gpurun_out/r03_config2.json (copied to profiles/)."""
+    into gpurun_out/r04_config2.json (copied to profiles/)."""
     import json
     import os
     import time
@@ -172,6 +172,14 @@ def test_config2_full_size_64_frame_sequence(cuda):
     t_res = time.perf_counter() - t0
     bytes_per_frame = (up.bytes_uploaded - bytes0) // T
     assert torch.equal(dr.nan_to_num(-7.0), db.nan_to_num(-7.0)) and torch.equal(cr, cb)
+    # the uploader hands the uint8 frames to the stem kernels as they are (raw_stem, the default for stereo); through a
+    # cast + pad pass of its own (st_pack_raw_inputs -> fp32 images -> LDS-DMA stems) the records are the same bits
+    assert up.raw_stem
+    up_pack = RawFrameUploader(8, (H, W), cuda, use_right=True, raw_stem=False)
+    dp, cp = detect_shard(runner, resident, cuda, uploader=up_pack)
+    torch.cuda.synchronize()
+    assert torch.equal(dp.nan_to_num(-7.0), dr.nan_to_num(-7.0)) and torch.equal(cp, cr)
+    del up_pack
     t0 = time.perf_counter()
     rb = track_gathered(db, cb, T, OCSORTTracker_Disparity(**cfg), _Model())
     t_track = time.perf_counter() - t0
@@ -209,8 +217,8 @@ def test_config2_full_size_64_frame_sequence(cuda):
                dense_frames_per_s_tuned_plan_from_host_numpy=round(T / t_tuned_list, 1),
                frames=T, dense_seconds=round(t_dense, 4), dense_frames_per_s=round(T / t_dense, 1),
                plan_of_the_parity_part='heuristic (autotune=False)',
-               includes='host numpy frames -> 2 pinned staging slots -> uint8 H2D on a copy stream -> st_pack_raw_inputs -> dense '
-                        'path, 8 frames per plan on 3 contexts',
+               includes='host numpy frames -> 2 pinned staging slots -> uint8 H2D on a copy stream -> stem kernels read the uint8 frames '
+                        '(cast + pad while staging) -> dense path, 8 frames per plan on 3 contexts',
                dense_frames_per_s_from_pinned_u8=round(T / t_res, 1),
                includes_pinned='the same from a HostSequence (uint8 frames resident in page-locked memory: no staging copy)',
                uploaded_bytes_per_frame=int(bytes_per_frame),   # 2 x 3 x 720 x 1280 uint8 (fp32 frames: 22.1 MB)
@@ -218,7 +226,7 @@ def test_config2_full_size_64_frame_sequence(cuda):
                tracks_returned=n_trk, detections_per_frame_mean=round(float(c1.float().mean()), 1),
                end_to_end_frames_per_s=round(T / (t_dense + t_track), 1))
     os.makedirs('gpurun_out', exist_ok=True)
-    json.dump(rec, open('gpurun_out/r03_config2.json', 'w'), indent=1)
+    json.dump(rec, open('gpurun_out/r04_config2.json', 'w'), indent=1)
     print(rec)
 
 
