@@ -1,0 +1,75 @@
+"""Yardstick, not parity: the way the REFERENCE would run this path on the same MI355X - its module graph in eager
+PyTorch (conv2d -> MIOpen, BatchNorm, SiLU, cat, add as separate launches; `oracle/torch_model.py` is that graph) -
+timed on the GPU next to the HIP path on the bench workload.  The eager figure covers LESS work (detector forward of
+both branches + the right image's stem/stage-1 features; no cost volume, aggregation, soft-argmin, decode, NMS, box
+depth), so the ratio is a lower bound.  Written to gpurun_out/r04_eager_yardstick.json (copied to profiles/)."""
+import json
+import os
+import time
+
+import pytest
+import torch
+
+from oracle.torch_model import OracleDetector
+from stereotracking_amd.pipeline import InflightPipelines
+from stereotracking_amd.synthetic import synthetic_batch, synthetic_state_dict
+
+pytestmark = pytest.mark.gpu
+
+
+def test_eager_pytorch_detector_vs_hip_path(cuda):
+    B, H, W, D = 8, 720, 1280, 192
+    runner = InflightPipelines(4, B, (H, W), 0.5, 0.33, 1, stereo=True, max_disp=D, max_det=1000, agg_layers=2)
+    sd = synthetic_state_dict(runner.param_table(), seed=0)
+    runner.load_state_dict(sd)
+    batch = synthetic_batch(list(range(B)), H, W, D)
+    img, right = batch['img'].to(cuda), batch['right'].to(cuda)
+    for _ in range(8):
+        out, _ = runner.submit(img, right)
+    runner.synchronize()
+    steps = 40
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        out, _ = runner.submit(img, right)
+    runner.synchronize()
+    hip_ms = (time.perf_counter() - t0) / steps * 1e3
+    disp = out['disp_postp'].clone()
+    del runner
+    torch.cuda.empty_cache()
+
+    ora = OracleDetector(0.33, 0.5, 1).eval()
+    ora.load_state_dict(sd, strict=False)
+    ora = ora.to(cuda)
+    torch.backends.cudnn.benchmark = True
+    res = {}
+    for fmt in ('nchw', 'channels_last'):
+        m = ora.to(memory_format=torch.channels_last) if fmt == 'channels_last' else ora
+        cv = (lambda t: t.contiguous(memory_format=torch.channels_last)) if fmt == 'channels_last' else (lambda t: t)
+        a, b, r = cv(img), cv(disp), cv(right)
+        with torch.no_grad():
+            for _ in range(3):
+                m(dict(img=a, disp_postp=b))
+                m.backbone.stage1_features(r)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            n = 10
+            for _ in range(n):
+                m(dict(img=a, disp_postp=b))
+                m.backbone.stage1_features(r)
+            torch.cuda.synchronize()
+        res[fmt] = (time.perf_counter() - t0) / n * 1e3
+    best = min(res.values())
+    rec = dict(workload='bench.py configs[1]: 8 stereo pairs 1280x720 per step, fp32',
+               hip_path_ms_per_step=round(hip_ms, 3), hip_path_pairs_per_s=round(B / hip_ms * 1e3, 1),
+               hip_path_covers='stems + stage 1 of left and right, cost volume, 2 aggregation convs, soft-argmin, upsample, '
+                               'two-branch backbone, PAFPN, head, decode + NMS, per-box depth (4 contexts in flight)',
+               eager_pytorch_ms_per_step={k: round(v, 3) for k, v in res.items()},
+               eager_pytorch_pairs_per_s=round(B / best * 1e3, 1),
+               eager_covers='the reference module graph in eager PyTorch on the same GPU (MIOpen conv2d, BatchNorm, SiLU, '
+                            'cat, add as separate launches): detector forward of both branches + stem / stage-1 features '
+                            'of the right image ONLY - no cost volume, aggregation, soft-argmin, decode, NMS, box depth',
+               ratio_lower_bound=round(best / hip_ms, 2))
+    os.makedirs('gpurun_out', exist_ok=True)
+    json.dump(rec, open('gpurun_out/r04_eager_yardstick.json', 'w'), indent=1)
+    print(rec)
+    assert hip_ms < best, 'the HIP path (which does more work) must not be slower than the eager module graph'
