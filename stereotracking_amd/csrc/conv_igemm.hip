@@ -169,8 +169,6 @@ __device__ __forceinline__ void conv_epilogue(const ConvKArgs& p, f32x16 (&acc)[
 // NBUF = 1: single-wave blocks (WM = WN = 1) only - the wave's own in-order LDS queue orders the
 //           write of chunk k+1 behind the reads of chunk k, so there is no cross-wave barrier at all and
 //           half the LDS (2 such waves per SIMD fit in 160 KiB).
-// ABL != 0: timing-only ablation builds (wrong results): 1 = no global loads / LDS stores after the first
-// chunk, 2 = additionally no barrier.
 // DMA = 1: tiles go global -> LDS directly (`buffer_load_dwordx4 ... lds`, 1 KiB per wave-instruction):
 //          no staging VGPRs, no ds_write, no address math between load and store.  The LDS image must be
 //          lane-linear (8 rows x 128 B per instruction, unpadded), so bank conflicts are removed by an XOR
@@ -182,7 +180,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvKArgs& p, f32x16 (&acc)[
 //         the staging loads is one add.  The general set-up is ~300 vector instructions per lane and the general
 //         update ~20 per chunk; on the fp32 matrix path VALU time adds to MFMA time (tools/micro/mfma_peak.hip), and a
 //         K = 128 layer has only 64 MFMAs per wave to hide them behind.
-template <int TM, int TN, int WM, int WN, int NBUF, int ABL = 0, int ILV = 1, int DMA = 0, int PW = 0>
+template <int TM, int TN, int WM, int WN, int NBUF, int ILV = 1, int DMA = 0, int PW = 0>
 __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(ConvKArgs p) {
   static_assert(NBUF == 2 || (WM == 1 && WN == 1), "single LDS buffer needs a single-wave block");
   static_assert(!DMA || (NBUF == 2 && 64 * WM * WN >= 128), "LDS-DMA variant: double buffer, >= 2 waves");
@@ -276,10 +274,9 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(ConvKArgs p) {
   };
   auto load_b = [&](int b, int kc) {
     breg[b] = __builtin_bit_cast(
-        f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrcB, woff[b], (ABL == 6 ? 0 : kc) * (BK * 4), 0));
+        f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrcB, woff[b], kc * (BK * 4), 0));
   };
   auto advance = [&]() {  // move this lane's (kh, kw, c) to the next K-chunk
-    if (ABL == 6) return;
     kc_k += BK;
     if (PW) {   // k = channel: the lane's group moves 32 channels on
       kc_off += BK * 4;
@@ -378,9 +375,9 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(ConvKArgs p) {
     constexpr bool MORE = decltype(more_tag)::value;
     const int buf = NBUF == 2 ? (kc & 1) : 0;
     const int nbuf = NBUF == 2 ? (buf ^ 1) : 0;
-    constexpr bool more = (ABL == 0 || ABL >= 4) && MORE;  // ABL 6: cache-hot re-loads
+    constexpr bool more = MORE;
     const bool vk = kc_k < p.K;  // the lane state already describes chunk kc + 1
-    if (!DMA && !ILV && more && ABL != 5) load_chunk(kc + 1);
+    if (!DMA && !ILV && more) load_chunk(kc + 1);
     if (DMA && !ILV && more) dma_chunk(kc + 1, nbuf);
 
     const float* Ab = As + buf * BM * LDK + (wm * 32 * TM + l31) * LDK + (DMA ? 0 : 4 * lh);
@@ -444,17 +441,10 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(ConvKArgs p) {
 
     if (!DMA && (!ILV || NBUF != 2) && more) {
       if (ILV) load_chunk(kc + 1);  // single-buffer blocks: stage after the reads of this chunk
-      if (ABL != 4) {
-        store_chunk(nbuf);
-      } else {
-#pragma unroll
-        for (int a_ = 0; a_ < AP; ++a_) asm volatile("" ::"v"(areg[a_]));
-#pragma unroll
-        for (int b_ = 0; b_ < BP; ++b_) asm volatile("" ::"v"(breg[b_]));
-      }
+      store_chunk(nbuf);
     }
     if (DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMA of chunk kc + 1 has landed
-    if (ABL < 2) __syncthreads();
+    __syncthreads();
   };
   for (int kc = 0; kc + 1 < nchunks; ++kc) do_chunk(kc, std::true_type{});
   do_chunk(nchunks - 1, std::false_type{});
@@ -730,187 +720,16 @@ static int launch_split(const ConvKArgs& a, int m_tiles, hipStream_t stream) {
   return ST_OK;
 }
 
-#ifdef ST_ABLATION   // measured-negative experiment: tools-only build, not in the product library
-// ---- wave-specialised variant ---------------------------------------------------------------------------
-// WM*WN MFMA waves + ONE loader wave per block.  The ablations (tools/conv_ablation.py) show that what the
-// staged kernel loses against its no-load build is the ISSUE cost of the staging instructions inside the
-// MFMA waves' in-order streams, not memory latency or bandwidth.  Here the MFMA waves run nothing but
-// ds_read_b128 + v_mfma (+ one barrier per K-chunk); the loader wave computes all im2col addresses and
-// issues every `buffer_load_dwordx4 ... lds` (LDS-DMA, source-side XOR swizzle as in DMA = 1) for the next
-// chunk, waits for them (vmcnt(0)) and joins the same barrier.
-template <int TM, int TN, int WM, int WN, int NL>
-__global__ __launch_bounds__(64 * (WM * WN + NL)) void conv_igemm_ws_kernel(ConvKArgs p) {
-  constexpr int NW = WM * WN;  // MFMA waves (+ NL loader waves: loader l issues the DMA instructions j = l mod NL)
-  constexpr int BM = 32 * TM * WM;
-  constexpr int BN = 32 * TN * WN;
-  constexpr int LDK = 32;
-  constexpr int AI = BM / 8, BI = BN / 8;  // DMA wave-instructions per chunk (8 rows x 128 B each)
-
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* As = smem;                 // [2][BM][32]
-  float* Bs = smem + 2 * BM * LDK;  // [2][BN][32]
-
-  const int nblk = gridDim.x, bid = blockIdx.x;
-  const int q8 = nblk >> 3, r8 = nblk & 7, xcd = bid & 7, slot = bid >> 3;
-  const int logical = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + slot;
-  const int mt = logical / p.n_tiles;
-  const int nt = logical - mt * p.n_tiles;
-  const int m0 = mt * BM, n0 = nt * BN;
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63, wave = tid >> 6;
-  const int nchunks = p.Kpad / BK;
-
-  if (wave >= NW) {
-    // =============================== loader waves ===============================
-    const int lw = wave - NW;
-    const int a8 = lane >> 3, q = lane & 7;
-    const __amdgpu_buffer_rsrc_t rsrcA =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in), 0, p.in_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsrcB =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.wgt), 0, p.wgt_bytes, 0x00020000);
-    int rowoff[AI];
-    unsigned vmask[AI];
-#pragma unroll
-    for (int j = 0; j < AI; ++j) {
-      const int m = m0 + 8 * j + a8;
-      const bool vm = m < p.M;
-      const int mm = vm ? m : 0;
-      const int n = mm / p.HoWo;
-      const int rem = mm - n * p.HoWo;
-      const int oy = rem / p.Wo;
-      const int ox = rem - oy * p.Wo;
-      const int iy0 = oy * p.stride - p.pad, ix0 = ox * p.stride - p.pad;
-      rowoff[j] = (((n * p.Hi + iy0) * p.Wi + ix0) * p.in_ld + p.in_off) * 4;
-      unsigned msk = 0;
-      for (int kh = 0; kh < p.KH; ++kh)
-        for (int kw = 0; kw < p.KW; ++kw)
-          if (vm && (unsigned)(iy0 + kh) < (unsigned)p.Hi && (unsigned)(ix0 + kw) < (unsigned)p.Wi)
-            msk |= 1u << (kh * p.KW + kw);
-      vmask[j] = msk;
-    }
-    // swizzle: row r = 8j + a8 stores k-group g in slot g ^ ((r >> 1) & 7) = g ^ ((4j + (a8 >> 1)) & 7): the lane
-    // fetches k-group kq[j & 1]; two running (tap, c, offset) states, one per parity of j
-    int st_c[2], st_kh[2], st_kw[2], st_k[2], st_tap[2], st_off[2];
-    unsigned woff[2];
-#pragma unroll
-    for (int e = 0; e < 2; ++e) {
-      const int kq = q ^ ((4 * e + (a8 >> 1)) & 7);
-      st_c[e] = kq * 4; st_kh[e] = 0; st_kw[e] = 0; st_k[e] = kq * 4;
-      while (st_c[e] >= p.Cin) {
-        st_c[e] -= p.Cin;
-        if (++st_kw[e] == p.KW) { st_kw[e] = 0; ++st_kh[e]; }
-      }
-      st_tap[e] = st_kh[e] * p.KW + st_kw[e];
-      st_off[e] = ((st_kh[e] * p.Wi + st_kw[e]) * p.in_ld + st_c[e]) * 4;
-      woff[e] = ((unsigned)(n0 + a8) * (unsigned)p.Kpad + kq * 4) * 4u;  // + 8 j rows, added per instruction
-    }
-    auto dma_chunk = [&](int kc, int buf) {
-#if defined(__HIP_DEVICE_COMPILE__)
-#pragma unroll
-      for (int j = 0; j < AI; ++j) {
-        if (j % NL != lw) continue;  // wave-uniform
-        const int e = j & 1;
-        const bool v = (st_k[e] < p.K) && ((vmask[j] >> st_tap[e]) & 1u);
-        const unsigned off = v ? (unsigned)(rowoff[j] + st_off[e]) : 0x80000000u;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(
-            rsrcA, (__attribute__((address_space(3))) void*)(As + buf * BM * LDK + 8 * j * LDK), 16, off, 0, 0, 0);
-      }
-#pragma unroll
-      for (int j = 0; j < BI; ++j) {
-        if (j % NL != lw) continue;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(
-            rsrcB, (__attribute__((address_space(3))) void*)(Bs + buf * BN * LDK + 8 * j * LDK), 16,
-            woff[j & 1] + (unsigned)(8 * j) * (unsigned)p.Kpad * 4u, kc * (BK * 4), 0, 0);
-      }
-#else
-      (void)kc; (void)buf;
+#ifdef ST_ABLATION   // tools-only build: the wave-specialised experiment (instances 22..29) lives in its own file
+#include "experiments/conv_igemm_ws.inc"
 #endif
-#pragma unroll
-      for (int e = 0; e < 2; ++e) {
-        st_k[e] += BK;
-        st_c[e] += BK;
-        while (st_c[e] >= p.Cin) {
-          st_c[e] -= p.Cin;
-          if (++st_kw[e] == p.KW) { st_kw[e] = 0; ++st_kh[e]; }
-        }
-        st_tap[e] = st_kh[e] * p.KW + st_kw[e];
-        st_off[e] = ((st_kh[e] * p.Wi + st_kw[e]) * p.in_ld + st_c[e]) * 4;
-      }
-    };
-    dma_chunk(0, 0);
-    __syncthreads();  // vmcnt(0) + barrier: chunk 0 landed
-    for (int kc = 0; kc < nchunks; ++kc) {
-      if (kc + 1 < nchunks) dma_chunk(kc + 1, (kc + 1) & 1);
-      __syncthreads();  // my DMAs landed (vmcnt(0)) and the MFMA waves are done with chunk kc
-    }
-    return;
-  }
 
-  // =============================== MFMA waves ===============================
-  const int wm = wave / WN, wn = wave - wm * WN;
-  const int l31 = lane & 31, lh = lane >> 5;
-  f32x16 acc[TM][TN];
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-  const int sw = (l31 >> 1) & 7;
-  __syncthreads();  // chunk 0 landed
-  for (int kc = 0; kc < nchunks; ++kc) {
-    const int buf = kc & 1;
-    const float* Ab = As + buf * BM * LDK + (wm * 32 * TM + l31) * LDK;
-    const float* Bb = Bs + buf * BN * LDK + (wn * 32 * TN + l31) * LDK;
-    const int gmax = (p.K - kc * BK + 7) >> 3;
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      if (g >= gmax) break;
-      const int koff = ((2 * g + lh) ^ sw) * 4;
-      f32x4 a[TM], b[TN];
-#pragma unroll
-      for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const f32x4*>(Ab + i * 32 * LDK + koff);
-#pragma unroll
-      for (int j = 0; j < TN; ++j) b[j] = *reinterpret_cast<const f32x4*>(Bb + j * 32 * LDK + koff);
-#pragma unroll
-      for (int s = 0; s < 4; ++s)
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-          for (int j = 0; j < TN; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][s], b[j][s], acc[i][j], 0, 0, 0);
-    }
-    __syncthreads();
-  }
-  conv_epilogue<TM, TN>(p, acc, m0, n0, wm, wn, l31, lh, BM, BN);
-}
-
-template <int TM, int TN, int WM, int WN, int NL = 1>
-static int launch_ws(const ConvKArgs& a, int m_tiles, hipStream_t stream) {
-  constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
-  constexpr size_t lds = (size_t)2 * (BM + BN) * 32 * sizeof(float);
-  static bool attr_set = false;
-  auto kern = conv_igemm_ws_kernel<TM, TN, WM, WN, NL>;
-  if (!attr_set) {
-    ST_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr_set = true;
-  }
-  dim3 grid((unsigned)(m_tiles * a.n_tiles)), block(64 * (WM * WN + NL));
-  hipLaunchKernelGGL(kern, grid, block, lds, stream, a);
-  ST_CHECK_HIP(hipGetLastError());
-  return ST_OK;
-}
-
-#endif  // ST_ABLATION
-
-template <int TM, int TN, int WM, int WN, int NBUF = 2, int ABL = 0, int ILV = 1, int DMA = 0, int PW = 0>
+template <int TM, int TN, int WM, int WN, int NBUF = 2, int ILV = 1, int DMA = 0, int PW = 0>
 static int launch_variant(const ConvKArgs& a, int m_tiles, hipStream_t stream) {
   constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
   constexpr size_t lds = (size_t)NBUF * (BM + BN) * (DMA ? 32 : LDK) * sizeof(float);
   static bool attr_set = false;
-  auto kern = conv_igemm_kernel<TM, TN, WM, WN, NBUF, ABL, ILV, DMA, PW>;
+  auto kern = conv_igemm_kernel<TM, TN, WM, WN, NBUF, ILV, DMA, PW>;
   if (!attr_set) {
     ST_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -960,17 +779,17 @@ const char* conv_variant_name(int id) {
   return id >= 0 && id < kNumVariants ? names[id] : "-";
 }
 
-// template arguments <TM, TN, WM, WN, NBUF, ABL, ILV, DMA> of each variant's kernel instance (so profiler
+// template arguments <TM, TN, WM, WN, NBUF, ILV, DMA> of each variant's kernel instance (so profiler
 // rows "st::conv_igemm_kernel<...>" can be matched to variants)
 const char* conv_variant_signature(int id) {
-  static const char* sigs[] = {"2, 2, 2, 2, 2, 0, 1, 0", "2, 2, 2, 1, 2, 0, 1, 0", "2, 1, 2, 1, 2, 0, 1, 0",
-                               "1, 1, 2, 2, 2, 0, 1, 0", "1, 1, 2, 1, 2, 0, 1, 0", "1, 2, 4, 1, 2, 0, 1, 0",
-                               "1, 1, 4, 1, 2, 0, 1, 0", "1, 2, 2, 2, 2, 0, 1, 0", "2, 2, 4, 1, 2, 0, 1, 0",
-                               "2, 2, 1, 1, 1, 0, 1, 0", "2, 1, 1, 1, 1, 0, 1, 0", "1, 2, 1, 1, 1, 0, 1, 0",
-                               "2, 2, 2, 2, 2, 0, 1, 1", "1, 1, 2, 2, 2, 0, 1, 1", "1, 2, 2, 2, 2, 0, 1, 1",
-                               "1, 1, 4, 1, 2, 0, 1, 1", "1, 2, 4, 1, 2, 0, 1, 1", "2, 2, 2, 2, 2, 0, 0, 1",
-                               "1, 1, 2, 2, 2, 0, 0, 1", "2, 2, 4, 2, 2, 0, 1, 1", "2, 2, 4, 2, 2, 0, 0, 1",
-                               "2, 2, 4, 2, 2, 0, 1, 0", "ws 2, 2, 2, 2", "ws 1, 1, 2, 2", "ws 1, 2, 2, 2",
+  static const char* sigs[] = {"2, 2, 2, 2, 2, 1, 0", "2, 2, 2, 1, 2, 1, 0", "2, 1, 2, 1, 2, 1, 0",
+                               "1, 1, 2, 2, 2, 1, 0", "1, 1, 2, 1, 2, 1, 0", "1, 2, 4, 1, 2, 1, 0",
+                               "1, 1, 4, 1, 2, 1, 0", "1, 2, 2, 2, 2, 1, 0", "2, 2, 4, 1, 2, 1, 0",
+                               "2, 2, 1, 1, 1, 1, 0", "2, 1, 1, 1, 1, 1, 0", "1, 2, 1, 1, 1, 1, 0",
+                               "2, 2, 2, 2, 2, 1, 1", "1, 1, 2, 2, 2, 1, 1", "1, 2, 2, 2, 2, 1, 1",
+                               "1, 1, 4, 1, 2, 1, 1", "1, 2, 4, 1, 2, 1, 1", "2, 2, 2, 2, 2, 0, 1",
+                               "1, 1, 2, 2, 2, 0, 1", "2, 2, 4, 2, 2, 1, 1", "2, 2, 4, 2, 2, 0, 1",
+                               "2, 2, 4, 2, 2, 1, 0", "ws 2, 2, 2, 2", "ws 1, 1, 2, 2", "ws 1, 2, 2, 2",
                                "ws 1, 1, 4, 1", "ws 1, 2, 4, 1", "ws 2, 2, 2, 2, 2", "ws 1, 2, 2, 2, 2",
                                "ws 2, 2, 2, 2, 4"};
   return id >= 0 && id < kNumVariants ? sigs[id] : "";
@@ -1086,51 +905,32 @@ int conv2d_launch(const StConvDesc& d, hipStream_t stream, int force_variant, in
   if (picked_variant) *picked_variant = pick;
   a.n_tiles = cout_pad / v.bn;
   const int m_tiles = ceil_div(a.M, v.bm);
-#ifdef ST_ABLATION
-  if (force_variant >= 100) {  // timing-only ablations (tools/conv_ablation.py): WRONG results by construction
-    const int abl = force_variant / 100;
-    if (pick == 0 && abl == 1) return launch_variant<2, 2, 2, 2, 2, 1>(a, m_tiles, stream);
-    if (pick == 0 && abl == 2) return launch_variant<2, 2, 2, 2, 2, 2>(a, m_tiles, stream);
-    if (pick == 3 && abl == 1) return launch_variant<1, 1, 2, 2, 2, 1>(a, m_tiles, stream);
-    if (pick == 3 && abl == 2) return launch_variant<1, 1, 2, 2, 2, 2>(a, m_tiles, stream);
-    if (pick == 0 && abl == 6) return launch_variant<2, 2, 2, 2, 2, 6, 0>(a, m_tiles, stream);  // cache-hot loads
-    if (pick == 3 && abl == 6) return launch_variant<1, 1, 2, 2, 2, 6, 0>(a, m_tiles, stream);
-    if (pick == 0 && abl == 4) return launch_variant<2, 2, 2, 2, 2, 4, 0>(a, m_tiles, stream);  // loads, no ds_write
-    if (pick == 0 && abl == 5) return launch_variant<2, 2, 2, 2, 2, 5, 0>(a, m_tiles, stream);  // ds_write, no loads
-    if (pick == 3 && abl == 4) return launch_variant<1, 1, 2, 2, 2, 4, 0>(a, m_tiles, stream);
-    if (pick == 3 && abl == 5) return launch_variant<1, 1, 2, 2, 2, 5, 0>(a, m_tiles, stream);
-    if (pick == 0 && abl == 3) return launch_variant<2, 2, 2, 2, 2, 0, 0>(a, m_tiles, stream);  // burst staging
-    if (pick == 3 && abl == 3) return launch_variant<1, 1, 2, 2, 2, 0, 0>(a, m_tiles, stream);
-    return set_error(ST_ERR_INVALID, "conv: no ablation build for variant %d", force_variant);
-  }
-#else
-  ST_REQUIRE(force_variant < 100, "conv: ablation builds exist only in the ST_ABLATION (tools) library");
-#endif
+  ST_REQUIRE(force_variant < 100, "conv: no such instance %d", force_variant);
   // pointwise layers run the PW instance of the picked tile variant (same tiles, shorter address code)
   const bool pw = d.KH == 1 && d.KW == 1 && d.stride == 1 && d.pad == 0;
   switch (pick) {
-    case 0: return pw ? launch_variant<2, 2, 2, 2, 2, 0, 1, 0, 1>(a, m_tiles, stream) : launch_variant<2, 2, 2, 2, 2, 0, 1, 0, 0>(a, m_tiles, stream);
-    case 1: return pw ? launch_variant<2, 2, 2, 1, 2, 0, 1, 0, 1>(a, m_tiles, stream) : launch_variant<2, 2, 2, 1, 2, 0, 1, 0, 0>(a, m_tiles, stream);
-    case 2: return pw ? launch_variant<2, 1, 2, 1, 2, 0, 1, 0, 1>(a, m_tiles, stream) : launch_variant<2, 1, 2, 1, 2, 0, 1, 0, 0>(a, m_tiles, stream);
-    case 3: return pw ? launch_variant<1, 1, 2, 2, 2, 0, 1, 0, 1>(a, m_tiles, stream) : launch_variant<1, 1, 2, 2, 2, 0, 1, 0, 0>(a, m_tiles, stream);
-    case 4: return pw ? launch_variant<1, 1, 2, 1, 2, 0, 1, 0, 1>(a, m_tiles, stream) : launch_variant<1, 1, 2, 1, 2, 0, 1, 0, 0>(a, m_tiles, stream);
-    case 5: return pw ? launch_variant<1, 2, 4, 1, 2, 0, 1, 0, 1>(a, m_tiles, stream) : launch_variant<1, 2, 4, 1, 2, 0, 1, 0, 0>(a, m_tiles, stream);
-    case 6: return pw ? launch_variant<1, 1, 4, 1, 2, 0, 1, 0, 1>(a, m_tiles, stream) : launch_variant<1, 1, 4, 1, 2, 0, 1, 0, 0>(a, m_tiles, stream);
-    case 7: return pw ? launch_variant<1, 2, 2, 2, 2, 0, 1, 0, 1>(a, m_tiles, stream) : launch_variant<1, 2, 2, 2, 2, 0, 1, 0, 0>(a, m_tiles, stream);
-    case 8: return pw ? launch_variant<2, 2, 4, 1, 2, 0, 1, 0, 1>(a, m_tiles, stream) : launch_variant<2, 2, 4, 1, 2, 0, 1, 0, 0>(a, m_tiles, stream);
-    case 9: return pw ? launch_variant<2, 2, 1, 1, 1, 0, 1, 0, 1>(a, m_tiles, stream) : launch_variant<2, 2, 1, 1, 1, 0, 1, 0, 0>(a, m_tiles, stream);
-    case 10: return pw ? launch_variant<2, 1, 1, 1, 1, 0, 1, 0, 1>(a, m_tiles, stream) : launch_variant<2, 1, 1, 1, 1, 0, 1, 0, 0>(a, m_tiles, stream);
-    case 11: return pw ? launch_variant<1, 2, 1, 1, 1, 0, 1, 0, 1>(a, m_tiles, stream) : launch_variant<1, 2, 1, 1, 1, 0, 1, 0, 0>(a, m_tiles, stream);
-    case 12: return pw ? launch_variant<2, 2, 2, 2, 2, 0, 1, 1, 1>(a, m_tiles, stream) : launch_variant<2, 2, 2, 2, 2, 0, 1, 1, 0>(a, m_tiles, stream);
-    case 13: return pw ? launch_variant<1, 1, 2, 2, 2, 0, 1, 1, 1>(a, m_tiles, stream) : launch_variant<1, 1, 2, 2, 2, 0, 1, 1, 0>(a, m_tiles, stream);
-    case 14: return pw ? launch_variant<1, 2, 2, 2, 2, 0, 1, 1, 1>(a, m_tiles, stream) : launch_variant<1, 2, 2, 2, 2, 0, 1, 1, 0>(a, m_tiles, stream);
-    case 15: return pw ? launch_variant<1, 1, 4, 1, 2, 0, 1, 1, 1>(a, m_tiles, stream) : launch_variant<1, 1, 4, 1, 2, 0, 1, 1, 0>(a, m_tiles, stream);
-    case 16: return pw ? launch_variant<1, 2, 4, 1, 2, 0, 1, 1, 1>(a, m_tiles, stream) : launch_variant<1, 2, 4, 1, 2, 0, 1, 1, 0>(a, m_tiles, stream);
-    case 17: return pw ? launch_variant<2, 2, 2, 2, 2, 0, 0, 1, 1>(a, m_tiles, stream) : launch_variant<2, 2, 2, 2, 2, 0, 0, 1, 0>(a, m_tiles, stream);
-    case 18: return pw ? launch_variant<1, 1, 2, 2, 2, 0, 0, 1, 1>(a, m_tiles, stream) : launch_variant<1, 1, 2, 2, 2, 0, 0, 1, 0>(a, m_tiles, stream);
-    case 19: return pw ? launch_variant<2, 2, 4, 2, 2, 0, 1, 1, 1>(a, m_tiles, stream) : launch_variant<2, 2, 4, 2, 2, 0, 1, 1, 0>(a, m_tiles, stream);
-    case 20: return pw ? launch_variant<2, 2, 4, 2, 2, 0, 0, 1, 1>(a, m_tiles, stream) : launch_variant<2, 2, 4, 2, 2, 0, 0, 1, 0>(a, m_tiles, stream);
-    case 21: return pw ? launch_variant<2, 2, 4, 2, 2, 0, 1, 0, 1>(a, m_tiles, stream) : launch_variant<2, 2, 4, 2, 2, 0, 1, 0, 0>(a, m_tiles, stream);
+    case 0: return pw ? launch_variant<2, 2, 2, 2, 2, 1, 0, 1>(a, m_tiles, stream) : launch_variant<2, 2, 2, 2, 2, 1, 0, 0>(a, m_tiles, stream);
+    case 1: return pw ? launch_variant<2, 2, 2, 1, 2, 1, 0, 1>(a, m_tiles, stream) : launch_variant<2, 2, 2, 1, 2, 1, 0, 0>(a, m_tiles, stream);
+    case 2: return pw ? launch_variant<2, 1, 2, 1, 2, 1, 0, 1>(a, m_tiles, stream) : launch_variant<2, 1, 2, 1, 2, 1, 0, 0>(a, m_tiles, stream);
+    case 3: return pw ? launch_variant<1, 1, 2, 2, 2, 1, 0, 1>(a, m_tiles, stream) : launch_variant<1, 1, 2, 2, 2, 1, 0, 0>(a, m_tiles, stream);
+    case 4: return pw ? launch_variant<1, 1, 2, 1, 2, 1, 0, 1>(a, m_tiles, stream) : launch_variant<1, 1, 2, 1, 2, 1, 0, 0>(a, m_tiles, stream);
+    case 5: return pw ? launch_variant<1, 2, 4, 1, 2, 1, 0, 1>(a, m_tiles, stream) : launch_variant<1, 2, 4, 1, 2, 1, 0, 0>(a, m_tiles, stream);
+    case 6: return pw ? launch_variant<1, 1, 4, 1, 2, 1, 0, 1>(a, m_tiles, stream) : launch_variant<1, 1, 4, 1, 2, 1, 0, 0>(a, m_tiles, stream);
+    case 7: return pw ? launch_variant<1, 2, 2, 2, 2, 1, 0, 1>(a, m_tiles, stream) : launch_variant<1, 2, 2, 2, 2, 1, 0, 0>(a, m_tiles, stream);
+    case 8: return pw ? launch_variant<2, 2, 4, 1, 2, 1, 0, 1>(a, m_tiles, stream) : launch_variant<2, 2, 4, 1, 2, 1, 0, 0>(a, m_tiles, stream);
+    case 9: return pw ? launch_variant<2, 2, 1, 1, 1, 1, 0, 1>(a, m_tiles, stream) : launch_variant<2, 2, 1, 1, 1, 1, 0, 0>(a, m_tiles, stream);
+    case 10: return pw ? launch_variant<2, 1, 1, 1, 1, 1, 0, 1>(a, m_tiles, stream) : launch_variant<2, 1, 1, 1, 1, 1, 0, 0>(a, m_tiles, stream);
+    case 11: return pw ? launch_variant<1, 2, 1, 1, 1, 1, 0, 1>(a, m_tiles, stream) : launch_variant<1, 2, 1, 1, 1, 1, 0, 0>(a, m_tiles, stream);
+    case 12: return pw ? launch_variant<2, 2, 2, 2, 2, 1, 1, 1>(a, m_tiles, stream) : launch_variant<2, 2, 2, 2, 2, 1, 1, 0>(a, m_tiles, stream);
+    case 13: return pw ? launch_variant<1, 1, 2, 2, 2, 1, 1, 1>(a, m_tiles, stream) : launch_variant<1, 1, 2, 2, 2, 1, 1, 0>(a, m_tiles, stream);
+    case 14: return pw ? launch_variant<1, 2, 2, 2, 2, 1, 1, 1>(a, m_tiles, stream) : launch_variant<1, 2, 2, 2, 2, 1, 1, 0>(a, m_tiles, stream);
+    case 15: return pw ? launch_variant<1, 1, 4, 1, 2, 1, 1, 1>(a, m_tiles, stream) : launch_variant<1, 1, 4, 1, 2, 1, 1, 0>(a, m_tiles, stream);
+    case 16: return pw ? launch_variant<1, 2, 4, 1, 2, 1, 1, 1>(a, m_tiles, stream) : launch_variant<1, 2, 4, 1, 2, 1, 1, 0>(a, m_tiles, stream);
+    case 17: return pw ? launch_variant<2, 2, 2, 2, 2, 0, 1, 1>(a, m_tiles, stream) : launch_variant<2, 2, 2, 2, 2, 0, 1, 0>(a, m_tiles, stream);
+    case 18: return pw ? launch_variant<1, 1, 2, 2, 2, 0, 1, 1>(a, m_tiles, stream) : launch_variant<1, 1, 2, 2, 2, 0, 1, 0>(a, m_tiles, stream);
+    case 19: return pw ? launch_variant<2, 2, 4, 2, 2, 1, 1, 1>(a, m_tiles, stream) : launch_variant<2, 2, 4, 2, 2, 1, 1, 0>(a, m_tiles, stream);
+    case 20: return pw ? launch_variant<2, 2, 4, 2, 2, 0, 1, 1>(a, m_tiles, stream) : launch_variant<2, 2, 4, 2, 2, 0, 1, 0>(a, m_tiles, stream);
+    case 21: return pw ? launch_variant<2, 2, 4, 2, 2, 1, 0, 1>(a, m_tiles, stream) : launch_variant<2, 2, 4, 2, 2, 1, 0, 0>(a, m_tiles, stream);
 #ifdef ST_ABLATION
     case 22: return launch_ws<2, 2, 2, 2>(a, m_tiles, stream);
     case 23: return launch_ws<1, 1, 2, 2>(a, m_tiles, stream);

@@ -165,10 +165,6 @@ int spp_pool_launch(const float* x, int x_ld, int x_off, int N, int H, int W, in
   // 4 channels 45 us, 2 channels 55 us (8-byte global accesses).
   int cg = 8;
   if ((long long)(C / 8) * N < 1024) cg = 4;
-#ifdef ST_ABLATION
-  if (const char* e = getenv("ST_SPP_CG")) cg = atoi(e);
-  if (cg != 2 && cg != 4) cg = 8;
-#endif
   const size_t lds = (size_t)2 * H * W * cg * sizeof(float);
   if (C % cg == 0 && lds <= 150 * 1024 && N <= 65535) {
     using Kern = void (*)(const float*, int, int, int, int, int, float*, int, int, int);

@@ -349,9 +349,6 @@ int stem_focus_conv_launch(const float* in, int N, int H, int W, int used_planes
   const long long out_bytes = (long long)N * a.Ho * a.Wo * out_ld * 4;
   ST_REQUIRE(out_bytes < (1ll << 31), "stem_focus_conv: output exceeds 2 GiB (split the batch)");
   a.out_bytes = (unsigned)out_bytes;
-#ifdef ST_ABLATION   // tools-only build, timing only: every epilogue store falls outside the buffer resource's range
-  if (getenv("ST_STEM_NO_STORE")) a.out_bytes = 0;   // and is dropped - the kernel without its HBM write stream
-#endif
   const bool vec = ((out_ld | out_off | Cout) & 3) == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0;
   using Kern = void (*)(const StemArgs);
   static const Kern kerns[12] = {
