@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define ST_VERSION 400
+#define ST_VERSION 410
 
 enum {
   ST_OK = 0,
@@ -222,8 +222,8 @@ int st_detector_set_param(StDetector* det, const char* name, const float* host, 
 int st_detector_finalize(StDetector* det);
 
 size_t st_detector_workspace_bytes(const StDetector* det);
-/* head output layout: for level l (stride 8,16,32): float[N][H_l*W_l][8] rows of
- * [cls logits (num_classes = 1..3) | reg x,y,w,h | obj logit | unused up to 8];
+/* head output layout: for level l (stride 8,16,32): float[N][H_l*W_l][row] rows of
+ * [cls logits (num_classes) | reg x,y,w,h | obj logit | unused up to st_head_row_floats(num_classes): 8 for 1..3 classes];
  * levels concatenated.  st_detector_head_floats = total float count. */
 size_t st_detector_head_floats(const StDetector* det);
 int st_detector_num_levels(const StDetector* det);
@@ -305,12 +305,19 @@ typedef struct StDecodeDesc {
   int nms_mask_rows;      /* candidates (in score order) whose pairwise IoU bits are precomputed chip-wide;
                            * 0 = default 4096.  Sizes the workspace (rows^2 / 8 bytes per image); later
                            * candidates are resolved on the fly by one wave - results do not depend on it */
-  int num_classes;        /* 0 / 1: one class (the shipped config).  2..3: head rows carry num_classes class logits
-                           * (then x, y, w, h, obj); multi_label decode - every (prior, class) pair with score > thr
-                           * is a candidate, in filter_scores_and_topk's order - and class-aware NMS by mmcv
-                           * batched_nms's offset trick (boxes + label * (max coordinate + 1));
-                           * out_labels = class, out_prior_idx = prior */
+  int num_classes;        /* 0 / 1: one class (the shipped config).  2..1024: head rows carry num_classes class logits
+                           * (then x, y, w, h, obj; st_head_row_floats(num_classes) floats per row); multi_label
+                           * decode - every (prior, class) pair with score > thr is a candidate, in
+                           * filter_scores_and_topk's order - and class-aware NMS by mmcv batched_nms's offset trick
+                           * (boxes + label * (max coordinate + 1)); out_labels = class, out_prior_idx = prior */
+  int single_label;       /* with several classes: test_cfg.multi_label = False - ONE candidate per prior, the class of
+                           * its largest score sigmoid(cls_c) * sigmoid(obj) (first maximum on ties; mmyolo
+                           * predict_by_feat: scores.max(1)), thresholded afterwards; NMS stays class-aware */
 } StDecodeDesc;
+
+/* Floats per prior in head_out: 8 for 1..3 classes (cls.., x, y, w, h, obj, padding), num_classes + 5 rounded up to a
+ * multiple of 4 beyond. */
+int st_head_row_floats(int num_classes);
 
 size_t st_decode_nms_workspace_bytes(const StDecodeDesc* d);
 /* outputs per image n: out_boxes[n][max_det][4] (xyxy), out_scores[n][max_det],

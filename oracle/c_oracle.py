@@ -39,10 +39,16 @@ def _p(a):
     return a.ctypes.data_as(C.c_void_p)
 
 
+def head_row_floats(num_classes):
+    """floats per prior in the head buffer (the product's st_head_row_floats, restated)."""
+    return 8 if num_classes <= 3 else (num_classes + 5 + 3) // 4 * 4
+
+
 def decode_nms(head, N, levels, score_thr, iou_thr, max_det, ori_shape, scale_factor=(1.0, 1.0), pad_param=None,
-               num_classes=1):
+               num_classes=1, multi_label=True):
     """head: flat float32 numpy array in the product's head_out layout; levels: [(h, w, stride, float_offset)].
-    num_classes > 1: multi_label decode + class-aware NMS (oracle_decode_nms_mc).
+    num_classes > 1: multi_label decode (or multi_label=False: one candidate per prior) + class-aware NMS
+    (oracle_decode_nms_gen).
     Returns boxes (N,max_det,4), scores, labels (int64), prior_idx (int32), counts (int32)."""
     lib = load()
     head = np.ascontiguousarray(head, dtype=np.float32)
@@ -60,10 +66,11 @@ def decode_nms(head, N, levels, score_thr, iou_thr, max_det, ori_shape, scale_fa
     pad_top = float(pad_param[0]) if pad_param is not None else 0.0
     f = C.c_float
     if num_classes > 1:
-        rc = lib.oracle_decode_nms_mc(_p(head), C.c_int(N), C.c_int(L), lh, lw, ls, lo, f(score_thr), f(iou_thr),
-                                      C.c_int(max_det), f(scale_factor[0]), f(scale_factor[1]), f(pad_left),
-                                      f(pad_top), f(ori_shape[1]), f(ori_shape[0]), C.c_int(num_classes), _p(boxes),
-                                      _p(scores), _p(labels), _p(prior), _p(counts))
+        rc = lib.oracle_decode_nms_gen(_p(head), C.c_int(N), C.c_int(L), lh, lw, ls, lo, f(score_thr), f(iou_thr),
+                                       C.c_int(max_det), f(scale_factor[0]), f(scale_factor[1]), f(pad_left),
+                                       f(pad_top), f(ori_shape[1]), f(ori_shape[0]), C.c_int(num_classes),
+                                       C.c_int(head_row_floats(num_classes)), C.c_int(1 if multi_label else 0),
+                                       _p(boxes), _p(scores), _p(labels), _p(prior), _p(counts))
     else:
         rc = lib.oracle_decode_nms(_p(head), C.c_int(N), C.c_int(L), lh, lw, ls, lo, f(score_thr), f(iou_thr),
                                    C.c_int(max_det), f(scale_factor[0]), f(scale_factor[1]), f(pad_left), f(pad_top),

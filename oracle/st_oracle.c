@@ -90,13 +90,17 @@ static int cand_cmp(const void* a, const void* b) {
  * class-aware NMS as mmcv batched_nms does it [upstream-memory, mmcv 2.0.0rc3]: the IoU is taken on
  * boxes + label * (boxes.max() + 1) (fp32), so boxes of different classes never overlap and same-class pairs see the
  * coordinates AFTER the offset addition rounded them.  nc <= 1: the single-class path above, unchanged. */
-int oracle_decode_nms_mc(const float* head, int N, int num_levels, const int* lvl_h, const int* lvl_w,
-                         const int* lvl_stride, const size_t* lvl_off, float score_thr, float iou_thr,
-                         int max_det, float scale_x, float scale_y, float pad_left, float pad_top,
-                         float ori_w, float ori_h, int nc, float* out_boxes, float* out_scores,
-                         int64_t* out_labels, int32_t* out_prior, int32_t* out_count) {
+/* Wide heads and multi_label = False.  Head row = `hr` floats per prior (8 for nc <= 3, nc + 5 rounded up to a multiple
+ * of 4 beyond: st_head_row_floats).  multi_label = 0 (mmyolo predict_by_feat, `if cfg.multi_label is False`
+ * [upstream-memory, mmyolo 0.2.0]): scores.max(1) over score_c = sigmoid(cls_c) * sigmoid(obj) - the FIRST maximum on
+ * ties (torch.max on CPU) - and the score threshold on that single (prior, class) pair; NMS stays class-aware. */
+int oracle_decode_nms_gen(const float* head, int N, int num_levels, const int* lvl_h, const int* lvl_w,
+                          const int* lvl_stride, const size_t* lvl_off, float score_thr, float iou_thr,
+                          int max_det, float scale_x, float scale_y, float pad_left, float pad_top,
+                          float ori_w, float ori_h, int nc, int hr, int multi_label, float* out_boxes,
+                          float* out_scores, int64_t* out_labels, int32_t* out_prior, int32_t* out_count) {
   if (nc < 1) nc = 1;
-  if (nc + 5 > 8) return -2;
+  if (nc + 5 > hr) return -2;
   int P = 0;
   for (int l = 0; l < num_levels; ++l) P += lvl_h[l] * lvl_w[l];
   Cand* cand = (Cand*)malloc(sizeof(Cand) * (size_t)(P > 0 ? P : 1) * nc);
@@ -107,16 +111,25 @@ int oracle_decode_nms_mc(const float* head, int N, int num_levels, const int* lv
     for (int l = 0; l < num_levels; ++l) {
       const int h = lvl_h[l], w = lvl_w[l];
       const float s = (float)lvl_stride[l];
-      const float* base = head + lvl_off[l] + (size_t)n * h * w * 8;
+      const float* base = head + lvl_off[l] + (size_t)n * h * w * hr;
       for (int py = 0; py < h; ++py)
         for (int px = 0; px < w; ++px, ++prior) {
-          const float* row = base + ((size_t)py * w + px) * 8;
+          const float* row = base + ((size_t)py * w + px) * hr;
           const float sobj = st_sigmoidf(row[nc + 4]);
           const float tx = row[nc] * s, ty = row[nc + 1] * s;
           const float cx = tx + (float)px * s, cy = ty + (float)py * s;
           const float bw = st_expf(row[nc + 2]) * s, bh = st_expf(row[nc + 3]) * s;
           const float hw = bw / 2.0f, hh = bh / 2.0f;
-          for (int c = 0; c < nc; ++c) {
+          int c_lo = 0, c_hi = nc;
+          if (!multi_label) {   /* one candidate per prior: its best class, first maximum */
+            float best = -1.0f;
+            for (int c = 0; c < nc; ++c) {
+              const float sc = st_sigmoidf(row[c]) * sobj;
+              if (sc > best) { best = sc; c_lo = c; }
+            }
+            c_hi = c_lo + 1;
+          }
+          for (int c = c_lo; c < c_hi; ++c) {
             const float score = st_sigmoidf(row[c]) * sobj;
             if (!(score > score_thr)) continue;
             Cand* q = &cand[K++];
@@ -172,6 +185,17 @@ int oracle_decode_nms_mc(const float* head, int N, int num_levels, const int* lv
   free(cand);
   free(sup);
   return 0;
+}
+
+int oracle_decode_nms_mc(const float* head, int N, int num_levels, const int* lvl_h, const int* lvl_w,
+                         const int* lvl_stride, const size_t* lvl_off, float score_thr, float iou_thr,
+                         int max_det, float scale_x, float scale_y, float pad_left, float pad_top,
+                         float ori_w, float ori_h, int nc, float* out_boxes, float* out_scores,
+                         int64_t* out_labels, int32_t* out_prior, int32_t* out_count) {
+  if (nc + 5 > 8) return -2;
+  return oracle_decode_nms_gen(head, N, num_levels, lvl_h, lvl_w, lvl_stride, lvl_off, score_thr, iou_thr, max_det,
+                               scale_x, scale_y, pad_left, pad_top, ori_w, ori_h, nc, 8, 1, out_boxes, out_scores,
+                               out_labels, out_prior, out_count);
 }
 
 int oracle_decode_nms(const float* head, int N, int num_levels, const int* lvl_h, const int* lvl_w,

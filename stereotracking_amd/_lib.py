@@ -60,12 +60,14 @@ class StDecodeDesc(C.Structure):
         ('score_thr', C.c_float), ('iou_thr', C.c_float), ('max_det', C.c_int),
         ('scale_x', C.c_float), ('scale_y', C.c_float), ('pad_left', C.c_float), ('pad_top', C.c_float),
         ('ori_w', C.c_float), ('ori_h', C.c_float), ('nms_mask_rows', C.c_int), ('num_classes', C.c_int),
+        ('single_label', C.c_int),
     ]
 
 
 _vp, _i, _f, _sz = C.c_void_p, C.c_int, C.c_float, C.c_size_t
 _PROTOS = {
     'st_version': (C.c_int, []),
+    'st_head_row_floats': (_i, [_i]),
     'st_png_unfilter': (_i, [_vp, _i, _i, _i, _vp]),
     'st_stem_focus_conv_u8': (_i, [_vp, _i, _i, _i, _i, _i, _f, _vp, _vp, _i, _vp, _i, _i, _i, _vp]),
     'st_detector_forward_phase0_raw': (_i, [_vp, _vp, _vp, _i, _i, _f, _vp, _sz, _vp]),

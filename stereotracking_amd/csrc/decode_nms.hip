@@ -64,7 +64,9 @@ struct DecodeArgs {
                      // are resolved on the fly by the reduce kernel (identical results, slower)
   int Tm;            // mcap / 64: mask words per row
   int batch;
-  int nc;            // classes (head row = nc class logits, x, y, w, h, obj; nc + 5 <= 8)
+  int nc;            // classes (head row = nc class logits, x, y, w, h, obj)
+  int hr;            // floats per head row (head_row_floats(nc): 8 up to 3 classes)
+  int single_label;  // several classes, multi_label=False: ONE candidate per prior, its best class
   int cand_cap;      // P * nc: rows of the candidate arrays
   float score_thr, iou_thr;
   int max_det;
@@ -83,8 +85,10 @@ struct DecodeArgs {
 __global__ __launch_bounds__(256) void decode_filter_kernel(DecodeArgs a) {
   const int n = blockIdx.y;
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  const int nc = a.nc;
   float logit[3] = {0.f, 0.f, 0.f}, obj = 0.f;
   f32x4 box = {0.f, 0.f, 0.f, 0.f};
+  const float* row = a.head;     // this prior's head row (class logits of wide heads are read from it below)
   if (p < a.P) {
     int l = 0;
     while (l + 1 < a.num_levels && p >= a.lvl_start[l + 1]) ++l;
@@ -92,17 +96,22 @@ __global__ __launch_bounds__(256) void decode_filter_kernel(DecodeArgs a) {
     const int w = a.lvl_w[l], hw = a.lvl_h[l] * w;
     const int py = q / w, px = q - py * w;
     const float s = (float)a.lvl_stride[l];
-    const float* row = a.head + a.lvl_off[l] + ((size_t)n * hw + q) * 8;
-    const f32x4 v0 = *reinterpret_cast<const f32x4*>(row);      // nc = 1: cls, x, y, w | h, obj, -, -
-    const f32x4 v1 = *reinterpret_cast<const f32x4*>(row + 4);
-    const float r8[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-    const int nc = a.nc;
-    for (int c = 0; c < nc; ++c) logit[c] = r8[c];
-    obj = r8[nc + 4];
-    const float cx = r8[nc] * s + (float)px * s;
-    const float cy = r8[nc + 1] * s + (float)py * s;
-    const float bw = st_expf(r8[nc + 2]) * s;
-    const float bh = st_expf(r8[nc + 3]) * s;
+    row = a.head + a.lvl_off[l] + ((size_t)n * hw + q) * a.hr;
+    float r5[5];                 // x, y, w, h, obj
+    if (nc <= 3) {               // 8-float rows: two 16-byte loads.  nc = 1: cls, x, y, w | h, obj, -, -
+      const f32x4 v0 = *reinterpret_cast<const f32x4*>(row);
+      const f32x4 v1 = *reinterpret_cast<const f32x4*>(row + 4);
+      const float r8[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+      for (int c = 0; c < nc; ++c) logit[c] = r8[c];
+      for (int e = 0; e < 5; ++e) r5[e] = r8[nc + e];
+    } else {
+      for (int e = 0; e < 5; ++e) r5[e] = row[nc + e];
+    }
+    obj = r5[4];
+    const float cx = r5[0] * s + (float)px * s;
+    const float cy = r5[1] * s + (float)py * s;
+    const float bw = st_expf(r5[2]) * s;
+    const float bh = st_expf(r5[3]) * s;
     const float hw2 = bw / 2.0f, hh2 = bh / 2.0f;
     box[0] = ((cx - hw2) - a.pad_left) / a.scale_x;
     box[1] = ((cy - hh2) - a.pad_top) / a.scale_y;
@@ -111,20 +120,36 @@ __global__ __launch_bounds__(256) void decode_filter_kernel(DecodeArgs a) {
   }
   const float sobj = st_sigmoidf(obj);
   const int lane = threadIdx.x & 63;
-  for (int c = 0; c < a.nc; ++c) {   // uniform trip count
-    const float score = st_sigmoidf(logit[c]) * sobj;
-    const bool valid = p < a.P && score > a.score_thr;
+  auto emit = [&](bool valid, float score, int c) {   // wave-aggregated append (called with a uniform trip count)
     const u64 ballot = __ballot(valid);
-    if (ballot == 0) continue;
+    if (ballot == 0) return;
     int base = 0;
     if (lane == __builtin_ctzll(ballot)) base = atomicAdd(&a.count[n], __builtin_popcountll(ballot));
     base = __shfl(base, __builtin_ctzll(ballot));
     if (valid) {
       const int pos = base + __builtin_popcountll(ballot & ((1ull << lane) - 1ull));
-      const unsigned flat = (unsigned)p * (unsigned)a.nc + (unsigned)c;   // filter_scores_and_topk's nonzero() order
+      const unsigned flat = (unsigned)p * (unsigned)nc + (unsigned)c;   // filter_scores_and_topk's nonzero() order
       a.cand_key[(size_t)n * a.cand_cap + pos] = ((u64)__float_as_uint(score) << 32) | (u64)(0xFFFFFFFFu - flat);
       a.cand_box[(size_t)n * a.cand_cap + pos] = box;
     }
+  };
+  if (a.single_label) {
+    // multi_label=False (mmyolo predict_by_feat): scores.max(1) over score_c = sigmoid(cls_c) * sigmoid(obj), the FIRST
+    // maximum on ties, then the score threshold on that one (prior, class) pair
+    float best = -1.0f;
+    int bc = 0;
+    for (int c = 0; c < nc; ++c) {
+      const float lg = nc <= 3 ? logit[c] : (p < a.P ? row[c] : 0.f);
+      const float score = st_sigmoidf(lg) * sobj;
+      if (score > best) { best = score; bc = c; }
+    }
+    emit(p < a.P && best > a.score_thr, best, bc);
+    return;
+  }
+  for (int c = 0; c < nc; ++c) {   // uniform trip count
+    const float lg = nc <= 3 ? logit[c] : (p < a.P ? row[c] : 0.f);
+    const float score = st_sigmoidf(lg) * sobj;
+    emit(p < a.P && score > a.score_thr, score, c);
   }
 }
 
@@ -339,13 +364,16 @@ static int decode_layout(const StDecodeDesc& d, DecodeLayout& L) {
   }
   ST_REQUIRE(P < (1 << 28), "st_decode_nms: too many priors");
   L.nc = d.num_classes > 0 ? d.num_classes : 1;
-  ST_REQUIRE(L.nc + 5 <= 8, "st_decode_nms: num_classes must be in [1, 3] (head row = 8 floats)");
+  ST_REQUIRE(L.nc <= 1024, "st_decode_nms: num_classes must be in [1, 1024]");
+  ST_REQUIRE(P * L.nc < (1ll << 31) - 1, "st_decode_nms: priors x classes exceeds 2^31");
   L.P = (int)P;
-  L.cand_cap = L.P * L.nc;      // (prior, class) pairs (multi_label; one class: the priors)
+  // (prior, class) pairs (multi_label; one class or single_label: the priors)
+  L.cand_cap = d.single_label ? L.P : L.P * L.nc;
   // nms_pre default (100000) >= priors: every candidate enters NMS.  The reduce kernel's LDS bitmap holds 32768
   // candidates: one class never exceeds it at the supported sizes; with several classes more than 32768 pairs above
   // score_thr in one image are reported as an overflow (count = INT_MAX), never dropped silently
-  ST_REQUIRE(L.nc > 1 || (L.P + 63) / 64 <= 512, "st_decode_nms: more than 32768 candidates per image not supported");
+  ST_REQUIRE((L.nc > 1 && !d.single_label) || (L.P + 63) / 64 <= 512,
+             "st_decode_nms: more than 32768 candidates per image not supported");
   L.cap = std::min(L.cand_cap, 32768);
   // IoU bit mask for the first `mcap` candidates in score order (a few hundred to a few thousand pass the score
   // threshold in practice); later candidates are resolved on the fly: the workspace no longer grows with P^2
@@ -400,6 +428,7 @@ extern "C" int st_decode_nms(const StDecodeDesc* d, const float* head_out_dev, v
   }
   a.lvl_start[d->num_levels] = start;
   a.P = L.P; a.cap = L.cap; a.mcap = L.mcap; a.Tm = L.Tm; a.batch = d->batch; a.nc = L.nc; a.cand_cap = L.cand_cap;
+  a.hr = head_row_floats(L.nc); a.single_label = (d->single_label && L.nc > 1) ? 1 : 0;
   a.score_thr = d->score_thr; a.iou_thr = d->iou_thr; a.max_det = d->max_det;
   a.scale_x = d->scale_x; a.scale_y = d->scale_y; a.pad_left = d->pad_left; a.pad_top = d->pad_top;
   a.ori_w = d->ori_w; a.ori_h = d->ori_h;

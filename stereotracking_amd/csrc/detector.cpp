@@ -496,13 +496,14 @@ int StDetector::build() {
   // ---- head: YOLOXHeadModule(in=outc, feat=outc, stacked_convs=2)
   const int feat = make_divisible(256, w);
   const int nc = cfg.num_classes;
-  ST_REQUIRE(nc >= 1 && nc + 5 <= 8, "detector: num_classes must be in [1,3] (head row = 8 floats)");
+  ST_REQUIRE(nc >= 1 && nc <= 1024, "detector: num_classes must be in [1, 1024]");
+  const int hr = head_row_floats(nc);   // floats per prior in the head buffer
   const std::string hp = "bbox_head.head_module.";
   head_floats = 0;
   for (int l = 0; l < 3; ++l) {
     lvl_h[l] = F[l].H; lvl_w[l] = F[l].W; lvl_stride[l] = 8 << l;
     lvl_off[l] = head_floats;
-    head_floats += (size_t)N * F[l].H * F[l].W * 8;
+    head_floats += (size_t)N * F[l].H * F[l].W * hr;
   }
   bool fused_pred = head_pred_applicable(feat, nc);
 #ifdef ST_ABLATION
@@ -534,7 +535,7 @@ int StDetector::build() {
     const std::string ls = std::to_string(l);
     TRef clsf = clsfs[l], regf = regfs[l];
     TRef ho;
-    ho.buf = BUF_HEAD; ho.N = N; ho.H = F[l].H; ho.W = F[l].W; ho.ld = 8; ho.base = lvl_off[l];
+    ho.buf = BUF_HEAD; ho.N = N; ho.H = F[l].H; ho.W = F[l].W; ho.ld = hr; ho.base = lvl_off[l];
     const int pcc = packed_conv2d({hp + "multi_level_conv_cls." + ls}, feat, {nc});
     const int pcr = packed_conv2d({hp + "multi_level_conv_reg." + ls, hp + "multi_level_conv_obj." + ls},
                                   feat, {4, 1});

@@ -35,6 +35,7 @@ bool bf16_mfma_in_use() { return g_bf16_mfma_in_use.load(std::memory_order_relax
 }  // namespace st
 
 extern "C" int st_version(void) { return ST_VERSION; }
+extern "C" int st_head_row_floats(int num_classes) { return st::head_row_floats(num_classes < 1 ? 1 : num_classes); }
 extern "C" const char* st_last_error(void) { return st::last_error().c_str(); }
 
 extern "C" size_t st_conv_packed_floats(int Cout, int Cin, int KH, int KW) {

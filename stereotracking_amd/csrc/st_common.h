@@ -24,6 +24,9 @@ void note_bf16_mfma_launch();   // a kernel issuing BF16 MFMAs is about to be la
 bool bf16_mfma_in_use();
 
 inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+// floats per prior in the head buffer: num_classes class logits, x, y, w, h, obj (+ padding to 16-byte rows); 8 for the
+// shipped 1..3-class heads, nc + 5 rounded up to a multiple of 4 beyond (st_head_row_floats)
+inline int head_row_floats(int nc) { return nc <= 3 ? 8 : (nc + 5 + 3) / 4 * 4; }
 inline int round_up(int a, int b) { return ceil_div(a, b) * b; }
 
 }  // namespace st

@@ -121,11 +121,11 @@ class YOLODetector_Disparity_V1(nn.Module):
             raise ValueError('backbone / neck / head widen+deepen factors must agree')
         self.widen_factor, self.deepen_factor = w, d
         self.num_classes = self.bbox_head.num_classes
-        if not 1 <= self.num_classes <= 3:
-            raise NotImplementedError('the head row holds num_classes + 5 <= 8 floats: num_classes must be in [1, 3]')
-        if self.num_classes > 1 and not self.test_cfg.get('multi_label', True):
-            raise NotImplementedError('with several classes the decode kernel implements multi_label=True (the base '
-                                      "config's value: every (prior, class) pair above score_thr is a candidate)")
+        if not 1 <= self.num_classes <= 1024:
+            raise ValueError('num_classes must be in [1, 1024]')
+        # several classes: multi_label (the base config's value: every (prior, class) pair above score_thr is a
+        # candidate) or multi_label=False (one candidate per prior: its best class) - both in the decode kernel
+        self.multi_label = bool(self.test_cfg.get('multi_label', True))
         # parameter tree from the library's own table (graph shapes do not matter for the table)
         probe = HipDetector(1, 32, 32, w, d, self.num_classes, bn_eps=self.backbone.bn_eps)
         self._table = probe.param_table()
@@ -161,6 +161,7 @@ class YOLODetector_Disparity_V1(nn.Module):
         if eng is None:
             eng = HipDetector(N, H, W, self.widen_factor, self.deepen_factor, self.num_classes,
                               bn_eps=self.backbone.bn_eps, stereo=stereo)
+            eng.multi_label = self.multi_label
             self._engines[key] = eng
         ver = self._weights_version()
         if self._uploaded.get(key) != ver:

@@ -80,6 +80,7 @@ class HipDetector:
         check(self.lib.st_detector_create(C.byref(cfg), C.byref(h)), 'st_detector_create')
         self.handle = h
         self.num_classes = int(num_classes)
+        self.multi_label = True      # test_cfg.multi_label (several classes): False = one candidate per prior (its best class)
         self._finalized = False
         self._ws = None
         self._dec_ws = None
@@ -208,8 +209,10 @@ class HipDetector:
                                (h.value * w.value * ld.value, w.value * ld.value, ld.value, 1), off)
 
     def head_levels(self, head_out):
-        """Per level (N, h*w, 8) views: [cls, x, y, w, h, obj, -, -]."""
-        return [head_out[off:off + self.batch * h * w * 8].view(self.batch, h * w, 8)
+        """Per level (N, h*w, row) views: [cls.., x, y, w, h, obj, padding]; row = st_head_row_floats(num_classes) (8 for
+        the shipped 1..3-class heads)."""
+        hr = self.head_row
+        return [head_out[off:off + self.batch * h * w * hr].view(self.batch, h * w, hr)
                 for h, w, _, off in self.levels]
 
     def head_nchw(self, head_out):
@@ -218,13 +221,17 @@ class HipDetector:
         nc = self.num_classes
         cls, reg, obj = [], [], []
         for (h, w, _, _), rows in zip(self.levels, self.head_levels(head_out)):
-            x = rows.view(self.batch, h, w, 8).permute(0, 3, 1, 2)
+            x = rows.view(self.batch, h, w, self.head_row).permute(0, 3, 1, 2)
             cls.append(x[:, 0:nc])
             reg.append(x[:, nc:nc + 4])
             obj.append(x[:, nc + 4:nc + 5])
         return cls, reg, obj
 
     # ---- decode + NMS ------------------------------------------------------------------------
+    @property
+    def head_row(self):
+        return int(self.lib.st_head_row_floats(self.num_classes))
+
     def decode_desc(self, score_thr, iou_thr, max_det, ori_shape, scale_factor=(1.0, 1.0), pad_param=None,
                     nms_mask_rows=0):
         d = StDecodeDesc()
@@ -241,6 +248,7 @@ class HipDetector:
         d.ori_h, d.ori_w = float(ori_shape[0]), float(ori_shape[1])
         d.nms_mask_rows = int(nms_mask_rows)
         d.num_classes = self.num_classes
+        d.single_label = 0 if self.multi_label else 1
         return d
 
     def decode_nms(self, head_out, score_thr=0.01, iou_thr=0.5, max_det=1000, ori_shape=None,

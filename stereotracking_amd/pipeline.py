@@ -93,7 +93,7 @@ class StereoDensePipeline:
     def __init__(self, batch, ori_shape=(720, 1280), widen_factor=0.5, deepen_factor=0.33, num_classes=1,
                  stereo=True, max_disp=192, feat_stride=4, temperature=32.0, score_thr=0.01, iou_thr=0.5,
                  max_det=1000, baseline=0.25, focal_length=640, pad_size_divisor=32, agg_layers=0, agg3d_layers=0,
-                 split_bf16=None):
+                 split_bf16=None, multi_label=True):
         """max_det: rows of the fixed-size detection buffer per frame.  The reference applies NO cap on the
         kept boxes (yolox_style=True => max_per_img = len(results)), so this is a
         capacity, not a threshold: `run()` reports `overflow` whenever a frame kept more boxes than fit, and
@@ -124,6 +124,7 @@ class StereoDensePipeline:
         self.baseline, self.focal_length = float(baseline), float(focal_length)
         self.det = HipDetector(self.batch, self.height, self.width, widen_factor, deepen_factor, num_classes,
                                stereo=self.stereo)
+        self.det.multi_label = bool(multi_label)     # several classes: test_cfg.multi_label
         self._bufs = None
 
     # ---- parameters ------------------------------------------------------------------------------

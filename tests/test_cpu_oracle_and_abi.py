@@ -28,7 +28,47 @@ def test_library_exports_every_declared_symbol(stlib):
     for n in names:
         assert hasattr(stlib, n), f'{n} declared in include/stereotrack.h but not exported'
         assert n in _lib._PROTOS, f'{n} has no ctypes prototype'
-    assert stlib.st_version() == 400      # ST_VERSION of include/stereotrack.h (also keys the tuning cache)
+    assert stlib.st_version() == 410      # ST_VERSION of include/stereotrack.h (also keys the tuning cache)
+
+
+@pytest.mark.parametrize('nc,multi_label', [(3, False), (6, True), (6, False), (80, False)])
+def test_oracle_wide_head_and_single_label_decode_matches_torch_formulation(nc, multi_label):
+    """Heads wider than 3 classes (rows of head_row_floats(nc) floats) and test_cfg.multi_label=False (one candidate per
+    prior: the class of its largest score) through oracle_decode_nms_gen == the independent torch formulation: same
+    priors, labels and order, floats to 1e-5."""
+    rng = np.random.RandomState(60 + nc)
+    N, H, W = 2, 96, 160
+    hr = c_oracle.head_row_floats(nc)
+    assert hr == (8 if nc <= 3 else (nc + 8) // 4 * 4) and hr >= nc + 5
+    levels, off = [], 0
+    for s_ in (8, 16, 32):
+        levels.append((H // s_, W // s_, s_, off))
+        off += N * (H // s_) * (W // s_) * hr
+    head = np.full(off, np.nan, np.float32)
+    for h, w, s_, o in levels:
+        rows = head[o:o + N * h * w * hr].reshape(N, h * w, hr)
+        rows[..., :nc] = rng.normal(-1.5, 2.0, rows.shape[:2] + (nc,))
+        rows[..., nc:nc + 2] = rng.normal(0, 1.0, rows.shape[:2] + (2,))
+        rows[..., nc + 2:nc + 4] = rng.normal(0.6, 0.7, rows.shape[:2] + (2,))
+        rows[..., nc + 4] = rng.normal(-1.0, 2.0, rows.shape[:2])
+    r0 = head[:N * levels[0][0] * levels[0][1] * hr].reshape(N, -1, hr)
+    r0[0, 5, :nc + 5] = r0[0, 4, :nc + 5]
+    r0[0, 7, :nc] = r0[0, 7, :nc].max()        # every class ties for the best score: the first one wins
+    M = 1500
+    b, sc, lab, pri, cnt = c_oracle.decode_nms(head, N, levels, 0.05, 0.5, M, (H - 6, W), num_classes=nc,
+                                               multi_label=multi_label)
+    ref = torch_decode_nms_multiclass(head, N, levels, 0.05, 0.5, (H - 6, W), nc, hr, multi_label)
+    assert cnt.min() > 30
+    for n in range(N):
+        k = int(cnt[n])
+        assert k == len(ref[n][0]) <= M
+        assert np.array_equal(pri[n, :k], ref[n][0]) and np.array_equal(lab[n, :k], ref[n][1])
+        assert np.abs(b[n, :k] - ref[n][2]).max() < 1e-3 and np.abs(sc[n, :k] - ref[n][3]).max() < 1e-5
+        if not multi_label:
+            assert len(set(pri[n, :k].tolist())) == k
+    if not multi_label:
+        hit = [i for i in range(int(cnt[0])) if pri[0, i] == 7]
+        assert not hit or lab[0, hit[0]] == 0
 
 
 def test_struct_sizes_match_the_library(stlib):
@@ -239,14 +279,14 @@ def test_oracle_detector_golden():
         assert np.abs(r.numpy() - ref).max() <= 1e-4 * max(1.0, np.abs(ref).max())
 
 
-def torch_decode_nms_multiclass(head, N, levels, score_thr, iou_thr, ori_shape, nc):
+def torch_decode_nms_multiclass(head, N, levels, score_thr, iou_thr, ori_shape, nc, hr=8, multi_label=True):
     """Independent torch formulation of the multi-class path [upstream-memory: mmyolo predict_by_feat with
-    multi_label=True, mmdet filter_scores_and_topk, mmcv batched_nms offset trick]."""
+    multi_label=True / False, mmdet filter_scores_and_topk, mmcv batched_nms offset trick]."""
     outs = []
     for n in range(N):
         rows, priors, strides = [], [], []
         for h, w, s, off in levels:
-            r = torch.from_numpy(head[off:off + N * h * w * 8].reshape(N, h * w, 8)[n])
+            r = torch.from_numpy(head[off:off + N * h * w * hr].reshape(N, h * w, hr)[n])
             ys, xs = torch.meshgrid(torch.arange(h), torch.arange(w), indexing='ij')
             priors.append(torch.stack([xs.reshape(-1) * s, ys.reshape(-1) * s], -1).float())
             strides.append(torch.full((h * w,), float(s)))
@@ -256,7 +296,12 @@ def torch_decode_nms_multiclass(head, N, levels, score_thr, iou_thr, ori_shape, 
         xy = r[:, nc:nc + 2] * s[:, None] + p
         wh = r[:, nc + 2:nc + 4].exp() * s[:, None]
         boxes = torch.cat([xy - wh / 2, xy + wh / 2], -1)
-        valid = torch.nonzero(scores > score_thr)                                      # row-major (prior, class)
+        if not multi_label:      # predict_by_feat: scores, labels = scores.max(1, keepdim=True); then the threshold
+            best, lab1 = scores.max(1)
+            keep1 = torch.nonzero(best > score_thr)[:, 0]
+            valid = torch.stack([keep1, lab1[keep1]], 1)
+        else:
+            valid = torch.nonzero(scores > score_thr)                                  # row-major (prior, class)
         sc = scores[valid[:, 0], valid[:, 1]]
         order = torch.sort(sc, descending=True, stable=True)[1]
         pri, lab, sc = valid[order, 0], valid[order, 1], sc[order]

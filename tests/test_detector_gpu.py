@@ -44,6 +44,30 @@ def test_detector_head_parity(widen, N, H, W, cuda):
         assert e_gpu <= 1e-3
 
 
+@pytest.mark.parametrize('nc', [3, 5, 80])
+def test_detector_head_parity_several_classes(nc, cuda):
+    """num_classes > 1: the prediction convs run un-fused into head rows of st_head_row_floats(nc) floats
+    (8 up to 3 classes, nc + 5 rounded up to 4 beyond: base config _base_/yolox_s_8x8_mmyolo.py:40-51 with another
+    num_classes); class logits, box and objectness columns within 1e-3 of the oracle head."""
+    det = HipDetector(2, 96, 160, 0.375, 0.33, nc)
+    sd = synthetic_state_dict(det.param_table(), seed=nc)
+    det.load_state_dict(sd)
+    ora = OracleDetector(0.33, 0.375, nc).eval()
+    missing, unexpected = ora.load_state_dict(sd, strict=False)
+    assert not unexpected and all(k.endswith('num_batches_tracked') for k in missing)
+    batch = synthetic_batch([0, 1], 80, 160, 64)
+    with torch.no_grad():
+        ref_rows = head_to_rows(*ora(batch))
+    head = det.forward(batch['img'].to(cuda), batch['disp_postp'].to(cuda))
+    torch.cuda.synchronize()
+    assert det.head_row == (8 if nc <= 3 else (nc + 5 + 3) // 4 * 4)
+    for rows, ref in zip(det.head_levels(head), ref_rows):
+        assert rows.shape[-1] == det.head_row and ref.shape[-1] == nc + 5
+        assert rel_err(rows[..., :nc + 5].cpu(), ref) <= 1e-3
+    cls, reg, obj = det.head_nchw(head)
+    assert cls[0].shape[1] == nc and reg[0].shape[1] == 4 and obj[0].shape[1] == 1
+
+
 def test_backbone_taps_match_oracle(cuda):
     det, ora = build_pair(0.375, 0.33, 1, 96, 160)
     batch = synthetic_batch([3], 80, 160, 64)
