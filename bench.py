@@ -676,6 +676,7 @@ def main():
                    'parallelism': (f'frames sharded x{world}, one all-gather of detections per step ({backend})'
                                    if world > 1 else 'single process, no process group (no collective in the step)'),
                    'ranks_seen': ranks_seen, 'hw_queues': hw_queues,
+                   'tuning_plan': os.path.relpath(pipe.tuning_source, ROOT) if os.path.isabs(str(getattr(pipe, 'tuning_source', ''))) else str(getattr(pipe, 'tuning_source', None)),
                    'detections_kept_rank0': counts, 'max_det': pipe.max_det, 'detections_overflow': False},
         'sustained': sustained,
     }
