@@ -250,6 +250,13 @@ int st_detector_forward_phase(StDetector* det, int phase, const float* img_dev,
 int st_detector_forward_phase0_raw(StDetector* det, const unsigned char* const* left_frames_host,
                                    const unsigned char* const* right_frames_host, int h, int w, float pad_value,
                                    void* workspace_dev, size_t workspace_bytes, st_stream_t stream);
+/* st_detector_forward (the disparity-INPUT configuration, the reference's shipped one) with the image as RAW frames:
+ * img_frames_host = HOST array of `batch` device pointers to uint8 [3][h][w] frames, converted + padded inside the RGB
+ * stem (see st_stem_focus_conv_u8); disp_dev = the fp32 (N,3,H,W) disparity input as before.  Bit-identical to
+ * st_pack_raw_frames + st_detector_forward. */
+int st_detector_forward_raw(StDetector* det, const unsigned char* const* img_frames_host, int h, int w,
+                            float pad_value, const float* disp_dev, void* workspace_dev, size_t workspace_bytes,
+                            st_stream_t stream, float* head_out_dev);
 /* Per-op timing for bench.py / profiling.  When enabled every op (focus pack, conv, spp) of the
  * following forwards is bracketed by hipEvents on the caller's stream; st_detector_op_times
  * synchronises on them and returns, per op: elapsed ms, kind (0 focus, 1 conv, 2 spp), the kernel

@@ -70,6 +70,7 @@ _PROTOS = {
     'st_head_row_floats': (_i, [_i]),
     'st_png_unfilter': (_i, [_vp, _i, _i, _i, _vp]),
     'st_stem_focus_conv_u8': (_i, [_vp, _i, _i, _i, _i, _i, _f, _vp, _vp, _i, _vp, _i, _i, _i, _vp]),
+    'st_detector_forward_raw': (_i, [_vp, _vp, _i, _i, _f, _vp, _vp, _sz, _vp, _vp]),
     'st_detector_forward_phase0_raw': (_i, [_vp, _vp, _vp, _i, _i, _f, _vp, _sz, _vp]),
     'st_pack_raw_frames': (_i, [_vp, _i, _i, _i, _i, _i, _f, _vp, _vp]),
     'st_detector_set_split': (_i, [_vp, _i]),

@@ -925,6 +925,26 @@ extern "C" int st_detector_forward_phase0_raw(StDetector* det, const unsigned ch
   return rc;
 }
 
+// The whole forward of the disparity-INPUT configuration (the reference's shipped one: precomputed disparity maps) with
+// the image as RAW uint8 frames: as st_detector_forward, the RGB stem reading the frames itself.
+extern "C" int st_detector_forward_raw(StDetector* det, const unsigned char* const* img_frames_host, int h, int w,
+                                       float pad_value, const float* disp_dev, void* workspace_dev,
+                                       size_t workspace_bytes, st_stream_t stream, float* head_out_dev) {
+  if (!det) return set_error(ST_ERR_INVALID, "st_detector_forward_raw: null detector");
+  if (!det->finalized) return set_error(ST_ERR_STATE, "st_detector_forward_raw: call st_detector_finalize first");
+  ST_REQUIRE(img_frames_host && disp_dev && workspace_dev && head_out_dev, "st_detector_forward_raw: null pointer");
+  ST_REQUIRE(!det->cfg.with_right_branch, "st_detector_forward_raw: detector was built for stereo; use st_detector_forward_phase0_raw");
+  if (workspace_bytes < det->ws_floats * sizeof(float))
+    return set_error(ST_ERR_WORKSPACE, "st_detector_forward_raw: workspace %zu < required %zu", workspace_bytes,
+                     det->ws_floats * sizeof(float));
+  det->raw_inputs[0] = StemRawInput{img_frames_host, h, w, pad_value};
+  const float* inputs[3] = {nullptr, disp_dev, nullptr};
+  const int rc = run_ops(det, 0, 1, inputs, static_cast<float*>(workspace_dev), head_out_dev,
+                         static_cast<hipStream_t>(stream));
+  det->raw_inputs[0] = StemRawInput{nullptr, 0, 0, 0.f};
+  return rc;
+}
+
 // Per-op timing for bench.py / profiling: when enabled, every op of the next forward is bracketed
 // by hipEvents on the caller's stream.  st_detector_op_times synchronises on those events.
 extern "C" int st_detector_set_timing(StDetector* det, int enable) {

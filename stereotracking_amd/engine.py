@@ -160,14 +160,25 @@ class HipDetector:
         return self._ws
 
     def forward(self, img, disp, head_out=None):
-        """img, disp: (N,3,H,W) float32 CUDA tensors -> flat head buffer (see include/stereotrack.h)."""
+        """img, disp: (N,3,H,W) float32 CUDA tensors -> flat head buffer (see include/stereotrack.h).  img may be a
+        RawChunk (uint8 frames: the RGB stem casts + pads them itself, st_detector_forward_raw)."""
+        raw = isinstance(img, RawChunk)
         for t, nm in ((img, 'img'), (disp, 'disp_postp')):
+            if raw and nm == 'img':
+                if len(img) != self.batch:
+                    raise ValueError(f'raw chunk of {len(img)} frames for a batch-{self.batch} context')
+                continue
             _require_cuda(t, nm)
             if tuple(t.shape) != (self.batch, 3, self.height, self.width):
                 raise ValueError(f'{nm}: expected {(self.batch, 3, self.height, self.width)}, got {tuple(t.shape)}')
         ws = self._workspace(img.device)
         if head_out is None:
             head_out = torch.empty(self.head_floats, dtype=torch.float32, device=img.device)
+        if raw:
+            check(self.lib.st_detector_forward_raw(self.handle, img.table(), img.hw[0], img.hw[1], img.pad_value, ptr(disp),
+                                                   ptr(ws), ws.numel(), current_stream(), ptr(head_out)),
+                  'st_detector_forward_raw')
+            return head_out
         check(self.lib.st_detector_forward(self.handle, ptr(img), ptr(disp), ptr(ws), ws.numel(),
                                            current_stream(), ptr(head_out)), 'st_detector_forward')
         return head_out

@@ -537,8 +537,12 @@ class OCSORT_Disparity(nn.Module):
         st['submitted'] += 1
         s, e = st['chunks'][ci]
         a = b = None
-        if stereo and self.raw_stem and isinstance(st['img'], RawFrames) and isinstance(st['second'], RawFrames):
-            a, b = st['img'].raw_chunk(s, e, B, runner), st['second'].raw_chunk(s, e, B, runner)
+        if self.raw_stem and isinstance(st['img'], RawFrames):
+            if stereo and isinstance(st['second'], RawFrames):
+                a, b = st['img'].raw_chunk(s, e, B, runner), st['second'].raw_chunk(s, e, B, runner)
+            elif not stereo:      # disparity-input configuration: the image raw, the fp32 disparity as it is
+                a = st['img'].raw_chunk(s, e, B, runner)
+                b = self._padded(st['second'], s, e, B) if a is not None else None
         if a is None or b is None:      # fp32 tensors (or frames the stem cannot read raw): cast + pad as a pass of its own
             a, b = self._padded(st['img'], s, e, B), self._padded(st['second'], s, e, B)
         holder = {}

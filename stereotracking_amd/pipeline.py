@@ -228,15 +228,15 @@ class StereoDensePipeline:
         return depth, scales, sboxes
 
     def run(self, img, right=None, disp_postp=None):
-        """img (N,3,H,W) fp32 CUDA; stereo: right (N,3,H,W); mono: disp_postp (N,3,H,W).  Stereo also takes img and
-        right as two engine.RawChunk (N uint8 frames each): the stem kernels cast + pad them while staging their windows.
+        """img (N,3,H,W) fp32 CUDA; stereo: right (N,3,H,W); mono: disp_postp (N,3,H,W).  img (and, stereo, right)
+        may be engine.RawChunk (N uint8 frames each): the stem kernels cast + pad them while staging their windows.
         Returns a dict of device tensors (no host sync; the context's PERSISTENT buffers, overwritten by its next run): boxes (N,M,4) unscaled xyxy, scores, labels,
         prior_idx, counts (TRUE number kept per frame), overflow (N,) bool = counts > M, depth, scales,
         scaled_boxes, disp_postp, head.  Rows past min(counts, M) are zero (prior_idx -1).  With disp_buffers > 1 the
         stereo module's disp_postp is buffer `self.disp_slot` of the ring (see _buffers)."""
         if isinstance(img, RawChunk):
-            if not (self.stereo and isinstance(right, RawChunk)):
-                raise ValueError('raw uint8 chunks feed the stereo pipeline (left and right)')
+            if self.stereo and not isinstance(right, RawChunk):
+                raise ValueError('the stereo pipeline takes left AND right as raw uint8 chunks (or both as fp32 tensors)')
         else:
             _require_cuda(img, 'img')
         b = self._buffers(img.device)

@@ -144,13 +144,14 @@ class RawFrameUploader:
 
     def __init__(self, batch, ori_hw, device, use_right=True, slots=2, raw_stem=None):
         self.B, (self.h, self.w) = int(batch), (int(ori_hw[0]), int(ori_hw[1]))
-        # raw_stem (stereo only; default on when the geometry allows): the uploaded uint8 frames are handed to the
-        # pipeline as engine.RawChunk pairs - the stem kernels cast + pad them while staging their windows, no pack
+        # raw_stem (default on when the geometry allows): the uploaded uint8 frames are handed to the
+        # pipeline as engine.RawChunk (stereo: left and right; disparity input: the image - the uint16 codes still go
+        # through st_pack_raw_inputs, the disparity stem reads fp32) - the stem kernels cast + pad them while staging their windows, no pack
         # pass and no fp32 image in HBM.  Each batch then gets device byte buffers of its own (the stems read them
         # later, on a context's stream), the page-locked staging slots still alternate.
-        self.raw_stem = bool(use_right and self.w % 4 == 0 and int(batch) <= 32) if raw_stem is None else bool(raw_stem)
-        if self.raw_stem and not (use_right and self.w % 4 == 0 and int(batch) <= 32):
-            raise ValueError('raw_stem needs the stereo form, width % 4 == 0 and batch <= 32')
+        self.raw_stem = bool(self.w % 4 == 0 and int(batch) <= 32) if raw_stem is None else bool(raw_stem)
+        if self.raw_stem and not (self.w % 4 == 0 and int(batch) <= 32):
+            raise ValueError('raw_stem needs width % 4 == 0 and batch <= 32')
         self.H, self.W = (self.h + 31) // 32 * 32, (self.w + 31) // 32 * 32
         self.dev, self.use_right = torch.device(device), bool(use_right)
         self.copy_stream = torch.cuda.Stream(device=self.dev)
@@ -223,18 +224,27 @@ class RawFrameUploader:
         if self.raw_stem:
             from .engine import RawChunk
             dev_bytes = {}
-            for src, name in zip(srcs, ('left', 'right')):
-                dev_bytes[name] = torch.empty((self.B, 3, self.h, self.w), dtype=torch.uint8, device=self.dev)
-                dev_bytes[name].record_stream(self.copy_stream)
+            for src, name in zip(srcs, ('left', 'right', 'code')):
+                if src is not None:
+                    dev_bytes[name] = torch.empty(tuple(src.shape), dtype=src.dtype, device=self.dev)
+                    dev_bytes[name].record_stream(self.copy_stream)
             self.copy_stream.wait_stream(cur)     # a recycled block's last reader was enqueued before this point
             with torch.cuda.stream(self.copy_stream):
-                for src, name in zip(srcs, ('left', 'right')):
-                    dev_bytes[name].copy_(src, non_blocking=True)
-                    self.bytes_uploaded += src.numel() * src.element_size()
+                for src, name in zip(srcs, ('left', 'right', 'code')):
+                    if src is not None:
+                        dev_bytes[name].copy_(src, non_blocking=True)
+                        self.bytes_uploaded += src.numel() * src.element_size()
                 sl['uploaded'].record(self.copy_stream)
             cur.wait_event(sl['uploaded'])
             sl['used'] = True
-            return dict(img=RawChunk(list(dev_bytes['left']), 114.0), right=RawChunk(list(dev_bytes['right']), 114.0))
+            out = dict(img=RawChunk(list(dev_bytes['left']), 114.0))
+            if self.use_right:
+                out['right'] = RawChunk(list(dev_bytes['right']), 114.0)
+            else:        # uint16 disparity codes -> fp32 px (x3 planes): the disparity stem reads fp32
+                out['disp_postp'] = torch.empty(self.B, 3, self.H, self.W, dtype=torch.float32, device=self.dev)
+                check(load().st_pack_raw_inputs(None, ptr(dev_bytes['code']), self.B, self.h, self.w, self.H, self.W, 114.0,
+                                                None, ptr(out['disp_postp']), None, current_stream()), 'st_pack_raw_inputs')
+            return out
         with torch.cuda.stream(self.copy_stream):
             if sl['used']:
                 self.copy_stream.wait_event(sl['consumed'])   # the pack kernel that last read the device bytes is done
