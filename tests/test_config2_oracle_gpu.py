@@ -111,6 +111,7 @@ def test_config2_sequence_against_oracle_pipeline_and_oracle_tracker(seq, name, 
     dsamp_gpu = o8['disp_postp'][:, 0, ::ds, ::ds].cpu().double().numpy()
     torch.cuda.synchronize()
     e64 = dict(gpu_box=0.0, cpu_box=0.0, gpu_score=0.0, cpu_score=0.0, gpu_disp=0.0, cpu_disp=0.0)
+    box_err_g, box_err_c = [], []
     for t in range(8):
         d64, d32 = g[f'dsamp64_{t}'], g[f'dsamp{t}'].astype(np.float64)
         den = np.maximum(1.0, np.abs(d64))
@@ -150,6 +151,12 @@ def test_config2_sequence_against_oracle_pipeline_and_oracle_tracker(seq, name, 
         es_c = float(np.abs(g[f'scores{t}'][ir].astype(np.float64) - s64).max())
         e64.update(gpu_box=max(e64['gpu_box'], eb_g), cpu_box=max(e64['cpu_box'], eb_c),
                    gpu_score=max(e64['gpu_score'], es_g), cpu_score=max(e64['cpu_score'], es_c))
+        # the whole DISTRIBUTION of the per-box distances (the maxima above are set by a handful of boxes on ambiguous
+        # matches: alternative kernel plans move the white-noise maximum between 1.05e-3 and 1.9e-3)
+        b64t = torch.as_tensor(b64, dtype=torch.float64)
+        den = b64t.abs().clamp(min=1.0)
+        box_err_g.append(((det.bboxes[common].cpu().double() - b64t).abs() / den).max(dim=1).values.numpy())
+        box_err_c.append(((torch.as_tensor(g[f'boxes{t}'][ir], dtype=torch.float64) - b64t).abs() / den).max(dim=1).values.numpy())
         tot['frames_box_over_1e3_gpu'] += eb_g > 1e-3
         tot['frames_box_over_1e3_cpu32'] += eb_c > 1e-3
         pc = gp[common]
@@ -212,6 +219,11 @@ def test_config2_sequence_against_oracle_pipeline_and_oracle_tracker(seq, name, 
     rec['totals'] = {k: int(v) for k, v in tot.items()}
     rec['worst'] = worst
     rec['vs_fp64'] = e64
+    eg, ec = np.concatenate(box_err_g), np.concatenate(box_err_c)
+    rec['box_vs_fp64_distribution'] = {
+        who: dict(boxes=int(len(e)), mean=float(e.mean()), p50=float(np.percentile(e, 50)), p99=float(np.percentile(e, 99)),
+                  p999=float(np.percentile(e, 99.9)), over_1e3=int((e > 1e-3).sum()), max=float(e.max()))
+        for who, e in (('gpu', eg), ('cpu32', ec))}
     noise = e64['gpu_score'] + e64['cpu_score']     # MEASURED: two evaluations this far from fp64 may order a pair either way
     rec['score_noise_measured'] = noise
     rec['ids_seen'] = len(phi)
