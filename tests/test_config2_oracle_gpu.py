@@ -239,6 +239,11 @@ def test_config2_sequence_against_oracle_pipeline_and_oracle_tracker(seq, name, 
     # (white noise) - no worse than 1.25 x the oracle's own distance
     for q in ('box', 'score', 'disp'):
         assert e64['gpu_' + q] <= max(1e-3, 1.25 * e64['cpu_' + q]), (q, e64)
+    # ... and not only at the maximum: the whole distribution of the per-box distance to float64 is no wider than the
+    # fp32 oracle's (mean and 99.9 % quantile within 1.25 x, both far inside 1e-3)
+    dist = rec['box_vs_fp64_distribution']
+    assert dist['gpu']['mean'] <= 1.25 * dist['cpu32']['mean'] and dist['gpu']['p999'] <= 1e-3, dist
+    assert dist['gpu']['p999'] <= max(2e-4, 1.5 * dist['cpu32']['p999']), dist
     assert worst['score'] <= 1e-3 and worst['track_box'] <= 1e-3, worst
     if seq == 'blurred':
         assert worst['box'] <= 1e-3, worst                    # gpu vs the fp32 oracle directly, as in round 3
