@@ -149,8 +149,25 @@ class YOLODetector_Disparity_V1(nn.Module):
         return True
 
     def init_weights(self):
-        """The reference's ColorPretrained init fetches a URL (yolo_detector_disparity_v1.py:144-166);
-        offline it is skipped, weights come from load_state_dict."""
+        """init_cfg = dict(type='ColorPretrained', checkpoint=<LOCAL file>): load a colour-image detector checkpoint and
+        start the disparity branch (`disp_stem`, `disp_stage1`) from the RGB branch's weights, non-strict - reference
+        yolo_detector_disparity_v1.py:144-166.  `type='Pretrained'`: the plain non-strict load.  The shipped config
+        names a URL (:46), which cannot be fetched offline: that raises with the instruction to pass a local path;
+        without init_cfg nothing happens (weights come from load_state_dict / load_checkpoint)."""
+        cfg = self.init_cfg
+        if not cfg:
+            return None
+        if isinstance(cfg, (list, tuple)):
+            cfg = cfg[0]
+        kind = cfg.get('type')
+        if kind not in ('ColorPretrained', 'Pretrained'):
+            return None
+        from .checkpoint import _state_dict_of, color_pretrained_state_dict, load_matching, read_checkpoint
+        sd = dict(_state_dict_of(read_checkpoint(cfg.get('checkpoint'), trusted=bool(cfg.get('trusted', False)))))
+        if kind == 'ColorPretrained':
+            sd = color_pretrained_state_dict(sd)
+        self.init_report = load_matching(self, sd, strict=False)
+        return self.init_report
 
     def _weights_version(self):
         return tuple(t._version for t in self.state_dict(keep_vars=True).values())

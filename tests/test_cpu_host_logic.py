@@ -423,3 +423,55 @@ def test_config3_sharded_sequence_world8_gloo(T):
         assert (start, stop) == (min(rank * chunk, T), min(rank * chunk + chunk, T))
         assert equal, f'rank {rank}: gathered records differ from the unsharded stream'
         assert ids == ref_ids and sums == ref_sums, f'rank {rank}: tracks differ from the single-process run'
+
+
+def test_checkpoint_loading_and_color_pretrained_init(tmp_path):
+    """load_checkpoint (the runner's `load_from`: non-strict, `module.` prefix stripped, size mismatches reported and
+    skipped) and the detector's ColorPretrained init (yolo_detector_disparity_v1.py:144-166: the disparity branch starts
+    from the RGB branch's stem / stage1 weights); a URL raises with the instruction to pass a local file."""
+    from stereotracking_amd import mot  # noqa: F401
+    from stereotracking_amd.checkpoint import load_checkpoint
+    from stereotracking_amd.config import Config
+    from stereotracking_amd.registry import MODELS
+    cfg = Config.fromfile(os.path.join(ROOT, 'configs', 'stereo_tracking', 'ocsort', 'yolox_s_mmyolo_mot_airdrone_disp.py'))
+    det_cfg = dict(cfg.model.detector)
+    det_cfg.pop('init_cfg', None)
+    src = MODELS.build(det_cfg)
+    g = torch.Generator().manual_seed(3)
+    colour = {}
+    for k, v in src.state_dict().items():
+        if 'disp_' in k or not v.is_floating_point():
+            continue                      # a colour-image checkpoint has no disparity branch
+        colour[k] = torch.randn(v.shape, generator=g)
+    k_cls = 'bbox_head.head_module.multi_level_conv_cls.0.weight'
+    colour[k_cls] = torch.randn(80, *colour[k_cls].shape[1:], generator=g)          # an 80-class (COCO) head
+    colour['ema_something.not_in_the_model'] = torch.zeros(3)
+    path = str(tmp_path / 'yolox_colour.pth')
+    torch.save(dict(state_dict={'module.' + k: v for k, v in colour.items()}, meta=dict(epoch=300)), path)
+
+    plain = MODELS.build(det_cfg)
+    ck = load_checkpoint(plain, path)
+    rep = ck['_load_report']
+    assert ck['meta']['epoch'] == 300 and [m[0] for m in rep['mismatched']] == [k_cls]
+    assert rep['unexpected'] == ['ema_something.not_in_the_model']
+    assert all('disp_' in k or k == k_cls or k.endswith('num_batches_tracked') for k in rep['missing'])
+    assert torch.equal(plain.state_dict()['backbone.stem.conv.conv.weight'], colour['backbone.stem.conv.conv.weight'])
+    assert float(plain.state_dict()['backbone.disp_stem.conv.conv.weight'].abs().sum()) == 0     # untouched
+
+    stripped = str(tmp_path / 'yolox_colour_plain_keys.pth')
+    torch.save(dict(state_dict=colour), stripped)
+    det = MODELS.build(dict(det_cfg, init_cfg=dict(type='ColorPretrained', checkpoint=stripped)))
+    rep = det.init_weights()
+    sd = det.state_dict()
+    for a, b in (('backbone.stem.conv.conv.weight', 'backbone.disp_stem.conv.conv.weight'),
+                 ('backbone.stage1.0.conv.weight', 'backbone.disp_stage1.0.conv.weight'),
+                 ('backbone.stage1.1.final_conv.bn.running_var', 'backbone.disp_stage1.1.final_conv.bn.running_var')):
+        assert torch.equal(sd[a], colour[a]) and torch.equal(sd[b], colour[a]), (a, b)
+    assert not any('disp_' in k and not k.endswith('num_batches_tracked') for k in rep['missing'])
+    assert [m[0] for m in rep['mismatched']] == [k_cls]
+    assert torch.equal(sd['backbone.stage2.0.conv.weight'], colour['backbone.stage2.0.conv.weight'])
+
+    shipped = MODELS.build(dict(cfg.model.detector))          # the shipped init_cfg names a URL
+    if shipped.init_cfg:
+        with pytest.raises(RuntimeError, match='local|download'):
+            shipped.init_weights()
