@@ -494,7 +494,7 @@ __device__ __forceinline__ void split3_f32x4(const f32x4 x, u32x2& hi, u32x2& mi
 
 // SBK = k per chunk: 32 (two k16 steps, one workgroup of 128 x 128 per CU) or 16 (one step, half the LDS: two
 // co-resident workgroups cover each other's barrier and fragment-read latency)
-template <int TM, int TN, int WM, int WN, int PW, int SBK>
+template <int TM, int TN, int WM, int WN, int PW, int SBK, bool SACC>
 __global__ __launch_bounds__(64 * WM * WN, (SBK == 16 ? 2 : 1)) void conv_split_kernel(ConvKArgs p) {
   constexpr int NT = 64 * WM * WN;
   constexpr int BM = 32 * TM * WM;
@@ -620,6 +620,20 @@ __global__ __launch_bounds__(64 * WM * WN, (SBK == 16 ? 2 : 1)) void conv_split_
     for (int j = 0; j < TN; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  // SACC: the five small term products accumulate in a register set of their own and join the leading products once, at
+  // the end - their low bits are not rounded away against a running sum 2^8..2^16 times larger.  Measured against float64
+  // at the path's layer shapes (tools/split_check.py): rms distance 0.37 x that of the exact-fp32 MFMA instance (one
+  // accumulator for all six products: 0.86 x); same speed wherever the second set fits in registers (every instance but
+  // the 128x128 k16 one, which keeps the single chain).
+  f32x16 accS[SACC ? TM : 1][SACC ? TN : 1];
+  if (SACC) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) accS[SACC ? i : 0][SACC ? j : 0][r] = 0.f;
+  }
 
   const int nchunks = p.Kpad / SBK;
   load_chunk(0, 0);
@@ -656,13 +670,23 @@ __global__ __launch_bounds__(64 * WM * WN, (SBK == 16 ? 2 : 1)) void conv_split_
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j) {   // smallest terms first, the leading product last
-          f32x16 c = acc[i][j];
-          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][1], fb[j][1], c, 0, 0, 0);
-          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][2], fb[j][0], c, 0, 0, 0);
-          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][2], c, 0, 0, 0);
-          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][1], fb[j][0], c, 0, 0, 0);
-          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][1], c, 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][0], c, 0, 0, 0);
+          if (SACC) {
+            f32x16 c = accS[SACC ? i : 0][SACC ? j : 0];
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][1], fb[j][1], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][2], fb[j][0], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][2], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][1], fb[j][0], c, 0, 0, 0);
+            accS[SACC ? i : 0][SACC ? j : 0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][1], c, 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][0], acc[i][j], 0, 0, 0);
+          } else {
+            f32x16 c = acc[i][j];
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][1], fb[j][1], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][2], fb[j][0], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][2], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][1], fb[j][0], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][1], c, 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][0], c, 0, 0, 0);
+          }
           if (more1) {
             const int slot = (st * TM + i) * TN + j;
 #pragma unroll
@@ -699,6 +723,12 @@ __global__ __launch_bounds__(64 * WM * WN, (SBK == 16 ? 2 : 1)) void conv_split_
       if (m2) do_chunk(kc, S0{}, T{}, T{}); else if (m1) do_chunk(kc, S0{}, T{}, F{}); else do_chunk(kc, S0{}, F{}, F{});
     }
   }
+  if (SACC) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) acc[i][j] += accS[SACC ? i : 0][SACC ? j : 0];
+  }
   conv_epilogue<TM, TN>(p, acc, m0, n0, wm, wn, l31, lh, BM, BN);
 }
 
@@ -707,7 +737,8 @@ static int launch_split(const ConvKArgs& a, int m_tiles, hipStream_t stream) {
   constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
   constexpr size_t lds = (size_t)2 * 3 * (BM + BN) * (SBK + 8) * 2;   // two buffers of three bf16 images
   static bool attr_set = false;
-  auto kern = conv_split_kernel<TM, TN, WM, WN, PW, SBK>;
+  constexpr bool SACC = !(TM == 2 && TN == 2 && SBK == 16);   // the 128x128 k16 instance has no registers for it
+  auto kern = conv_split_kernel<TM, TN, WM, WN, PW, SBK, SACC>;
   if (!attr_set) {
     ST_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

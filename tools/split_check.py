@@ -53,6 +53,20 @@ def run(name, N, H, W, Cin, Cout, k=1, stride=1, res=False, up=False, split=None
         print(f'{name:36s} no exact-fp32 reference instance for Cout={Cout}', flush=True)
         return
     scale = ref[0].abs().max().item()
+    # float64 reference of the same layer (torch conv2d in double on the GPU): how far are the exact-fp32 instance and
+    # the split instances from it (max and rms, relative to the output scale)
+    import torch.nn.functional as F
+    y64 = F.conv2d(x.double().permute(0, 3, 1, 2), w.double().to(dev), b.double().to(dev), stride, k // 2)
+    y64 = F.silu(y64)
+    if res:
+        y64 = (y64 + r.double().permute(0, 3, 1, 2)) * 0.5
+    y64 = y64.permute(0, 2, 3, 1)
+
+    def vs64(t):
+        e = (t.double() - y64).abs()
+        return e.max().item() / scale, (e.pow(2).mean().sqrt().item()) / scale
+    m0, r0_ = vs64(ref[0])
+    print(f'{name:36s} exact-fp32 instance {v_ref}: vs fp64 max {m0:.2e} rms {r0_:.2e}', flush=True)
     for v in (50, 51, 52, 53, 54, 55):
         worst, nondet = 0.0, False
         first = None
@@ -72,7 +86,9 @@ def run(name, N, H, W, Cin, Cout, k=1, stride=1, res=False, up=False, split=None
                 nondet = True
         else:
             flag = 'FAIL' if worst > 1e-4 or nondet else 'ok'
-            print(f'{name:36s} variant {v}: max err {worst:.2e} of scale {scale:.2f} {"NONDETERMINISTIC " if nondet else ""}{flag}', flush=True)
+            m1, r1 = vs64(first)
+            print(f'{name:36s} variant {v}: max err {worst:.2e} of scale {scale:.2f} {"NONDETERMINISTIC " if nondet else ""}{flag}'
+                  f'   vs fp64 max {m1:.2e} rms {r1:.2e}', flush=True)
 
 
 run('op13 3x3s2 64->128 @184x320', 8, 184, 320, 64, 128, 3, 2)
