@@ -5,6 +5,7 @@
 set -e
 TAG=${1:-r04}
 OUT=gpurun_out/prof_$TAG
+rm -rf $OUT      # stale traces of an earlier call must not be picked up below
 mkdir -p $OUT
 # the plan every entry point shares: the committed configs/tuning/mi355x.json (measured here when absent)
 export ST_TUNE_CACHE=$PWD/configs/tuning/mi355x.json
