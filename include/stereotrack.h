@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define ST_VERSION 410
+#define ST_VERSION 420
 
 enum {
   ST_OK = 0,
@@ -205,6 +205,12 @@ typedef struct StDetectorConfig {
                               * reference loader yields, loading_disparity.py:85-86, and what
                               * st_disp_upsample_pack writes): the disparity stem then reads plane 0 only with
                               * plane-summed weights (K = 36 instead of 108).  0 = generic 3-plane input. */
+  int rgb_only;         /* 1 = the single-branch detector of the reference's second stereo config
+                         * (configs/stereo_tracking/ocsort/yolox_s_mmyolo_mot_airdrone.py:40-42: backbone
+                         * `mmtrack.CSPDarknet`, mmtrack/models/backbones/csp_darknet.py:8-13 - forward reads x['img']
+                         * only): no disp_stem / disp_stage1 parameters or launches, no branch average; stage2 consumes
+                         * the RGB stage-1 features.  The disparity input of the forward calls may then be NULL (the
+                         * MOT shell still consumes the disparity for the per-box depth, ocsort_disparity.py:82-83). */
 } StDetectorConfig;
 
 int st_detector_create(const StDetectorConfig* cfg, StDetector** out);

@@ -151,6 +151,36 @@ class YOLOXCSPDarknet_Disparity_V1(nn.Module):
         return self.stage1(self.stem(img))
 
 
+class CSPDarknetRGB(nn.Module):
+    """Reference `mmtrack.CSPDarknet` (mmtrack/models/backbones/csp_darknet.py:8-13): mmdet 3.0.0rc4's CSPDarknet with
+    `forward(x) = super().forward(x['img'])` - the backbone of the RGB-only stereo config
+    (configs/stereo_tracking/ocsort/yolox_s_mmyolo_mot_airdrone.py:42).  mmdet's class [upstream-memory] builds
+    `stem` = Focus(3, 64w, 3) and `stage1..4` = [ConvModule(3x3, s2), (SPPBottleneck in stage4), CSPLayer] from the same
+    P5 arch table as the two-branch class (:66-69 there), i.e. the image branch of it with the same state_dict keys."""
+
+    arch = YOLOXCSPDarknet_Disparity_V1.arch
+
+    def __init__(self, deepen_factor=0.33, widen_factor=0.5, out_indices=(2, 3, 4)):
+        super().__init__()
+        self.out_indices = out_indices
+        self.stem = Focus(3, make_divisible(64, widen_factor))
+        for idx, setting in enumerate(self.arch):
+            self.add_module(f'stage{idx + 1}',
+                            nn.Sequential(*YOLOXCSPDarknet_Disparity_V1._stage(setting, widen_factor, deepen_factor)))
+
+    def forward(self, x):
+        y = self.stem(x['img'])   # csp_darknet.py:11
+        outs = []
+        for i in (1, 2, 3, 4):
+            y = getattr(self, f'stage{i}')(y)
+            if i in self.out_indices:
+                outs.append(y)
+        return tuple(outs)
+
+    def stage1_features(self, img):
+        return self.stage1(self.stem(img))
+
+
 class YOLOXPAFPN(nn.Module):
     """mmyolo 0.2.0 YOLOXPAFPN on BaseYOLONeck.forward (configs/_base_/yolox_s_8x8_mmyolo.py:30-37)."""
 
@@ -221,9 +251,11 @@ class _Head(nn.Module):
 class OracleDetector(nn.Module):
     """YOLODetector_Disparity_V1._forward, mmtrack/models/detectors/yolo_detector_disparity_v1.py:127-142."""
 
-    def __init__(self, deepen_factor=0.33, widen_factor=0.5, num_classes=1):
+    def __init__(self, deepen_factor=0.33, widen_factor=0.5, num_classes=1, rgb_only=False):
+        """rgb_only: the reference's second stereo config - detector `mmyolo.YOLODetector` over `mmtrack.CSPDarknet`
+        (yolox_s_mmyolo_mot_airdrone.py:40-42): same neck / head, single-branch backbone."""
         super().__init__()
-        self.backbone = YOLOXCSPDarknet_Disparity_V1(deepen_factor, widen_factor)
+        self.backbone = (CSPDarknetRGB if rgb_only else YOLOXCSPDarknet_Disparity_V1)(deepen_factor, widen_factor)
         self.neck = YOLOXPAFPN(deepen_factor, widen_factor)
         self.bbox_head = _Head(num_classes=num_classes, widen_factor=widen_factor)
 

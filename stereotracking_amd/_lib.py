@@ -41,6 +41,7 @@ class StDetectorConfig(C.Structure):
         ('struct_size', C.c_int), ('widen_factor', C.c_float), ('deepen_factor', C.c_float),
         ('num_classes', C.c_int), ('batch', C.c_int), ('height', C.c_int), ('width', C.c_int),
         ('bn_eps', C.c_double), ('with_right_branch', C.c_int), ('disp_planes_identical', C.c_int),
+        ('rgb_only', C.c_int),
     ]
 
 

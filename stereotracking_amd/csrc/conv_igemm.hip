@@ -745,7 +745,6 @@ static int launch_split(const ConvKArgs& a, int m_tiles, hipStream_t stream) {
     attr_set = true;
   }
   dim3 grid((unsigned)(m_tiles * a.n_tiles)), block(64 * WM * WN);
-  note_bf16_mfma_launch();   // kernels with v_pk_fma_f32 op_sel broadcasts switch to scalar FMAs from now on (st_common.cpp)
   hipLaunchKernelGGL(kern, grid, block, lds, stream, a);
   ST_CHECK_HIP(hipGetLastError());
   return ST_OK;

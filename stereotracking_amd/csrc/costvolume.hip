@@ -18,6 +18,7 @@
 // (__shfl_xor 16, 32), so the D x H x W volume is only written when the caller asks for it.
 #include <algorithm>
 #include <cstdint>
+#include <cstdlib>
 
 #include "st_common.h"
 
@@ -148,11 +149,14 @@ static inline int cvt_row(int n) {  // >= n, multiple of 4, (row / 4) odd
   return r;
 }
 
-// PK: diagonal accumulator pairs on v_pk_fma_f32 with the R operand broadcast by op_sel (see below).  PK = false
-// evaluates the same fmaf chains with scalar v_fma_f32 - bit-identical, ~7 % slower - and is what the launcher picks once
-// a kernel issuing BF16 MFMAs has been launched in this process: v_pk_fma_f32 with op_sel returns wrong sums while
-// bf16 MFMAs of another wave execute on the same SIMD (measured: tools/cv_stress.py).
-template <int DG, bool PK>
+// FMA: how the diagonal accumulator pairs (below) are evaluated.  Every form runs the same fmaf chains, bit-identical:
+//   0  two scalar v_fma_f32 per pair;
+//   1  one v_pk_fma_f32 with the R operand broadcast by op_sel / op_sel_hi (what the compiler makes of f32x2{r, r});
+//   2  one v_pk_fma_f32 WITHOUT op_sel on an explicit (r, r) register pair (one v_mov pair per window element and channel).
+// Round 4 found form 1 returning wrong sums while bf16 MFMAs of another kernel execute on the chip (tools/cv_stress.py,
+// tools/micro/pkfma_corun.hip): the product library instantiates and launches form 0 only (see
+// st_costvolume_softargmin; tests/test_cpu_oracle_and_abi.py checks the built code object for packed-fp32 op_sel).
+template <int DG, int FMA>
 __global__ __launch_bounds__(128) void costvolume_tiled_kernel(const float* __restrict__ featL,
                                                                const float* __restrict__ featR, int Hf, int Wf,
                                                                int C, int ld, int D, float temperature, int rowL,
@@ -271,6 +275,17 @@ __global__ __launch_bounds__(128) void costvolume_tiled_kernel(const float* __re
         lv[h ^ 1] = *reinterpret_cast<const f32x4*>(lp + cn * rowL);
 #pragma unroll
         for (int q = 0; q < NW / 4; ++q) rv[h ^ 1][q] = *reinterpret_cast<const f32x4*>(rp + cn * rowR + 4 * q);
+        // FMA == 2: window elements 2 .. DG+2 as explicit (r, r) pairs; the empty asm makes each pair an opaque value, so
+        // the compiler has to build it in a register pair of its own instead of folding the broadcast into op_sel
+        f32x2 rdup[FMA == 2 ? DG + 1 : 1];
+        if (FMA == 2) {
+#pragma unroll
+          for (int i = 2; i <= DG + 2; ++i) {
+            const float r = rv[h][i >> 2][i & 3];
+            rdup[i - 2] = f32x2{r, r};
+            asm volatile("" : "+v"(rdup[i - 2]));
+          }
+        }
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
           const f32x2 lpair = q ? f32x2{lv[h][2], lv[h][3]} : f32x2{lv[h][0], lv[h][1]};
@@ -278,7 +293,8 @@ __global__ __launch_bounds__(128) void costvolume_tiled_kernel(const float* __re
           for (int k = 0; k < DG - 1; ++k) {
             const int i = DG + 2 * q - k;   // window index of x + 2q - d0 - k (= that of x + 2q + 1 - d0 - (k + 1))
             const float r = rv[h][i >> 2][i & 3];
-            if (PK) accd[q][k] = __builtin_elementwise_fma(lpair, f32x2{r, r}, accd[q][k]);
+            if (FMA == 1) accd[q][k] = __builtin_elementwise_fma(lpair, f32x2{r, r}, accd[q][k]);
+            else if (FMA == 2) accd[q][k] = __builtin_elementwise_fma(lpair, rdup[i - 2], accd[q][k]);
             else accd[q][k] = f32x2{fmaf(lpair[0], r, accd[q][k][0]), fmaf(lpair[1], r, accd[q][k][1])};
           }
           constexpr int ilo = 1, ihi = DG + 1;   // + 2q: windows of (p = 2q, k = DG-1) and (p = 2q+1, k = 0)
@@ -485,11 +501,23 @@ extern "C" int st_costvolume_softargmin(const float* featL_dev, const float* fea
     ST_REQUIRE(totalt + 8 < (1ll << 31), "st_costvolume_softargmin: grid too large");
     const int per_xcd = (int)((totalt + 7) / 8);
     const dim3 gridt((unsigned)(8 * per_xcd)), blockt(128);
-    const bool scalar_fma = bf16_mfma_in_use();
+    // The product launches form 0 (scalar FMAs) ALWAYS: form 1 goes wrong whenever a bf16 MFMA of any kernel on the chip -
+    // this library's split instances, another library, another process - executes beside it (the op_sel / op_sel_hi
+    // bit of a v_pk_fma_f32 source is dropped for single steps: tools/micro/pkfma_corun.hip reproduces it in registers,
+    // profiles/r05_pkfma_corun.txt), and form 2 costs more vector instructions than form 0.  No process state, no
+    // launch-order dependence; forms 1 / 2 exist in the tools build for the reproducer only.
+#ifdef ST_ABLATION
+    int fma_mode = 0;
+    if (const char* e = getenv("ST_CV_FMA")) fma_mode = atoi(e);   // tools/cv_stress.py
 #define ST_CVT_LAUNCH(DGV)                                                                                    \
   do {                                                                                                         \
-    if (scalar_fma) ST_CVT_LAUNCH_I(DGV, false); else ST_CVT_LAUNCH_I(DGV, true);                              \
+    if (fma_mode == 1) ST_CVT_LAUNCH_I(DGV, 1);                                                                \
+    else if (fma_mode == 2) ST_CVT_LAUNCH_I(DGV, 2);                                                           \
+    else ST_CVT_LAUNCH_I(DGV, 0);                                                                              \
   } while (0)
+#else
+#define ST_CVT_LAUNCH(DGV) ST_CVT_LAUNCH_I(DGV, 0)
+#endif
 #define ST_CVT_LAUNCH_I(DGV, PKV)                                                                             \
   do {                                                                                                         \
     auto kern = costvolume_tiled_kernel<DGV, PKV>;                                                             \

@@ -426,8 +426,11 @@ int StDetector::build() {
   cur_phase = 1;
   TRef s1_left = s1;
   s1_left.N = N;  // first N images of the stacked batch
+  const bool rgb_only = cfg.rgb_only != 0;   // mmtrack.CSPDarknet (csp_darknet.py:8-13): the image branch alone
   TRef packed_disp, stem_disp;
-  if (fused_stem) {
+  if (rgb_only) {
+    // no disparity branch: nothing to stage
+  } else if (fused_stem) {
     stem_disp = new_tensor(N, H2, W2, c1);
     const int pcs = packed_convmodules({"backbone.disp_stem.conv"}, 12, {c1}, 3);
     convs[pcs].stem = true;
@@ -438,15 +441,17 @@ int StDetector::build() {
     Op f; f.type = Op::FOCUS; f.focus_input = 1; f.out1 = packed_disp; f.focus_batch_off = 0; f.phase = 1;
     ops.push_back(f);
   }
-  TRef y = new_tensor(N, H4, W4, c2);
+  TRef y = rgb_only ? s1_left : new_tensor(N, H4, W4, c2);
   TRef C3 = catTD1.slice(c3, c3);
   begin_group(sbatch, N);
   {
-    TRef dstem = fused_stem ? window(stem_disp, sbatch)
-                            : convmodule("backbone.disp_stem.conv", window(packed_disp, sbatch), c1, 3, 1);
-    TRef d1c = convmodule("backbone.disp_stage1.0", dstem, c2, 3, 2);
-    // y = (o_stem + o_disp_stem) / 2   (csp_darknet_disparity_v1.py:184)
-    csp_layer("backbone.disp_stage1.1", d1c, c2, n1, true, window(y, sbatch), window(s1_left, sbatch), 0.5f);
+    if (!rgb_only) {
+      TRef dstem = fused_stem ? window(stem_disp, sbatch)
+                              : convmodule("backbone.disp_stem.conv", window(packed_disp, sbatch), c1, 3, 1);
+      TRef d1c = convmodule("backbone.disp_stage1.0", dstem, c2, 3, 2);
+      // y = (o_stem + o_disp_stem) / 2   (csp_darknet_disparity_v1.py:184)
+      csp_layer("backbone.disp_stage1.1", d1c, c2, n1, true, window(y, sbatch), window(s1_left, sbatch), 0.5f);
+    }
     TRef s2c = convmodule("backbone.stage2.0", window(y, sbatch), c3, 3, 2);
     csp_layer("backbone.stage2.1", s2c, c3, n2, true, window(C3, sbatch));
   }
@@ -867,7 +872,7 @@ extern "C" int st_detector_forward(StDetector* det, const float* img_dev, const 
                                    float* head_out_dev) {
   if (!det) return set_error(ST_ERR_INVALID, "st_detector_forward: null detector");
   if (!det->finalized) return set_error(ST_ERR_STATE, "st_detector_forward: call st_detector_finalize first");
-  ST_REQUIRE(img_dev && disp_dev && workspace_dev && head_out_dev, "st_detector_forward: null pointer");
+  ST_REQUIRE(img_dev && (disp_dev || det->cfg.rgb_only) && workspace_dev && head_out_dev, "st_detector_forward: null pointer");
   ST_REQUIRE(!det->cfg.with_right_branch, "st_detector_forward: detector was built for stereo; use st_detector_forward_phase");
   if (workspace_bytes < det->ws_floats * sizeof(float))
     return set_error(ST_ERR_WORKSPACE, "st_detector_forward: workspace %zu < required %zu", workspace_bytes,
@@ -895,7 +900,7 @@ extern "C" int st_detector_forward_phase(StDetector* det, int phase, const float
     ST_REQUIRE(img_dev != nullptr, "st_detector_forward_phase: null img");
     ST_REQUIRE(!det->cfg.with_right_branch || right_dev != nullptr, "st_detector_forward_phase: right image required");
   } else {
-    ST_REQUIRE(disp_dev && head_out_dev, "st_detector_forward_phase: null disp/head pointer");
+    ST_REQUIRE((disp_dev || det->cfg.rgb_only) && head_out_dev, "st_detector_forward_phase: null disp/head pointer");
   }
   const float* inputs[3] = {img_dev, disp_dev, right_dev};
   return run_ops(det, phase, phase, inputs, static_cast<float*>(workspace_dev), head_out_dev,
@@ -932,7 +937,7 @@ extern "C" int st_detector_forward_raw(StDetector* det, const unsigned char* con
                                        size_t workspace_bytes, st_stream_t stream, float* head_out_dev) {
   if (!det) return set_error(ST_ERR_INVALID, "st_detector_forward_raw: null detector");
   if (!det->finalized) return set_error(ST_ERR_STATE, "st_detector_forward_raw: call st_detector_finalize first");
-  ST_REQUIRE(img_frames_host && disp_dev && workspace_dev && head_out_dev, "st_detector_forward_raw: null pointer");
+  ST_REQUIRE(img_frames_host && (disp_dev || det->cfg.rgb_only) && workspace_dev && head_out_dev, "st_detector_forward_raw: null pointer");
   ST_REQUIRE(!det->cfg.with_right_branch, "st_detector_forward_raw: detector was built for stereo; use st_detector_forward_phase0_raw");
   if (workspace_bytes < det->ws_floats * sizeof(float))
     return set_error(ST_ERR_WORKSPACE, "st_detector_forward_raw: workspace %zu < required %zu", workspace_bytes,

@@ -24,14 +24,6 @@ int set_error(int code, const char* fmt, ...) {
   return code;
 }
 
-// Process-wide: has any kernel that issues BF16 MFMAs (the split-operand conv instances) been launched?  Kernels built
-// on v_pk_fma_f32 with op_sel operand broadcast (the cost volume) were measured to return WRONG sums while bf16 MFMAs of
-// another wave execute on the same SIMD (tools/cv_stress.py: 232 of 240 volumes differ; with scalar v_fma_f32: 0), so
-// they switch to their scalar-FMA instantiation (bit-identical results) from the first such launch on.
-static std::atomic<int> g_bf16_mfma_in_use{0};
-void note_bf16_mfma_launch() { g_bf16_mfma_in_use.store(1, std::memory_order_relaxed); }
-bool bf16_mfma_in_use() { return g_bf16_mfma_in_use.load(std::memory_order_relaxed) != 0; }
-
 }  // namespace st
 
 extern "C" int st_version(void) { return ST_VERSION; }

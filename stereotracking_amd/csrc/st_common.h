@@ -20,9 +20,6 @@ struct StemRawInput {
   float pad_value;
 };
 
-void note_bf16_mfma_launch();   // a kernel issuing BF16 MFMAs is about to be launched (st_common.cpp)
-bool bf16_mfma_in_use();
-
 inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 // floats per prior in the head buffer: num_classes class logits, x, y, w, h, obj (+ padding to 16-byte rows); 8 for the
 // shipped 1..3-class heads, nc + 5 rounded up to a multiple of 4 beyond (st_head_row_floats)

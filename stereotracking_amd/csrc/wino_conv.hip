@@ -303,7 +303,10 @@ __device__ __forceinline__ void wino_conv3x3_body(const WinoArgs& p, int b_) {
         if (RES) {
           const unsigned roff = ok ? (unsigned)((m * p.res_ld + p.res_off + co) * 4) : 0x80000000u;
           const f32x4 rv = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rrsrc, roff, 0, 0));
-          v = (v + rv) * p.post_scale;
+          // element by element: as an f32x4 expression this became v_pk_mul_f32 with the scalar broadcast by op_sel_hi -
+          // the one packed-fp32 operand form this library no longer emits (costvolume.hip)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = (v[e] + rv[e]) * p.post_scale;
         }
         const unsigned off = ok ? (unsigned)((m * p.out_ld + p.out_off + co) * 4) : 0x80000000u;
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), orsrc, off, 0, 0);

@@ -3,6 +3,10 @@ strings and accepting the same config kwargs, with every FLOP delegated to the H
 
   YOLODetector_Disparity_V1             mmtrack/models/detectors/yolo_detector_disparity_v1.py:15-166
   YOLOXCSPDarknet_Disparity_V1_MMYOLO   mmtrack/models/backbones/csp_darknet_disparity_v1.py:16-206
+  CSPDarknet (`mmtrack.CSPDarknet`)     mmtrack/models/backbones/csp_darknet.py:8-13 (mmdet's CSPDarknet reading x['img'])
+  YOLODetector (`mmyolo.YOLODetector`)  the detector type of the RGB-only stereo config
+                                        (configs/stereo_tracking/ocsort/yolox_s_mmyolo_mot_airdrone.py:40-42 over
+                                        configs/_base_/yolox_s_8x8_mmyolo.py:17-19)
   YOLOXPAFPN / YOLOXHead / YOLOXHeadModule   mmyolo 0.2.0 (configs/_base_/yolox_s_8x8_mmyolo.py:30-69)
 
 The nn.Modules below only HOLD parameters (named exactly like the reference state_dict, so
@@ -64,6 +68,36 @@ class YOLOXCSPDarknet_Disparity_V1_MMYOLO(_ParamHolder):
         self.bn_eps = float(norm_cfg.get('eps', 1e-5))
 
 
+@MODELS.register_module(name=['CSPDarknet'])
+class CSPDarknet(_ParamHolder):
+    """`mmtrack.CSPDarknet` (reference csp_darknet.py:8-13): mmdet 3.0.0rc4's CSPDarknet whose forward takes the MOT
+    shell's input dict and reads `x['img']` only - the backbone of the reference's RGB-only stereo configuration
+    (yolox_s_mmyolo_mot_airdrone.py:42; kwargs merged in from _base_/yolox_s_8x8_mmyolo.py:20-28).  Same module tree and
+    state_dict keys as the image branch of the two-branch class (stem, stage1..stage4; stage4 = conv, SPPBottleneck,
+    CSPLayer): the HIP plan is the two-branch plan without disp_stem / disp_stage1 and without the average."""
+
+    def __init__(self, arch='P5', deepen_factor=1.0, widen_factor=1.0, out_indices=(2, 3, 4), frozen_stages=-1,
+                 use_depthwise=False, arch_ovewrite=None, spp_kernal_sizes=(5, 9, 13), conv_cfg=None, norm_cfg=None,
+                 act_cfg=None, norm_eval=False, init_cfg=None):
+        super().__init__()
+        norm_cfg = norm_cfg or dict(type='BN', momentum=0.03, eps=0.001)
+        act_cfg = act_cfg or dict(type='Swish')
+        unsupported = []
+        if arch != 'P5': unsupported.append(f'arch={arch}')
+        if arch_ovewrite: unsupported.append('arch_ovewrite')
+        if use_depthwise: unsupported.append('use_depthwise=True')
+        if conv_cfg: unsupported.append(f'conv_cfg={conv_cfg}')
+        if tuple(spp_kernal_sizes) != (5, 9, 13): unsupported.append(f'spp_kernal_sizes={spp_kernal_sizes}')
+        if tuple(out_indices) != (2, 3, 4): unsupported.append(f'out_indices={out_indices}')
+        if norm_cfg.get('type') not in ('BN', 'SyncBN'): unsupported.append(f'norm {norm_cfg}')
+        if act_cfg.get('type') not in ('SiLU', 'Swish'): unsupported.append(f'act {act_cfg}')   # x * sigmoid(x) both
+        if unsupported:
+            raise NotImplementedError('HIP CSPDarknet supports the shipped stereo configs only; unsupported: '
+                                      + ', '.join(unsupported))
+        self.deepen_factor, self.widen_factor = float(deepen_factor), float(widen_factor)
+        self.bn_eps = float(norm_cfg.get('eps', 1e-5))
+
+
 @MODELS.register_module()
 class YOLOXPAFPN(_ParamHolder):
     def __init__(self, in_channels=(256, 512, 1024), out_channels=256, deepen_factor=1.0, widen_factor=1.0,
@@ -104,7 +138,9 @@ class YOLOXHead(_ParamHolder):
 
 @MODELS.register_module(name=['YOLODetector_Disparity_V1'])
 class YOLODetector_Disparity_V1(nn.Module):
-    """Two-branch YOLOX detector; same constructor / method surface as the reference class."""
+    """YOLOX detector over the HIP launch plan; same constructor / method surface as the reference class.  Which plan
+    runs (two-branch, or the image branch alone) follows from the BACKBONE class, as in the reference; the subclass
+    `YOLODetector` below is the detector type of the RGB-only config."""
 
     def __init__(self, backbone, neck, bbox_head, train_cfg=None, test_cfg=None, data_preprocessor=None,
                  init_cfg=None, use_syncbn=True):
@@ -120,6 +156,7 @@ class YOLODetector_Disparity_V1(nn.Module):
         if (self.neck.widen_factor, self.neck.deepen_factor) != (w, d) or self.bbox_head.head_module.widen_factor != w:
             raise ValueError('backbone / neck / head widen+deepen factors must agree')
         self.widen_factor, self.deepen_factor = w, d
+        self.rgb_only = isinstance(self.backbone, CSPDarknet)
         self.num_classes = self.bbox_head.num_classes
         if not 1 <= self.num_classes <= 1024:
             raise ValueError('num_classes must be in [1, 1024]')
@@ -127,7 +164,7 @@ class YOLODetector_Disparity_V1(nn.Module):
         # candidate) or multi_label=False (one candidate per prior: its best class) - both in the decode kernel
         self.multi_label = bool(self.test_cfg.get('multi_label', True))
         # parameter tree from the library's own table (graph shapes do not matter for the table)
-        probe = HipDetector(1, 32, 32, w, d, self.num_classes, bn_eps=self.backbone.bn_eps)
+        probe = HipDetector(1, 32, 32, w, d, self.num_classes, bn_eps=self.backbone.bn_eps, rgb_only=self.rgb_only)
         self._table = probe.param_table()
         del probe
         bn_prefixes = set()
@@ -177,7 +214,7 @@ class YOLODetector_Disparity_V1(nn.Module):
         eng = self._engines.get(key)
         if eng is None:
             eng = HipDetector(N, H, W, self.widen_factor, self.deepen_factor, self.num_classes,
-                              bn_eps=self.backbone.bn_eps, stereo=stereo)
+                              bn_eps=self.backbone.bn_eps, stereo=stereo, rgb_only=self.rgb_only)
             eng.multi_label = self.multi_label
             self._engines[key] = eng
         ver = self._weights_version()
@@ -200,12 +237,17 @@ class YOLODetector_Disparity_V1(nn.Module):
         N, _, H, W = img.shape
         if batch_inputs.get('disp_postp') is None:
             if self.stereo is None or batch_inputs.get('right') is None:
+                if self.rgb_only:   # the single-branch detector needs the image alone
+                    eng = self._engine(N, H, W)
+                    return eng, eng.forward(img, None)
                 raise TypeError("need 'disp_postp', or 'right' plus a StereoCostVolume module")
             eng = self._engine(N, H, W, stereo=True)
             disp = self.stereo.compute(eng, img, batch_inputs['right'].float().contiguous(), valid_hw or (H, W))
             batch_inputs['disp_postp'] = disp
             return eng, eng.forward_phase(1, disp=disp)
         eng = self._engine(N, H, W)
+        if self.rgb_only:    # csp_darknet.py:11: the backbone reads x['img']; disp_postp is for the depth step only
+            return eng, eng.forward(img, None)
         return eng, eng.forward(img, batch_inputs['disp_postp'].float().contiguous())
 
     # ---- reference API -----------------------------------------------------------------------------
@@ -264,3 +306,11 @@ class YOLODetector_Disparity_V1(nn.Module):
         if mode == 'tensor':
             return self._forward(inputs, data_samples)
         raise NotImplementedError(f'mode={mode}')
+
+
+@MODELS.register_module(name=['YOLODetector'])
+class YOLODetector(YOLODetector_Disparity_V1):
+    """`mmyolo.YOLODetector` as configs/stereo_tracking/ocsort/yolox_s_mmyolo_mot_airdrone.py:40-42 uses it (type from
+    configs/_base_/yolox_s_8x8_mmyolo.py:19): the single-stage detector whose backbone `mmtrack.CSPDarknet` picks
+    `x['img']` out of the MOT shell's input dict (csp_darknet.py:8-13).  Same HIP plan machinery as the two-branch class;
+    with the two-branch backbone configured it behaves exactly like `YOLODetector_Disparity_V1`."""

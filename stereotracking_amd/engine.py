@@ -64,18 +64,22 @@ class HipDetector:
     """
 
     def __init__(self, batch, height, width, widen_factor=0.5, deepen_factor=0.33, num_classes=1,
-                 bn_eps=1e-3, stereo=False, disp_replicated=None):
+                 bn_eps=1e-3, stereo=False, disp_replicated=None, rgb_only=False):
         """disp_replicated: the three planes of disp_postp are identical (a 3-channel repeat of one map), so the
         disparity stem may read plane 0 with plane-summed weights.  Default: True for stereo contexts (the
-        disparity then comes from st_disp_upsample_pack, which writes exactly that), False otherwise."""
+        disparity then comes from st_disp_upsample_pack, which writes exactly that), False otherwise.
+        rgb_only: the single-branch detector of the reference's RGB configuration (backbone `mmtrack.CSPDarknet`,
+        csp_darknet.py:8-13): no disparity branch in the plan or the parameter table; `disp` of the forward calls is
+        ignored and may be None."""
         self.lib = _lib.load()
         self.batch, self.height, self.width = int(batch), int(height), int(width)
         self.stereo = bool(stereo)
+        self.rgb_only = bool(rgb_only)
         self.widen_factor, self.deepen_factor = float(widen_factor), float(deepen_factor)
         self.disp_replicated = self.stereo if disp_replicated is None else bool(disp_replicated)
         cfg = StDetectorConfig(C.sizeof(StDetectorConfig), float(widen_factor), float(deepen_factor),
                                int(num_classes), self.batch, self.height, self.width, float(bn_eps),
-                               int(self.stereo), int(self.disp_replicated))
+                               int(self.stereo), int(self.disp_replicated), int(self.rgb_only))
         h = C.c_void_p()
         check(self.lib.st_detector_create(C.byref(cfg), C.byref(h)), 'st_detector_create')
         self.handle = h
@@ -163,7 +167,11 @@ class HipDetector:
         """img, disp: (N,3,H,W) float32 CUDA tensors -> flat head buffer (see include/stereotrack.h).  img may be a
         RawChunk (uint8 frames: the RGB stem casts + pads them itself, st_detector_forward_raw)."""
         raw = isinstance(img, RawChunk)
+        if self.rgb_only:
+            disp = None          # not an input of the single-branch plan
         for t, nm in ((img, 'img'), (disp, 'disp_postp')):
+            if nm == 'disp_postp' and self.rgb_only:
+                continue
             if raw and nm == 'img':
                 if len(img) != self.batch:
                     raise ValueError(f'raw chunk of {len(img)} frames for a batch-{self.batch} context')

@@ -386,7 +386,8 @@ class OCSORT_Disparity(nn.Module):
                 baseline=self.baseline, focal_length=self.focal_length,
                 pad_size_divisor=getattr(self.data_preprocessor, 'pad_size_divisor', 32) or 32,
                 agg_layers=sm.agg_layers if stereo else 0, agg3d_layers=sm.agg3d_layers if stereo else 0,
-                split_bf16=self.split_bf16, multi_label=getattr(det, 'multi_label', True))
+                split_bf16=self.split_bf16, multi_label=getattr(det, 'multi_label', True),
+                rgb_only=getattr(det, 'rgb_only', False))
             for p in runner.pipes:     # the track-box depth reads run k's disparity while later runs are in flight
                 p.disp_buffers = self.queue_depth + 1
             ent = self._dense[key] = [runner, None]

@@ -93,7 +93,7 @@ class StereoDensePipeline:
     def __init__(self, batch, ori_shape=(720, 1280), widen_factor=0.5, deepen_factor=0.33, num_classes=1,
                  stereo=True, max_disp=192, feat_stride=4, temperature=32.0, score_thr=0.01, iou_thr=0.5,
                  max_det=1000, baseline=0.25, focal_length=640, pad_size_divisor=32, agg_layers=0, agg3d_layers=0,
-                 split_bf16=None, multi_label=True):
+                 split_bf16=None, multi_label=True, rgb_only=False):
         """max_det: rows of the fixed-size detection buffer per frame.  The reference applies NO cap on the
         kept boxes (yolox_style=True => max_per_img = len(results)), so this is a
         capacity, not a threshold: `run()` reports `overflow` whenever a frame kept more boxes than fit, and
@@ -122,8 +122,11 @@ class StereoDensePipeline:
         self.temperature = float(temperature)
         self.score_thr, self.iou_thr, self.max_det = float(score_thr), float(iou_thr), int(max_det)
         self.baseline, self.focal_length = float(baseline), float(focal_length)
+        # rgb_only: the single-branch detector (reference config yolox_s_mmyolo_mot_airdrone.py:40-42, backbone
+        # mmtrack.CSPDarknet); the disparity (loaded, or from the stereo module) is then consumed by box_depth only
+        self.rgb_only = bool(rgb_only)
         self.det = HipDetector(self.batch, self.height, self.width, widen_factor, deepen_factor, num_classes,
-                               stereo=self.stereo)
+                               stereo=self.stereo, rgb_only=self.rgb_only)
         self.det.multi_label = bool(multi_label)     # several classes: test_cfg.multi_label
         self._bufs = None
 
@@ -145,7 +148,7 @@ class StereoDensePipeline:
             return
         import os
         key = (f'v{self.det.lib.st_version()}_b{self.batch}_{self.height}x{self.width}_w{self.det.widen_factor:g}'
-               f'_d{self.det.deepen_factor:g}_s{int(self.stereo)}_a{self.agg_layers}_D{self.D}'
+               f'_d{self.det.deepen_factor:g}_s{int(self.stereo)}{"r" if self.rgb_only else ""}_a{self.agg_layers}_D{self.D}'
                f'_ops{self.det.lib.st_detector_num_ops(self.det.handle)}_{_device_tag()}'
                + ('_split' + os.environ.get('ST_SPLIT_MASK', '') if self.split_bf16 else ''))
         # (the 3-D aggregation layers run on a kernel of their own: no tile choice, not part of the key)
@@ -299,7 +302,8 @@ class InflightPipelines:
         return len(self.pipes)
 
     def __getattr__(self, name):   # geometry / thresholds of the (identical) contexts: batch, max_det, stereo, ...
-        if name in ('batch', 'max_det', 'stereo', 'height', 'width', 'ori_h', 'ori_w', 'agg_layers', 'agg3d_layers', 'split_bf16'):
+        if name in ('batch', 'max_det', 'stereo', 'height', 'width', 'ori_h', 'ori_w', 'agg_layers', 'agg3d_layers', 'split_bf16',
+                    'rgb_only'):
             return getattr(self.pipes[0], name)
         raise AttributeError(name)
 

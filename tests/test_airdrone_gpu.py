@@ -46,9 +46,11 @@ def dataset(tmp_path_factory):
                              data_prefix=dict(img_path='val/'), depth_dir_name='depth')
 
 
-@pytest.mark.parametrize('use_right', [False, True])
-def test_tiny_airdrone_through_reader_pipeline_tracker_metrics(dataset, use_right, cuda):
-    pipe = StereoDensePipeline(4, (H, W), 0.375, 0.33, 1, stereo=use_right, max_disp=D, max_det=256)
+@pytest.mark.parametrize('use_right,rgb_only', [(False, False), (True, False), (False, True), (True, True)])
+def test_tiny_airdrone_through_reader_pipeline_tracker_metrics(dataset, use_right, rgb_only, cuda):
+    """rgb_only: the detector of the reference's RGB-only stereo config (yolox_s_mmyolo_mot_airdrone.py:40-42); the
+    disparity - loaded or computed - still drives the per-box depth and the depth-range filter."""
+    pipe = StereoDensePipeline(4, (H, W), 0.375, 0.33, 1, stereo=use_right, max_disp=D, max_det=256, rgb_only=rgb_only)
     pipe.load_state_dict(synthetic_state_dict(pipe.param_table(), seed=9, prior_prob=0.2, logit_std=2.5), autotune=False)
     videos, gts = ds.load_videos(dataset, use_right)
     assert sorted(videos) == ['seq00', 'seq01', 'seq02'] and all(len(v) == T for v in videos.values())

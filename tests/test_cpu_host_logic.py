@@ -70,7 +70,7 @@ REF_CFG_DIR = '/root/reference/configs/stereo_tracking/ocsort'
 
 
 @pytest.mark.skipif(not os.path.isdir(REF_CFG_DIR), reason='reference tree not present (GPU box)')
-@pytest.mark.parametrize('name', ['yolox_s_mmyolo_mot_airdrone_disp.py'])
+@pytest.mark.parametrize('name', ['yolox_s_mmyolo_mot_airdrone_disp.py', 'yolox_s_mmyolo_mot_airdrone.py'])
 def test_reference_config_files_parse_verbatim_and_build(name):
     """Drop-in check of the plugin surface: the REFERENCE's own config file, read from where it lies
     (with its own `_base_` chain), parses with this repo's loader and `MODELS.build(cfg.model)` yields the HIP-backed
@@ -79,12 +79,20 @@ def test_reference_config_files_parse_verbatim_and_build(name):
     from stereotracking_amd.config import Config
     from stereotracking_amd.registry import MODELS
     cfg = Config.fromfile(os.path.join(REF_CFG_DIR, name))
-    ours = Config.fromfile(CFG)
+    ours = Config.fromfile(os.path.join(os.path.dirname(CFG), name))    # BOTH configs under configs/stereo_tracking
+    rgb_only = not name.endswith('_disp.py')
     assert cfg.model.detector.test_cfg == ours.model.detector.test_cfg       # same merged thresholds
     assert dict(cfg.model.tracker) == dict(ours.model.tracker)
     assert dict(cfg.model.detector.backbone) == dict(ours.model.detector.backbone)
     model = MODELS.build(cfg.model)
-    assert type(model).__name__ == 'OCSORT_Disparity' and type(model.detector).__name__ == 'YOLODetector_Disparity_V1'
+    assert type(model).__name__ == 'OCSORT_Disparity'
+    assert type(model.detector).__name__ == ('YOLODetector' if rgb_only else 'YOLODetector_Disparity_V1')
+    # the RGB-only config: backbone mmtrack.CSPDarknet (csp_darknet.py:8-13) - no disparity-branch parameters at all
+    assert type(model.detector.backbone).__name__ == ('CSPDarknet' if rgb_only else 'YOLOXCSPDarknet_Disparity_V1_MMYOLO')
+    assert model.detector.rgb_only == rgb_only
+    names = [n for n, _ in model.detector._table]
+    assert any('disp_stem' in n or 'disp_stage1' in n for n in names) == (not rgb_only)
+    assert 'backbone.stage4.1.conv2.conv.weight' in names and 'neck.out_layers.2.conv.weight' in names
     assert model.detector.widen_factor == 0.5 and model.detector.deepen_factor == 0.33
     assert model.tracker.match_iou_thr == 0.1 and model.tracker.num_frames_retain == 30
     assert type(model.data_preprocessor).__name__ == 'TrackDataPreprocessor_Disparity_V1'

@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol(stlib):
     for n in names:
         assert hasattr(stlib, n), f'{n} declared in include/stereotrack.h but not exported'
         assert n in _lib._PROTOS, f'{n} has no ctypes prototype'
-    assert stlib.st_version() == 410      # ST_VERSION of include/stereotrack.h (also keys the tuning cache)
+    assert stlib.st_version() == 420      # ST_VERSION of include/stereotrack.h (also keys the tuning cache)
 
 
 @pytest.mark.parametrize('nc,multi_label', [(3, False), (6, True), (6, False), (80, False)])
@@ -420,3 +420,19 @@ def test_oracle_agg3d_equals_conv3d():
     ident = np.zeros((3, 3, 3), np.float32)
     ident[1, 1, 1] = 1.0
     assert np.array_equal(c_oracle.agg3d(vol, ident, 0.0, 0), vol)
+
+
+def test_shipped_code_has_no_packed_fp32_operand_select():
+    """Structural fence of the round-4 wrong-result finding: on MI355X a packed-fp32 VOP3P instruction whose
+    source is selected by op_sel / op_sel_hi (operand broadcast) executes single steps with the bit dropped while bf16
+    MFMAs of ANY kernel run on the chip (tools/micro/pkfma_corun.hip).  The product library must not contain that
+    operand form at all - checked on the built gfx950 code objects, so a compiler that folds a broadcast into op_sel
+    again fails here, on CPU, before anything runs."""
+    import isa_utils
+    from stereotracking_amd import _lib
+    code = isa_utils.disassemble_library(_lib.LIB_PATH)
+    assert len(code) > 100, 'disassembly found too few kernels'
+    n_packed = sum(1 for lines in code.values() for ins in lines if ins.startswith('v_pk_') and '_f32' in ins)
+    assert n_packed > 0          # the Winograd transforms do use packed fp32 (default operand selection)
+    bad = [(sym, ins) for sym, lines in code.items() for ins in lines if ins.startswith('v_pk_') and 'op_sel' in ins]
+    assert not bad, f'{len(bad)} packed instructions with op_sel, e.g. {bad[:3]}'

@@ -11,11 +11,11 @@ from stereotracking_amd.synthetic import synthetic_batch, synthetic_state_dict
 pytestmark = pytest.mark.gpu
 
 
-def build_pair(widen, deepen, N, H, W, seed=0):
-    det = HipDetector(N, H, W, widen, deepen, 1)
+def build_pair(widen, deepen, N, H, W, seed=0, rgb_only=False):
+    det = HipDetector(N, H, W, widen, deepen, 1, rgb_only=rgb_only)
     sd = synthetic_state_dict(det.param_table(), seed=seed)
     det.load_state_dict(sd)
-    ora = OracleDetector(deepen, widen, 1).eval()
+    ora = OracleDetector(deepen, widen, 1, rgb_only=rgb_only).eval()
     missing, unexpected = ora.load_state_dict(sd, strict=False)
     assert not unexpected and all(k.endswith('num_batches_tracked') for k in missing)
     return det, ora
@@ -42,6 +42,36 @@ def test_detector_head_parity(widen, N, H, W, cuda):
         print(f'level {lvl}: gpu-vs-fp64 {e_gpu:.2e}  cpu32-vs-fp64 {e_cpu:.2e}  gpu-vs-cpu32 {rel_err(got, ref):.2e}')
         assert rel_err(got, ref) <= 1e-3
         assert e_gpu <= 1e-3
+
+
+@pytest.mark.parametrize('widen,N,H,W', [(0.5, 2, 192, 320), (0.375, 1, 96, 160)])
+def test_rgb_only_detector_head_and_taps_parity(widen, N, H, W, cuda):
+    """The reference's SECOND stereo config (configs/stereo_tracking/ocsort/yolox_s_mmyolo_mot_airdrone.py:40-42):
+    `mmyolo.YOLODetector` over `mmtrack.CSPDarknet` (csp_darknet.py:8-13, forward reads x['img'] only) = the launch plan
+    without disp_stem / disp_stage1 and without the average.  Head rows and backbone taps against the oracle with the
+    branch disabled (fp32 and fp64); the disparity pointer is NULL for this plan, and a disparity that IS passed changes
+    nothing."""
+    det, ora = build_pair(widen, 0.33, N, H, W, seed=4, rgb_only=True)
+    assert not any('disp_' in n for n, _ in det.param_table())
+    batch = synthetic_batch(list(range(N)), H - 16, W, 64)
+    with torch.no_grad():
+        ref_rows = head_to_rows(*ora(batch))
+        feats = ora.backbone(batch)
+        ref64_rows = head_to_rows(*ora.double()({k: v.double() for k, v in batch.items()}))
+    head = det.forward(batch['img'].to(cuda), None).clone()
+    torch.cuda.synchronize()
+    for name, ref in zip(('stage2', 'stage3', 'stage4'), feats):
+        assert rel_err(det.tap(name).cpu().permute(0, 3, 1, 2), ref) <= 1e-3, name
+    for rows, ref, ref64 in zip(det.head_levels(head), ref_rows, ref64_rows):
+        got = rows[..., :6].cpu()
+        assert rel_err(got, ref) <= 1e-3
+        assert rel_err(got.double(), ref64) <= 1e-3
+    head2 = det.forward(batch['img'].to(cuda), batch['disp_postp'].to(cuda))
+    torch.cuda.synchronize()
+    assert torch.equal(head, head2)
+    # and it is NOT the two-branch result: the same image-branch weights inside the two-branch plan give another head
+    det2, _ = build_pair(widen, 0.33, N, H, W, seed=4)
+    assert not torch.equal(det2.forward(batch['img'].to(cuda), batch['disp_postp'].to(cuda)), head)
 
 
 @pytest.mark.parametrize('nc', [3, 5, 80])

@@ -1,5 +1,6 @@
 """GPU: the HIP path against the committed golden vectors, and the config-built plugin surface
 (MODELS.build -> OCSORT_Disparity.test_step) end to end against the oracle composition."""
+import math
 import os
 
 import numpy as np
@@ -20,6 +21,7 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 GOLD = os.path.join(ROOT, 'tests', 'golden')
 CFG = os.path.join(ROOT, 'configs', 'stereo_tracking', 'ocsort', 'yolox_s_mmyolo_mot_airdrone_disp.py')
+CFG_RGB = os.path.join(ROOT, 'configs', 'stereo_tracking', 'ocsort', 'yolox_s_mmyolo_mot_airdrone.py')
 CFG_STEREO = os.path.join(ROOT, 'configs', 'stereo_tracking', 'ocsort', 'stereo_yolox_s_mot_airdrone_costvolume.py')
 
 
@@ -178,6 +180,51 @@ def test_mot_shell_matches_oracle_composition(cuda):
             assert rel_err(trk.bboxes.cpu(), unscale_boxes_np(rt[:, 2:6], rt[:, 8])) <= 1e-3
             assert set(trk.keys()) >= {'bboxes', 'labels', 'scores', 'scales', 'depth', 'gt_depth', 'instances_id'}
     assert n_tracked > 0, 'the scenario must actually exercise the association step'
+
+
+def test_rgb_only_config_shell_matches_oracle_composition(cuda):
+    """The reference's second config under configs/stereo_tracking (yolox_s_mmyolo_mot_airdrone.py:29-58): detector
+    `mmyolo.YOLODetector` over `mmtrack.CSPDarknet` (image branch only), the SAME OCSORT_Disparity shell, the loaded
+    disparity consumed by the per-box depth alone (ocsort_disparity.py:82-83).  model.test_step frame by frame against
+    the oracle composition with the branch disabled: kept priors equal, boxes / scores within 1e-3, and the depth of the
+    detections (which the tracker's scaled boxes are built from) equal to oracle/depth.py on the oracle's boxes."""
+    from stereotracking_amd.structures import TrackDataSample
+    model, sd, cfg = build_model(CFG_RGB, cuda)
+    assert type(model.detector).__name__ == 'YOLODetector' and model.detector.rgb_only
+    assert not any('disp_' in k for k in model.state_dict())
+    ora = OracleDetector(0.33, 0.375, 1, rgb_only=True).eval()
+    missing, unexpected = ora.load_state_dict(sd, strict=False)
+    assert not unexpected and all(k.endswith('num_batches_tracked') for k in missing)
+    ori = (80, 160)
+    frames = [synthetic_batch([60 + (t // 2)], ori[0], ori[1], 32) for t in range(6)]
+    n_tracked = 0
+    for t, fr in enumerate(frames):
+        sample = TrackDataSample(dict(frame_id=t, ori_shape=ori, img_shape=ori, scale_factor=(1.0, 1.0)))
+        data = dict(inputs=dict(img=[fr['img'][0:1, :, :ori[0]].to(torch.uint8)],
+                                disp_postp=[fr['disp_postp'][0:1, :, :ori[0]]],
+                                disp_mask=[fr['disp_mask'][0:1, :, :ori[0]].to(torch.uint8)]),
+                    data_samples=[sample])
+        out = model.test_step(data)[0]
+        torch.cuda.synchronize()
+        img_seen = torch.nn.functional.pad(fr['img'][0:1, :, :ori[0]].to(torch.uint8).float(), [0, 0, 0, 16])
+        boxes, scores, prior, depth, scales, sboxes = oracle_frame(ora, img_seen, fr['disp_postp'][0:1], ori)
+        det = out.pred_det_instances
+        assert len(det) == len(boxes) and len(boxes) > 0
+        assert np.array_equal(det.prior_idx.cpu().numpy(), prior), 'kept prior indices differ'
+        assert rel_err(det.bboxes.cpu(), boxes) <= 1e-3
+        assert (det.scores.cpu() - scores).abs().max() <= 1e-3
+        trk = out.pred_track_instances
+        n_tracked += len(trk)
+        if len(trk):
+            assert set(trk.keys()) >= {'bboxes', 'labels', 'scores', 'scales', 'depth', 'gt_depth', 'instances_id'}
+            # every track box is one of this frame's detections (un-scaled again by the shell): its depth is that
+            # detection's oracle depth
+            for b, d in zip(trk.bboxes.cpu(), trk.depth.cpu()):
+                j = int((boxes - b).abs().sum(1).argmin())
+                if float((boxes[j] - b).abs().max()) <= 1e-2:
+                    ref_d = float(depth[j])
+                    assert (math.isnan(ref_d) and math.isnan(float(d))) or abs(float(d) - ref_d) <= 1e-3 * max(1.0, abs(ref_d))
+    assert n_tracked > 0
 
 
 def test_batched_predict_equals_sequential_and_stereo_module(cuda):

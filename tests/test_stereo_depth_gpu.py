@@ -55,6 +55,61 @@ def test_costvolume_bit_exact_and_softargmin(N, Hf, Wf, Cc, ld, D, cuda):
     assert np.array_equal(o.cpu().numpy().view(np.uint32), ref_disp.view(np.uint32))
 
 
+def test_costvolume_beside_bf16_mfma_kernels_equals_serial_run(cuda):
+    """Round-4 finding, closed structurally in round 5: a v_pk_fma_f32 whose source is broadcast by op_sel / op_sel_hi
+    drops that bit for single steps while bf16 MFMAs execute on the chip (tools/micro/pkfma_corun.hip reproduces it in
+    registers, profiles/r05_pkfma_corun.txt); the cost-volume kernel built that way returned a wrong volume in 236 of 240
+    co-runs.  The library now ships the scalar-FMA form only.  ONE co-run: four cost volumes on four streams beside the
+    split-operand (bf16 MFMA) conv instances on two more streams; every volume must equal the one the same call gives
+    alone, bit for bit (consumer contract: ocsort_disparity.py:115,132-134 reads this disparity per box)."""
+    from stereotracking_amd._lib import StConvDesc
+    lib = _lib.load()
+    N, Hf, Wf, Cc, D = 8, 184, 320, 64, 48
+    NS = 4
+    g = torch.Generator(device='cpu').manual_seed(5)
+    feats = [(torch.randn(N, Hf, Wf, Cc, generator=g).to(cuda), torch.randn(N, Hf, Wf, Cc, generator=g).to(cuda))
+             for _ in range(NS)]
+    vols = [torch.full((N, Hf, Wf, D), float('nan'), device=cuda) for _ in range(NS)]
+
+    def cost_volume(i, stream):
+        fl, fr = feats[i]
+        check(lib.st_costvolume_softargmin(ptr(fl), ptr(fr), N, Hf, Wf, Cc, Cc, D, 32.0, ptr(vols[i]), None,
+                                           C.c_void_p(stream.cuda_stream)))
+
+    ref = []
+    for i in range(NS):
+        cost_volume(i, torch.cuda.current_stream())
+        torch.cuda.synchronize()
+        ref.append(vols[i].clone())
+        vols[i].fill_(float('nan'))
+    # the aggressor: a 256 -> 128 pointwise layer of the path on the split-operand instances (v_mfma_f32_32x32x16_bf16)
+    xs = torch.randn(8, 92, 160, 256, generator=g).to(cuda)
+    w = torch.randn(128, 256, 1, 1, generator=g) / 16
+    b = torch.zeros(128)
+    wp = torch.empty(lib.st_conv_packed_floats(128, 256, 1, 1))
+    bp = torch.zeros(128)
+    check(lib.st_conv_pack_weights(ptr(w), ptr(b), None, None, None, None, 0.0, 128, 256, 1, 1, ptr(wp), ptr(bp)))
+    wpd, bpd = wp.to(cuda), bp.to(cuda)
+    out = torch.empty(8, 92, 160, 128, device=cuda)
+    d = StConvDesc()
+    d.in_dev = xs.data_ptr(); d.N, d.Hi, d.Wi, d.Cin, d.in_ld, d.in_off = 8, 92, 160, 256, 256, 0
+    d.wgt_dev = wpd.data_ptr(); d.bias_dev = bpd.data_ptr()
+    d.Cout, d.KH, d.KW, d.stride, d.pad = 128, 1, 1, 1, 0
+    d.out1_dev = out.data_ptr(); d.out1_ld, d.out1_off, d.split = 128, 0, 128
+    d.act, d.post_scale = 1, 1.0
+    streams = [torch.cuda.Stream() for _ in range(NS)]
+    extra = [torch.cuda.Stream() for _ in range(2)]
+    torch.cuda.synchronize()
+    for i, s in enumerate(streams):
+        if i < len(extra):
+            for v in (53, 54, 50, 51):
+                check(lib.st_conv2d_nhwc_variant(C.byref(d), C.c_void_p(extra[i].cuda_stream), v))
+        cost_volume(i, s)
+    torch.cuda.synchronize()
+    for i in range(NS):
+        assert torch.equal(vols[i], ref[i]), f'cost volume {i} differs from its serial run beside bf16 MFMA kernels'
+
+
 @pytest.mark.parametrize('N,Hf,Wf,Cc,D', [(1, 3, 300, 8, 192), (2, 2, 210, 16, 160), (1, 2, 260, 24, 256)])
 def test_wide_volume_materialised_in_slabs_is_bit_exact(N, Hf, Wf, Cc, D, cuda):
     """SURVEY.md §8(d)'s full-resolution sizing (D = 192 levels): volumes wider than the 128 disparities one launch of the
