@@ -51,6 +51,12 @@ def parse():
                     help='let the autotuner pick the split-operand (bf16x3) conv instances (default: exact-fp32 MFMA only)')
     ap.add_argument('--split-leg', action='store_true',
                     help='also time the workload with the split-operand instances allowed (secondary line)')
+    ap.add_argument('--input-batches', type=int, default=4,
+                    help='DISTINCT synthetic input batches resident in HBM, fed round-robin in the timed loop (181 MB each: '
+                         'one batch alone could partly live in the 256 MB Infinity Cache across steps)')
+    ap.add_argument('--agg3d-leg', action='store_true',
+                    help='also time the workload with ONE 3-D aggregation layer (3x3x3 over d, y, x) in front of the 2-D '
+                         'ones (secondary line; pair 0 checked against the CPU oracle)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-test-step', action='store_true',
                     help='skip the second leg through Config.fromfile -> MODELS.build -> model.test_step')
@@ -130,6 +136,11 @@ def conv_roofline(pipe, img, right, steps):
     agg_macs = sm.agg_macs(pipe.batch, Hf, Wf)   # per aggregation layer
     VARIANT_TILES = {v: lib.st_conv_variant_name(v).decode() for v in range(64)}
     VARIANT_TILES[-1] = 'skipped'
+    # One row per LAUNCH kind: the ops a fused / grouped launch computes are summed into the row of the launch that
+    # computes them, time and flops together ('wino2x2g+' = the riders of a grouped Winograd launch: their time is
+    # inside the leading 'wino2x2g' op's event pair, so both names form ONE row; the fused front kernel's three ops
+    # carry one variant name already).  Rounds 3-4 printed the riders as a row of their own with flops but no time.
+    ROW = {'wino2x2g+': 'wino2x2g'}
     per_variant = {}
     for v in sorted(set(var[kind == 1].tolist()) | set(agg)):
         sel = (kind == 1) & (var == v)
@@ -142,9 +153,17 @@ def conv_roofline(pipe, img, right, steps):
             n_launch //= 3      # one launch computes three ops of the plan (3x3/s2 + main|short + conv1)
         if VARIANT_TILES[v] == 'wino2x2g+':
             n_launch = 0        # riders of a grouped Winograd launch: computed by the 'wino2x2g' op in front of them
-        per_variant[VARIANT_TILES[v]] = dict(launches=n_launch, event_pairs=n_events, ms_per_step=round(float(t), 4),
-                                             gflop_per_step=round(fl / 1e9, 3),
-                                             tflops=round(fl / (t * 1e-3) / 1e12, 3) if t > 0 else 0.0)
+        name = ROW.get(VARIANT_TILES[v], VARIANT_TILES[v])
+        e = per_variant.setdefault(name, dict(launches=0, ops=0, event_pairs=0, ms_per_step=0.0, gflop_per_step=0.0))
+        e['launches'] += n_launch
+        e['ops'] += int(sel.sum()) + n_agg // steps
+        e['event_pairs'] += n_events
+        e['ms_per_step'] += float(t)
+        e['gflop_per_step'] += fl / 1e9
+    for e in per_variant.values():
+        e['tflops'] = round(e['gflop_per_step'] / e['ms_per_step'], 3) if e['ms_per_step'] > 0 else 0.0
+        e['ms_per_step'] = round(e['ms_per_step'], 4)
+        e['gflop_per_step'] = round(e['gflop_per_step'], 3)
     # Kernel families of the MFMA work.  `roofline` describes the DOMINANT one = the family with the largest summed
     # duration per step.  conv_igemm_kernel's tile instances are one kernel template (which instance a layer uses is
     # an autotune outcome that varies from run to run) and are aggregated; the Winograd, direct 3x3, streaming 1x1
@@ -171,7 +190,7 @@ def conv_roofline(pipe, img, right, steps):
         e['instances'].append(name)
     # Durations: raw HIP-event times carry the event-pair overhead (two barrier packets, measured above on this stream:
     # `event_pair_overhead_us`); rocprofv3's kernel durations do not.  The overhead is subtracted per launch so that
-    # `achieved` / `avg_launch_us` reproduce from profiles/r04_kernel_stats_inflight1.csv (the raw figures are kept
+    # `achieved` / `avg_launch_us` reproduce from profiles/r05_kernel_stats_inflight1.csv (the raw figures are kept
     # next to them).  `frac` is a fraction of the INSTRUCTION peak: flops the matrix pipes execute / time / 157.3 - for
     # the Winograd family that is the direct-convolution count / 2.25 (F(2x2,3x3) issues 16 of every 36 multiplies),
     # which goes into `algorithmic_speedup`, never into `frac`.
@@ -195,10 +214,10 @@ def conv_roofline(pipe, img, right, steps):
     conv_fl = 2.0 * float(macs[kind == 1].sum() + agg_macs * sum(a[0] for a in agg.values()) / steps)
     conv_exec = sum(e['executed_gflop_per_step'] for e in fam.values()) * 1e9
     # HBM bytes per launch of the dominant family from this round's rocprofv3 PMC passes of this command (FETCH_SIZE x2
-    # gfx950 correction + WRITE_SIZE, separate passes; tools/profile_round.sh writes profiles/r04_hbm_traffic.json from
+    # gfx950 correction + WRITE_SIZE, separate passes; tools/profile_round.sh writes profiles/r05_hbm_traffic.json from
     # the SAME commit's library).  null when that file is absent: never a number from another round.
     traffic, traffic_src = None, None
-    tpath = os.path.join(ROOT, 'profiles', 'r04_hbm_traffic.json')
+    tpath = os.path.join(ROOT, 'profiles', 'r05_hbm_traffic.json')
     if os.path.exists(tpath):
         tj = json.load(open(tpath))
         tot_b, cov = 0.0, 0
@@ -209,7 +228,7 @@ def conv_roofline(pipe, img, right, steps):
                 cov += n
         if cov:
             traffic = int(tot_b / cov)
-            traffic_src = ('profiles/r04_hbm_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command '
+            traffic_src = ('profiles/r05_hbm_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command '
                            '(separate runs of tools/profile_round.sh), launch-weighted over %s*' % dom)
     roof = dict(bound='mfma', kernel=dom + ('<...> (all tile instances)' if dom == 'st::conv_igemm_kernel' else ''),
                 achieved=D['tflops'], peak=PEAK_FP32_MFMA_TFLOPS, unit='TFLOP/s', frac=D['frac'],
@@ -225,7 +244,7 @@ def conv_roofline(pipe, img, right, steps):
                            '/ summed kernel duration of the family in a serialized pass (HIP events on the launch '
                            'stream minus the measured event-pair overhead; an event-bracketed launch also carries its '
                            'dispatch latency, so these durations read ~4 % above the rocprofv3 kernel-trace durations '
-                           'of the same launches in profiles/r04_kernel_stats_inflight1.csv: `achieved` is a lower '
+                           'of the same launches in profiles/r05_kernel_stats_inflight1.csv: `achieved` is a lower '
                            'bound); frac = achieved / peak <= 1',
                 families=fam,
                 all_mfma_kernels=dict(ms_per_step=round(conv_ms, 4),
@@ -374,6 +393,82 @@ def split_leg(args, sd, img, right, headline):
                     conv_ops=sum(1 for t in plan if t >= 0),
                     note='NOT the headline: plan with split-operand (bf16x3) conv instances; outputs differ from the '
                          'exact-fp32 plan by fp32-level noise (head 3e-4 relative), parity record in DESIGN.md')
+    except Exception as e:   # a secondary line must never cost the headline
+        return dict(error=repr(e))
+
+
+def agg3d_leg(args, inputs, batch_cpu, headline, dev):
+    """SECONDARY line, never `value`: the same workload with ONE 3-D aggregation layer (single-channel 3x3x3 over d, y, x:
+    csrc/agg3d.hip) in front of the 2-D aggregation convs - north_star's "3D/2D aggregation" as a benched form.  The K
+    steps are timed exactly like the headline; pair 0's disparity is checked against the CPU oracle with the same
+    layer (oracle/stereo.py, agg3d_layers=1); the layer's own launch is timed with HIP events on its stream."""
+    import ctypes as C
+    from oracle import stereo as ostereo
+    from oracle.torch_model import OracleDetector
+    from stereotracking_amd._lib import check, ptr
+    from stereotracking_amd.pipeline import InflightPipelines
+    from stereotracking_amd.synthetic import synthetic_state_dict
+    try:
+        runner = InflightPipelines(max(1, args.inflight), args.batch, (720, 1280), 0.5, 0.33, 1, stereo=True,
+                                   max_disp=args.max_disp, max_det=args.max_det, agg_layers=args.agg_layers,
+                                   agg3d_layers=1)
+        sd = synthetic_state_dict(runner.param_table(), seed=0)     # keyed by NAME: the detector / 2-D weights of the headline
+        g = torch.Generator().manual_seed(3)
+        w3 = torch.randn(1, 1, 3, 3, 3, generator=g) * 0.15
+        w3[0, 0, 1, 1, 1] += 1.0                                     # a smoothing-like kernel around the identity
+        sd['stereo.agg3d.0.weight'], sd['stereo.agg3d.0.bias'] = w3, torch.zeros(1)
+        runner.load_state_dict(sd)
+        nb = len(inputs)
+        for i in range(args.warmup):
+            runner.submit(*inputs[i % nb])
+        runner.synchronize()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            out = runner.submit(*inputs[i % nb])[0]
+        runner.synchronize()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        v = args.batch * args.steps / dt
+        out = runner.submit(*inputs[0])[0]
+        torch.cuda.synchronize()
+        disp0 = out['disp_postp'][0, 0].cpu()
+        # the layer alone, at the bench volume
+        pipe = runner.pipes[0]
+        lib = pipe.det.lib
+        Hf, Wf, D = pipe.height // pipe.feat_stride, pipe.width // pipe.feat_stride, pipe.D
+        vin = torch.randn(args.batch, Hf, Wf, D, device=dev)
+        vout = torch.empty_like(vin)
+        w27 = (C.c_float * 27)(*w3.reshape(-1).tolist())
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        for _ in range(3):
+            check(lib.st_volume_agg3d(ptr(vin), ptr(vout), args.batch, Hf, Wf, D, w27, 0.0, 0, None))
+        e0.record()
+        for _ in range(20):
+            check(lib.st_volume_agg3d(ptr(vin), ptr(vout), args.batch, Hf, Wf, D, w27, 0.0, 0, None))
+        e1.record()
+        torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) / 20 * 1e3
+        nbytes = 2.0 * vin.numel() * 4
+        # oracle, pair 0
+        ora = OracleDetector(0.33, 0.5, 1).eval()
+        ora.load_state_dict(sd, strict=False)
+        img, right = batch_cpu['img'][:1], batch_cpu['right'][:1]
+        with torch.no_grad():
+            fl = ora.backbone.stage1_features(img).permute(0, 2, 3, 1).contiguous().numpy()
+            fr = ora.backbone.stage1_features(right).permute(0, 2, 3, 1).contiguous().numpy()
+        ref = torch.from_numpy(ostereo.disparity(fl, fr, fl.shape[-1], D, 32.0, sd, args.agg_layers, valid_hw=(720, 1280),
+                                                 agg3d_layers=1)[2])[0, 0]
+        ad = (disp0 - ref).abs()
+        return dict(value=round(v, 3), unit='stereo frame-pairs/s', ms_per_step=round(dt / args.steps * 1e3, 4),
+                    vs_headline=round(v / headline, 4), agg3d_layers=1, agg_layers=args.agg_layers,
+                    agg3d_kernel=dict(kernel='st::agg3d_kernel', volume=[args.batch, Hf, Wf, D], avg_launch_us=round(us, 2),
+                                      bytes_per_launch=int(nbytes), bound='hbm', peak=8000.0, unit='GB/s',
+                                      achieved=round(nbytes / (us * 1e-6) / 1e9, 1), frac=round(nbytes / (us * 1e-6) / 8e12, 4)),
+                    disparity_vs_oracle_pair0=dict(l1_px=float(ad.mean()), max_abs_px=float(ad.max()),
+                                                   max_rel=float((ad / ref.abs().clamp(min=1.0)).max())),
+                    note='NOT the headline: one 3x3x3 aggregation layer over (d, y, x) added in front of the 2-D convs; the '
+                         'frozen spec of the benched module (SURVEY 8 a-7) aggregates with 2-D convs only')
     except Exception as e:   # a secondary line must never cost the headline
         return dict(error=repr(e))
 
@@ -581,8 +676,17 @@ def main():
     sd = synthetic_state_dict(runner.param_table(), seed=0)
     runner.load_state_dict(sd)   # plan from pipeline.default_tuning_cache() (committed), measured when absent
     # every rank gets its own 8 pairs (weak scaling: frames shard across ranks)
+    # --input-batches DISTINCT batches, all resident in HBM before the timed region, fed round-robin: step i reads
+    # batch i % nb (the timed loop of rounds 1-4 re-read ONE 181 MB batch, which the Infinity Cache can partly hold)
+    nb = max(1, args.input_batches)
     batch_cpu = synthetic_batch([rank * B + i for i in range(B)], 720, 1280, args.max_disp)
-    img, right = batch_cpu['img'].to(dev), batch_cpu['right'].to(dev)
+    inputs = [(batch_cpu['img'].to(dev), batch_cpu['right'].to(dev))]
+    for j in range(1, nb):
+        bj = synthetic_batch([100000 * j + rank * B + i for i in range(B)], 720, 1280, args.max_disp)
+        inputs.append((bj['img'].to(dev), bj['right'].to(dev)))
+        del bj
+    img, right = inputs[0]
+    step_no = [0]
     from stereotracking_amd.dist import DetectionGatherer
     gathered = [torch.empty(world * B, pipe.max_det + 1, 8, device=cdev) for _ in runner.pipes] if world > 1 else None
     # ONE communication stream for every all-gather of this rank: collectives are issued in host program order (step
@@ -598,7 +702,9 @@ def main():
         return out
 
     def step():
-        return runner.submit(img, right, post=post)[0]
+        l, r = inputs[step_no[0] % nb]
+        step_no[0] += 1
+        return runner.submit(l, r, post=post)[0]
 
     for _ in range(args.warmup):
         out = step()
@@ -654,6 +760,10 @@ def main():
             dts = float(t.item())
         sustained = dict(seconds=round(dts, 3), steps=n_s, value=round(world * B * n_s / dts, 3))
 
+    if (step_no[0] - 1) % nb != 0:     # the record checks below compare against batch 0's CPU oracle: end on batch 0
+        step_no[0] = 0
+        out = step()
+        torch.cuda.synchronize()
     counts = out['counts'].cpu().tolist()
     disp_pair0 = out['disp_postp'][0, 0].cpu()                   # BASELINE metric's "disparity L1 vs ref" (rank 0, pair 0)
     rec_counts = out['records'][:, 0, 0].cpu().long().tolist()   # what the tracker side of the all-gather sees
@@ -671,7 +781,7 @@ def main():
                                'full YOLOX-s two-branch backbone+PAFPN+head, cost volume at 1/4 res '
                                f'({args.max_disp // 4} levels) + {args.agg_layers} 3x3 aggregation convs + soft-argmin, '
                                'decode+NMS, per-box depth',
-                   'global_batch': world * B, 'inflight_contexts': len(runner), 'gpu_max_hw_queues': os.environ.get('GPU_MAX_HW_QUEUES'),
+                   'global_batch': world * B, 'inflight_contexts': len(runner), 'distinct_input_batches': nb, 'gpu_max_hw_queues': os.environ.get('GPU_MAX_HW_QUEUES'),
                    'hip_force_dev_kernarg': os.environ.get('HIP_FORCE_DEV_KERNARG'),
                    'parallelism': (f'frames sharded x{world}, one all-gather of detections per step ({backend})'
                                    if world > 1 else 'single process, no process group (no collective in the step)'),
@@ -697,6 +807,8 @@ def main():
                             'timed region overlaps kernels of consecutive batches, which inflates per-launch durations '
                             '(compare profiles/*_inflight1 for the serialized rocprof summary)')
         line['roofline'] = roof
+        if world == 1 and args.agg3d_leg:
+            line['secondary_agg3d'] = agg3d_leg(args, inputs, batch_cpu, line['value'], dev)
         if world == 1 and not args.no_test_step:
             del runner   # its three workspaces are not needed any more
             line['test_step'] = test_step_leg(args, sd, batch_cpu, dev, B * args.steps)

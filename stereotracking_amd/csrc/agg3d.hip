@@ -4,11 +4,15 @@
 // oracle/st_oracle.c::oracle_agg3d and this kernel is BIT-EXACT against it (same fmaf order: rows j, columns k,
 // disparity taps i; padded taps contribute fmaf(w, 0, acc); SiLU through the oracle's exp polynomial).
 //
-// HBM-bound stencil (27 FMAs per cell against 8 bytes of traffic): one workgroup owns one row segment of TW pixels
-// of one image and stages the 3 x (TW + 2) pixel rows x D floats it needs in LDS once (coalesced 16-byte loads, zero
-// fill = the padding in y / x); a thread produces 4 consecutive disparities of one pixel from 9 aligned 16-byte LDS
-// reads + the two neighbours across the quad borders, and stores 16 bytes.  Every volume element is fetched from
-// memory 3 x (TW + 2) / TW = 3.1 times per layer through L2 (its two neighbour rows are other workgroups' tiles).
+// HBM-bound stencil (27 FMAs per cell against 8 bytes of traffic), written as a STREAMING stencil: one workgroup owns a
+// column strip of TW pixels x all D disparities and walks down a band of RY rows, keeping a ring of four pixel rows
+// ((TW + 2) x D floats each) in LDS - rows y-1, y, y+1 feed output row y while row y+2 travels from memory through
+// registers into the fourth slot (one barrier per row).  A volume element is fetched (TW + 2) / TW x (RY + 2) / RY
+// times per layer (1.2x at the bench volume; the round-4 kernel staged three rows per output row: 3.1x).  A thread
+// produces 4 consecutive disparities of one pixel from 9 aligned 16-byte LDS reads + the two neighbours across the quad
+// borders, and stores 16 bytes.
+#include <algorithm>
+
 #include "st_common.h"
 
 namespace st {
@@ -34,59 +38,86 @@ __device__ __forceinline__ float a3_expf(float x) {  // same polynomial as decod
   return ldexpf(p, (int)n);
 }
 
-constexpr int A3_TW = 64;   // pixels of one row per workgroup
-
 struct Agg3dArgs {
   const float* in;
   float* out;
   int N, Hf, Wf, D;
+  int RY;        // rows per band
   float w[27];   // [i = kD][j = kH][k = kW]
   float bias;
   int act;
 };
 
+// TW: pixels per strip; NST: float4 staging registers per thread = ceil((TW + 2) * (D / 4) / 256)
+template <int TW, int NST>
 __global__ __launch_bounds__(256) void agg3d_kernel(const Agg3dArgs a) {
   extern __shared__ float4 a3_smem4[];
   float* lds = reinterpret_cast<float*>(a3_smem4);
   const int D = a.D, DQ = D >> 2;
-  const int x0 = blockIdx.x * A3_TW, y = blockIdx.y, n = blockIdx.z;
+  constexpr int TC = TW + 2;
+  const int x0 = blockIdx.x * TW, y0 = blockIdx.y * a.RY, n = blockIdx.z;
+  const int y1 = min(y0 + a.RY, a.Hf);
   const int tid = threadIdx.x;
-  constexpr int TC = A3_TW + 2;
-  // ---- stage rows y-1 .. y+1, columns x0-1 .. x0+TW, all D disparities (zero outside the image)
-  const int nload = 3 * TC * DQ;
-  for (int e = tid; e < nload; e += 256) {
-    const int q = e % DQ, pc = e / DQ;
-    const int c = pc % TC, r = pc / TC;
-    const int gy = y + r - 1, gx = x0 + c - 1;
-    f32x4 v = {0.f, 0.f, 0.f, 0.f};
-    if (gy >= 0 && gy < a.Hf && gx >= 0 && gx < a.Wf)
-      v = *reinterpret_cast<const f32x4*>(a.in + (((size_t)n * a.Hf + gy) * a.Wf + gx) * D + 4 * q);
-    *reinterpret_cast<f32x4*>(lds + (size_t)pc * D + 4 * q) = v;
+  const int rowf = TC * D;          // floats per staged pixel row
+  const int nrow4 = TC * DQ;        // float4 per staged pixel row
+  f32x4 st[NST];
+  // one pixel row gy (columns x0-1 .. x0+TW, zero outside the image) from memory into registers / registers into slot
+  auto load_row = [&](int gy) {
+#pragma unroll
+    for (int i = 0; i < NST; ++i) {
+      const int e = tid + 256 * i;
+      const int q = e % DQ, c = e / DQ;
+      const int gx = x0 + c - 1;
+      st[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (e < nrow4 && gy >= 0 && gy < a.Hf && gx >= 0 && gx < a.Wf)
+        st[i] = *reinterpret_cast<const f32x4*>(a.in + (((size_t)n * a.Hf + gy) * a.Wf + gx) * D + 4 * q);
+    }
+  };
+  auto store_row = [&](int gy) {
+    float* dst = lds + (size_t)((gy + 4) & 3) * rowf;
+#pragma unroll
+    for (int i = 0; i < NST; ++i) {
+      const int e = tid + 256 * i;
+      if (e < nrow4) *reinterpret_cast<f32x4*>(dst + 4 * e) = st[i];
+    }
+  };
+  for (int r = -1; r <= 1; ++r) {
+    load_row(y0 + r);
+    store_row(y0 + r);
   }
   __syncthreads();
-  const int nitem = A3_TW * DQ;
-  for (int it = tid; it < nitem; it += 256) {
-    const int q = it % DQ, px = it / DQ;
-    if (x0 + px >= a.Wf) continue;
-    float acc[4] = {a.bias, a.bias, a.bias, a.bias};
+  const int nitem = TW * DQ;
+  for (int y = y0; y < y1; ++y) {
+    const bool more = y + 1 < y1;
+    if (more) load_row(y + 2);      // in flight while this row is computed
+    for (int it = tid; it < nitem; it += 256) {
+      const int q = it % DQ, px = it / DQ;
+      if (x0 + px >= a.Wf) continue;
+      float acc[4] = {a.bias, a.bias, a.bias, a.bias};
 #pragma unroll
-    for (int j = 0; j < 3; ++j)
+      for (int j = 0; j < 3; ++j) {
+        const float* row = lds + (size_t)((y + j - 1 + 4) & 3) * rowf;
 #pragma unroll
-      for (int k = 0; k < 3; ++k) {
-        const float* p = lds + (size_t)(j * TC + px + k) * D + 4 * q;
-        const f32x4 v = *reinterpret_cast<const f32x4*>(p);
-        const float vm = q > 0 ? p[-1] : 0.0f;
-        const float vp = q < DQ - 1 ? p[4] : 0.0f;
-        const float vals[6] = {vm, v[0], v[1], v[2], v[3], vp};
+        for (int k = 0; k < 3; ++k) {
+          const float* p = row + (size_t)(px + k) * D + 4 * q;
+          const f32x4 v = *reinterpret_cast<const f32x4*>(p);
+          const float vm = q > 0 ? p[-1] : 0.0f;
+          const float vp = q < DQ - 1 ? p[4] : 0.0f;
+          const float vals[6] = {vm, v[0], v[1], v[2], v[3], vp};
 #pragma unroll
-        for (int e = 0; e < 4; ++e)
+          for (int e = 0; e < 4; ++e)
 #pragma unroll
-          for (int i = 0; i < 3; ++i) acc[e] = fmaf(a.w[(i * 3 + j) * 3 + k], vals[e + i], acc[e]);
+            for (int i = 0; i < 3; ++i) acc[e] = fmaf(a.w[(i * 3 + j) * 3 + k], vals[e + i], acc[e]);
+        }
       }
-    f32x4 o;
+      f32x4 o;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) o[e] = a.act ? acc[e] / (1.0f + a3_expf(-acc[e])) : acc[e];
-    *reinterpret_cast<f32x4*>(a.out + (((size_t)n * a.Hf + y) * a.Wf + x0 + px) * D + 4 * q) = o;
+      for (int e = 0; e < 4; ++e) o[e] = a.act ? acc[e] / (1.0f + a3_expf(-acc[e])) : acc[e];
+      *reinterpret_cast<f32x4*>(a.out + (((size_t)n * a.Hf + y) * a.Wf + x0 + px) * D + 4 * q) = o;
+    }
+    // slot (y + 2) & 3 held row y - 2: last read while row y - 1 was computed, i.e. before the previous barrier
+    if (more) store_row(y + 2);
+    __syncthreads();
   }
 }
 
@@ -106,11 +137,36 @@ extern "C" int st_volume_agg3d(const float* vol_in_dev, float* vol_out_dev, int 
   a.in = vol_in_dev; a.out = vol_out_dev; a.N = N; a.Hf = Hf; a.Wf = Wf; a.D = D;
   for (int i = 0; i < 27; ++i) a.w[i] = weight27_host[i];
   a.bias = bias; a.act = act;
-  const int lds = 3 * (A3_TW + 2) * D * (int)sizeof(float);
-  static int lds_set = 0;
-  ST_ENSURE_DYNAMIC_LDS(agg3d_kernel, lds, lds_set);
-  hipLaunchKernelGGL(agg3d_kernel, dim3((unsigned)ceil_div(Wf, A3_TW), (unsigned)Hf, (unsigned)N), dim3(256), lds,
-                     static_cast<hipStream_t>(stream_), a);
+  // strip width by LDS budget (4 rows x (TW + 2) x D floats): 64 pixels up to 48 levels (51 KB), 32 up to 96 (52 KB),
+  // 16 beyond (55 KB at D = 192) - two to three workgroups per CU in every case
+  const int TW = D <= 48 ? 64 : (D <= 96 ? 32 : 16);
+  const int strips = ceil_div(Wf, TW);
+  // band height: enough workgroups for ~4 per CU, bands of at least 8 rows (halo re-read (RY + 2) / RY <= 1.25)
+  const int want_bands = std::max(1, ceil_div(4 * 256, N * strips));
+  int RY = std::max(8, ceil_div(Hf, want_bands));
+  RY = std::min(RY, Hf);
+  a.RY = RY;
+  const int bands = ceil_div(Hf, RY);
+  ST_REQUIRE(bands < 65536, "st_volume_agg3d: grid too large");
+  const int lds = 4 * (TW + 2) * D * (int)sizeof(float);
+  const dim3 grid((unsigned)strips, (unsigned)bands, (unsigned)N);
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+#define ST_A3_LAUNCH(TWV, NSTV)                                                                      \
+  do {                                                                                               \
+    auto kern = agg3d_kernel<TWV, NSTV>;                                                             \
+    static int lds_set = 0;                                                                          \
+    ST_ENSURE_DYNAMIC_LDS(kern, lds, lds_set);                                                       \
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, a);                                       \
+  } while (0)
+  const int nst = ceil_div((TW + 2) * (D / 4), 256);
+  if (TW == 64) {            // D <= 48: (66 * 12) / 256 -> up to 4
+    if (nst <= 2) ST_A3_LAUNCH(64, 2); else ST_A3_LAUNCH(64, 4);
+  } else if (TW == 32) {     // D <= 96: (34 * 24) / 256 -> 4
+    ST_A3_LAUNCH(32, 4);
+  } else {                   // D <= 192: (18 * 48) / 256 -> 4
+    ST_A3_LAUNCH(16, 4);
+  }
+#undef ST_A3_LAUNCH
   ST_CHECK_HIP(hipGetLastError());
   return ST_OK;
 }

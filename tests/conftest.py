@@ -10,6 +10,8 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu)')
+    config.addinivalue_line('markers', 'yardstick: timing comparisons (record-only under -m gpu; ST_YARDSTICK_ASSERT=1 '
+                                       'turns their speed claims into assertions)')
 
 
 # Collection order of the GPU run (the driver uses `-x`): oracle-parity files first, multi-process rehearsals LAST, so

@@ -20,7 +20,7 @@ reference run's own margins, parity_utils.explain_kept_difference) that it hangs
 allows two kept boxes to swap places in the score order only when their reference scores differ by < 5e-5; the
 counts of differing priors / swapped positions and the margins go into the record.
 
-The measured figures are written to gpurun_out/r04_e2e_parity.json (copied to profiles/)."""
+The measured figures are written to gpurun_out/r05_e2e_parity.json (copied to profiles/)."""
 import numpy as np
 import pytest
 import torch
@@ -130,7 +130,7 @@ def test_benched_configuration_parity(cuda):
             c['explain'] = explain_kept_difference(r['rows'], pipe.det.levels, out['prior_idx'][n, :int(counts[n])].cpu().numpy(),
                                                    r['prior'], pipe.score_thr, pipe.iou_thr)
         rec['e2e'][f'pair{n}'] = c
-    write_record('r04_e2e_parity.json', rec)
+    write_record('r05_e2e_parity.json', rec)
     print(rec)
 
     # ---- the bars ---------------------------------------------------------------------------------------

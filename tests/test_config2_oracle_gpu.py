@@ -31,7 +31,7 @@ The float criterion is measured against float64, per quantity (boxes, scores, di
 amplifies fp32 feature noise on texture-less matches, for every fp32 evaluation.)  The score noise that legitimises an
 order swap is no longer hand-set: two detections may swap only if their FLOAT64 scores are closer than the sum of the
 two measured score errors (gpu-vs-fp64 + cpu32-vs-fp64) of that sequence.
-The record goes to gpurun_out/r04_config2_oracle_<sequence>_<thresholds>.json (copied to profiles/)."""
+The record goes to gpurun_out/r05_config2_oracle_<sequence>_<thresholds>.json (copied to profiles/)."""
 import os
 
 import numpy as np
@@ -230,7 +230,7 @@ def test_config2_sequence_against_oracle_pipeline_and_oracle_tracker(seq, name, 
     rec['ids_relabeled'] = len(relabeled)
     rec['ids_relabeled_across_birth_frames'] = len(cross_frame)
     rec['relabeled_examples'] = {str(a): b for a, b in list(relabeled.items())[:16]}
-    write_record(f'r04_config2_oracle_{seq}_{name}.json', rec)
+    write_record(f'r05_config2_oracle_{seq}_{name}.json', rec)
     print({k: v for k, v in rec.items() if k != 'frames'})
 
     rows = max(tot['track_rows'], 1)
@@ -244,6 +244,10 @@ def test_config2_sequence_against_oracle_pipeline_and_oracle_tracker(seq, name, 
     dist = rec['box_vs_fp64_distribution']
     assert dist['gpu']['mean'] <= 1.25 * dist['cpu32']['mean'] and dist['gpu']['p999'] <= 1e-3, dist
     assert dist['gpu']['p999'] <= max(2e-4, 1.5 * dist['cpu32']['p999']), dist
+    # ... and the TAIL is counted: boxes further than 1e-3 from float64.  Round 4 measured 0 (blurred) and 3 of 15 550
+    # (white noise; the fp32 oracle: 0 and 1).  A change that widens the tail but keeps the maximum inside 1.25 x the
+    # oracle's would pass every bound above; it does not pass this one.
+    assert dist['gpu']['over_1e3'] <= (0 if seq == 'blurred' else 3), dist
     assert worst['score'] <= 1e-3 and worst['track_box'] <= 1e-3, worst
     if seq == 'blurred':
         assert worst['box'] <= 1e-3, worst                    # gpu vs the fp32 oracle directly, as in round 3

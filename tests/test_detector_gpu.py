@@ -68,10 +68,13 @@ def test_rgb_only_detector_head_and_taps_parity(widen, N, H, W, cuda):
         assert rel_err(got.double(), ref64) <= 1e-3
     head2 = det.forward(batch['img'].to(cuda), batch['disp_postp'].to(cuda))
     torch.cuda.synchronize()
-    assert torch.equal(head, head2)
+    for r1, r2 in zip(det.head_levels(head), det.head_levels(head2)):     # (columns 6, 7 of a head row are padding)
+        assert torch.equal(r1[..., :6], r2[..., :6])
     # and it is NOT the two-branch result: the same image-branch weights inside the two-branch plan give another head
     det2, _ = build_pair(widen, 0.33, N, H, W, seed=4)
-    assert not torch.equal(det2.forward(batch['img'].to(cuda), batch['disp_postp'].to(cuda)), head)
+    head3 = det2.forward(batch['img'].to(cuda), batch['disp_postp'].to(cuda))
+    torch.cuda.synchronize()
+    assert not torch.equal(det2.head_levels(head3)[0][..., :6], det.head_levels(head)[0][..., :6])
 
 
 @pytest.mark.parametrize('nc', [3, 5, 80])

@@ -140,7 +140,7 @@ def test_config2_full_size_64_frame_sequence(cuda):
     two-branch detector + 2 aggregation convs, detector + disparity feeding the (CPU) association, on one GPU.
     Batched execution (8 frames per launch plan on 3 in-flight contexts) gives bit-identical detections and the same
     track ids / boxes as the strictly sequential frame-by-frame run (batch 1, one context); the measured rates go
-    into gpurun_out/r04_config2.json (copied to profiles/)."""
+    into gpurun_out/r05_config2.json (copied to profiles/)."""
     import json
     import os
     import time
@@ -226,7 +226,7 @@ def test_config2_full_size_64_frame_sequence(cuda):
                tracks_returned=n_trk, detections_per_frame_mean=round(float(c1.float().mean()), 1),
                end_to_end_frames_per_s=round(T / (t_dense + t_track), 1))
     os.makedirs('gpurun_out', exist_ok=True)
-    json.dump(rec, open('gpurun_out/r04_config2.json', 'w'), indent=1)
+    json.dump(rec, open('gpurun_out/r05_config2.json', 'w'), indent=1)
     print(rec)
 
 

@@ -336,11 +336,15 @@ def test_stereo_module_with_aggregation_matches_oracle(agg_layers, tuned, cuda):
 
 # ---- 3-D aggregation (north_star: "its 3D/2D aggregation"; csrc/agg3d.hip) -----------------------------------------
 @pytest.mark.parametrize('N,Hf,Wf,D,act', [(2, 5, 70, 48, 1), (1, 3, 130, 16, 0), (1, 4, 64, 48, 1), (1, 1, 1, 4, 1),
-                                           (1, 7, 65, 96, 0), (2, 2, 200, 12, 1)])
+                                           (1, 7, 65, 96, 0), (2, 2, 200, 12, 1),
+                                           (1, 37, 70, 48, 1),     # several row bands of the streaming stencil, ragged last band
+                                           (1, 9, 40, 192, 1),     # the 16-pixel strips of D = 192
+                                           (3, 19, 33, 28, 0)])    # D <= 28: the 2-register staging instance
 def test_agg3d_layer_bit_exact(N, Hf, Wf, D, act, cuda):
     """One single-channel 3x3x3 layer over (d, y, x), zero padded in all three dimensions: BIT-EXACT against
-    oracle_agg3d (same fmaf order, SiLU through the shared exp polynomial); ragged row segments (Wf not a multiple of
-    the 64-pixel tile), one-pixel volumes and D = 4 (every quad is a border quad) included."""
+    oracle_agg3d (same fmaf order, SiLU through the shared exp polynomial); ragged column strips (Wf not a multiple of
+    the strip width), several row bands with a ragged last one, one-pixel volumes and D = 4 (every quad is a border quad)
+    included."""
     lib = _lib.load()
     rng = np.random.RandomState(7 * D + Wf)
     vol = rng.normal(0, 1.5, (N, Hf, Wf, D)).astype(np.float32)
@@ -357,6 +361,37 @@ def test_agg3d_layer_bit_exact(N, Hf, Wf, D, act, cuda):
     # argument checks: in place, D not a multiple of 4
     assert lib.st_volume_agg3d(ptr(src), ptr(src), N, Hf, Wf, D, w27, bias, act, current_stream()) != 0
     assert lib.st_volume_agg3d(ptr(src), ptr(dst), N, Hf, Wf, 6, w27, bias, act, current_stream()) != 0
+
+
+def test_full_resolution_sizing_composition_d192_bit_exact(cuda):
+    """north_star's literal sizing as a TESTED composition, not only a timed kernel: a D = 192-level volume at full
+    resolution (a 64 x 256 crop; C = 8 features) built by st_costvolume_softargmin in slabs (2 x 96 disparities),
+    aggregated by st_volume_agg3d (3x3x3 over d, y, x across the slab boundary), regressed by st_softargmin - each
+    stage BIT-EXACT against oracle/st_oracle.c, end to end (consumer contract: loading_disparity.py:85-86,129-134 -
+    float32 pixels per full-resolution pixel)."""
+    lib = _lib.load()
+    N, Hf, Wf, Cc, D, T = 1, 64, 256, 8, 192, 4.0
+    rng = np.random.RandomState(192)
+    fl = rng.normal(0, 1, (N, Hf, Wf, Cc)).astype(np.float32)
+    fr = rng.normal(0, 1, (N, Hf, Wf, Cc)).astype(np.float32)
+    w = rng.normal(0, 0.3, (3, 3, 3)).astype(np.float32)
+    w[1, 1, 1] += 1.0
+    ref_vol = c_oracle.costvolume(fl, fr, Cc, D)
+    ref_agg = c_oracle.agg3d(ref_vol, w, 0.0, 0)
+    ref_disp = c_oracle.softargmin(ref_agg, T)
+    l, r = torch.from_numpy(fl).to(cuda), torch.from_numpy(fr).to(cuda)
+    vol = torch.full((N, Hf, Wf, D), float('nan'), device=cuda)
+    agg = torch.full((N, Hf, Wf, D), float('nan'), device=cuda)
+    disp = torch.full((N, Hf, Wf), float('nan'), device=cuda)
+    w27 = (C.c_float * 27)(*w.reshape(-1).tolist())
+    check(lib.st_costvolume_softargmin(ptr(l), ptr(r), N, Hf, Wf, Cc, Cc, D, T, ptr(vol), None, current_stream()))
+    check(lib.st_volume_agg3d(ptr(vol), ptr(agg), N, Hf, Wf, D, w27, 0.0, 0, current_stream()), 'st_volume_agg3d')
+    check(lib.st_softargmin(ptr(agg), N, Hf, Wf, D, T, ptr(disp), current_stream()))
+    torch.cuda.synchronize()
+    assert np.array_equal(vol.cpu().numpy().view(np.uint32), ref_vol.view(np.uint32))
+    assert np.array_equal(agg.cpu().numpy().view(np.uint32), ref_agg.view(np.uint32))
+    assert np.array_equal(disp.cpu().numpy().view(np.uint32), ref_disp.view(np.uint32))
+    assert np.isfinite(ref_disp).all() and ref_disp.min() >= 0 and ref_disp.max() <= D - 1
 
 
 @pytest.mark.parametrize('agg3d_layers,agg_layers', [(1, 0), (2, 0), (2, 1)])

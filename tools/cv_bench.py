@@ -28,3 +28,24 @@ for name, oc, od in (('volume only', cost, None), ('fused soft-argmin only', Non
     e1.record()
     torch.cuda.synchronize()
     print(f'costvolume ({name}): {e0.elapsed_time(e1) / reps * 1e3:.1f} us')
+
+# ---- 3-D aggregation layer (st_volume_agg3d: single-channel 3x3x3 over d, y, x; algorithmic traffic = volume read once +
+# written once) at the bench volume and at the full-resolution sizing of SURVEY.md 8(d) (D = 192 x 720 x 1280, one pair)
+import ctypes as C  # noqa: E402
+w27 = (C.c_float * 27)(*[0.03 * ((i * 7) % 11 - 5) for i in range(27)])
+for label, (n, hf, wf, d) in (('bench volume 8x184x320x48', (8, 184, 320, 48)), ('full-res 1x720x1280x192', (1, 720, 1280, 192))):
+    vin = torch.randn(n, hf, wf, d, device=dev)
+    vout = torch.empty_like(vin)
+    for _ in range(3):
+        check(lib.st_volume_agg3d(ptr(vin), ptr(vout), n, hf, wf, d, w27, 0.01, 1, None))
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        check(lib.st_volume_agg3d(ptr(vin), ptr(vout), n, hf, wf, d, w27, 0.01, 1, None))
+    e1.record()
+    torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) / reps * 1e3
+    nbytes = 2.0 * vin.numel() * 4
+    print(f'agg3d ({label}): {us:.1f} us, algorithmic {nbytes / 1e6:.1f} MB -> {nbytes / us / 1e6:.2f} TB/s = {nbytes / us / 8e6:.2f} of 8 TB/s')
+    del vin, vout

@@ -46,10 +46,31 @@ tot /= a.steps
 buf = C.create_string_buffer(512)
 lines = []
 tiles = {v: lib.st_conv_variant_name(v).decode() for v in range(-1, 64)}
+# One row per LAUNCH.  An op computed inside the launch of the op in front of it (the fused front kernel's three ops, a
+# chained 1x1 pair, the riders of a grouped Winograd launch) has only its event pair's overhead as "duration": it is
+# recognised by a rate no launch of its own could have (above the fp32 MFMA peak, x2.25 for Winograd) and folded into
+# the leading row, time and flops together; it is listed under it without a rate.
+PEAK = 157.3
+descs = []
 for i in range(n):
     lib.st_detector_op_desc(det.handle, i, buf, 512)
-    tf = 2 * macs[i] / (tot[i] * 1e-3) / 1e12 if tot[i] > 0 and macs[i] > 0 else 0
-    lines.append(f'{i:3d} {tot[i] * 1e3:9.1f} us  {tiles[int(var[i])]:>8s} {2 * macs[i] / 1e9:8.2f} GF {tf:7.1f} TF/s  {buf.value.decode()}')
+    descs.append(buf.value.decode())
+leader = list(range(n))
+for i in range(1, n):
+    name = tiles[int(var[i])]
+    rate = 2 * macs[i] / (tot[i] * 1e-3) / 1e12 if tot[i] > 0 else 0.0
+    if kind[i] == 1 and kind[i - 1] == 1 and (name == 'wino2x2g+' or rate > PEAK * (2.25 if name.startswith('wino') else 1.0)):
+        leader[i] = leader[i - 1]
+for i in range(n):
+    if leader[i] != i:
+        lines.append(f'{i:3d}         +      {tiles[int(var[i])]:>8s} {2 * macs[i] / 1e9:8.2f} GF     (in launch {leader[i]})  {descs[i]}')
+        continue
+    members = [j for j in range(n) if leader[j] == i]
+    t = sum(tot[j] for j in members)
+    fl = 2 * sum(macs[j] for j in members)
+    tf = fl / (t * 1e-3) / 1e12 if t > 0 and fl > 0 else 0
+    lines.append(f'{i:3d} {t * 1e3:9.1f} us  {tiles[int(var[i])]:>8s} {fl / 1e9:8.2f} GF {tf:7.1f} TF/s  {descs[i]}'
+                 + (f'  [{len(members)} ops in this launch]' if len(members) > 1 else ''))
 agg_ms = np.asarray(agg_ms).mean(0) if agg_ms and agg_ms[0] else np.zeros(0)
 am = sm.agg_macs(a.batch, pipe.height // 4, pipe.width // 4)
 for l, t in enumerate(agg_ms):

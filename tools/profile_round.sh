@@ -3,7 +3,7 @@
 # MFMA-pipe utilisation and HBM traffic per kernel.  Outputs under gpurun_out/prof_$1; summaries are then copied to
 # profiles/ by hand.  rocprofv3 gets the program itself after `--` (no wrapper), counters in their own passes.
 set -e
-TAG=${1:-r04}
+TAG=${1:-r05}
 OUT=gpurun_out/prof_$TAG
 rm -rf $OUT      # stale traces of an earlier call must not be picked up below
 mkdir -p $OUT
