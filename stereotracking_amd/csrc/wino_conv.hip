@@ -24,6 +24,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -58,6 +59,7 @@ struct WinoArgs {
   int act;
   int tbx, tby, ncb, nkc;
   int g_last;   // channel groups of 8 that exist in the LAST K-chunk (4 unless Cin % 32 != 0)
+  unsigned nblocks, per_xcd, order, grid;   // workgroups of this problem and their order over the grid (wn_block_of)
   unsigned in_bytes, out_bytes, res_bytes, wino_bytes;
 };
 
@@ -318,9 +320,45 @@ __device__ __forceinline__ void wino_conv3x3_body(const WinoArgs& p, int b_) {
 #endif
 }
 
+// XCD-aware tile order.  Workgroup ids are dealt round-robin to the 8 XCDs (each with an L2 of its own), and the block
+// decomposition has the cout block fastest, then the window column: in launch order the `ncb` workgroups that DMA the
+// SAME 18 x 10 window sat behind different L2s and the window was fetched from memory once per cout block (round 4
+// counters: the 256-cout head conv0 fetched 3.7 x its input).  Order 2 (shipped) keeps the round-robin walk over the
+// WINDOWS - the chip advances through the map exactly as before - but gives all cout blocks of a window to ONE XCD in
+// consecutive slots: id = (xcd, slot) -> window (slot / ncb) * 8 + xcd, cout block slot % ncb.  Order 1 (every XCD
+// walks a contiguous range of blocks, halo columns shared too) measured 0.6 % slower under the in-flight loop than
+// launch order (profiles/r05_wino_order_ab.txt); order 0 = launch order.  Bijective on [0, nblocks); the padding ids exit.
+__device__ __forceinline__ bool wn_block_of(unsigned bid, unsigned order, unsigned per_xcd, unsigned ncb, unsigned nblocks,
+                                            unsigned& b) {
+  if (order == 2) {
+    const unsigned slot = bid >> 3;
+    b = ((slot / ncb) * 8u + (bid & 7u)) * ncb + slot % ncb;
+  } else if (order == 1) {
+    b = (bid & 7u) * per_xcd + (bid >> 3);
+  } else {
+    b = bid;
+  }
+  return b < nblocks;
+}
+static unsigned wn_order() {
+#ifdef ST_ABLATION
+  if (const char* e = getenv("ST_WINO_ORDER")) return (unsigned)atoi(e);
+#endif
+  return 2u;
+}
+// grid size of `blocks` workgroups (ncb cout blocks per window) under an order; per_xcd is order 1's range length
+static unsigned wn_grid(long long blocks, unsigned ncb, unsigned order, unsigned* per_xcd) {
+  *per_xcd = (unsigned)((blocks + 7) / 8);
+  if (order == 1) return 8u * *per_xcd;
+  if (order == 2) return (unsigned)((blocks / ncb + 7) / 8 * 8 * ncb);
+  return (unsigned)blocks;
+}
+
 template <int CBN, int LCBN, bool RES, bool KTAIL>
 __global__ __launch_bounds__(256, 2) void wino_conv3x3_kernel(const WinoArgs p) {
-  wino_conv3x3_body<CBN, LCBN, RES, KTAIL>(p, (int)blockIdx.x);
+  unsigned b;
+  if (!wn_block_of(blockIdx.x, p.order, p.per_xcd, (unsigned)p.ncb, p.nblocks, b)) return;   // uniform
+  wino_conv3x3_body<CBN, LCBN, RES, KTAIL>(p, (int)b);
 }
 
 // GROUPED launch: up to WN_GROUP_MAX independent layers of the same instance (same cout blocking, no residual) share
@@ -333,17 +371,20 @@ __global__ __launch_bounds__(256, 2) void wino_conv3x3_kernel(const WinoArgs p) 
 constexpr int WN_GROUP_MAX = 6;
 struct WinoGroupArgs {
   WinoArgs p[WN_GROUP_MAX];
-  unsigned first[WN_GROUP_MAX + 1];   // first[k] = first block of problem k; first[n] = grid size
+  unsigned first[WN_GROUP_MAX + 1];   // first[k] = first grid id of problem k (a multiple of 8); first[n] = grid size
   int n;
 };
 
 template <int CBN, int LCBN>
 __global__ __launch_bounds__(256, 2) void wino_conv3x3_group_kernel(const WinoGroupArgs g) {
-  const unsigned b = blockIdx.x;
+  const unsigned bid = blockIdx.x;
   int k = 0;
 #pragma unroll
-  for (int q = 1; q < WN_GROUP_MAX; ++q) k += (q < g.n && b >= g.first[q]) ? 1 : 0;
-  wino_conv3x3_body<CBN, LCBN, false, false>(g.p[k], (int)(b - g.first[k]));
+  for (int q = 1; q < WN_GROUP_MAX; ++q) k += (q < g.n && bid >= g.first[q]) ? 1 : 0;
+  // every problem owns a grid range of its own that starts at a multiple of 8: the local id keeps the block's XCD
+  unsigned b;
+  if (!wn_block_of(bid - g.first[k], g.p[k].order, g.p[k].per_xcd, (unsigned)g.p[k].ncb, g.p[k].nblocks, b)) return;
+  wino_conv3x3_body<CBN, LCBN, false, false>(g.p[k], (int)b);
 }
 
 }  // namespace
@@ -417,7 +458,7 @@ static int wino_launch_instance(const WinoArgs& a, unsigned blocks, hipStream_t 
   static int lds_set = 0;
   auto kern = wino_conv3x3_kernel<CBN, LCBN, RES, KTAIL>;
   ST_ENSURE_DYNAMIC_LDS(kern, lds, lds_set);
-  hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), lds, stream, a);
+  hipLaunchKernelGGL(kern, dim3(a.grid), dim3(256), lds, stream, a);
   return ST_OK;
 }
 
@@ -444,7 +485,10 @@ static int wino_fill_args(const StConvDesc& d, bool narrow, WinoArgs& a, long lo
   a.wino_bytes = (unsigned)(wino_packed_floats(d.Cout, d.Cin) * 4);
   a.g_last = 4 - (a.nkc * 32 - d.Cin) / 8;          // whole groups of 8 padded channels are skipped
   const long long blocks = (long long)d.N * a.tbx * a.tby * a.ncb;
-  ST_REQUIRE(blocks < (1ll << 31), "winograd conv: grid too large");
+  ST_REQUIRE(blocks + 8 < (1ll << 31), "winograd conv: grid too large");
+  a.nblocks = (unsigned)blocks;
+  a.order = wn_order();
+  a.grid = wn_grid(blocks, (unsigned)a.ncb, a.order, &a.per_xcd);
   *blocks_out = blocks;
   return ST_OK;
 }
@@ -490,8 +534,8 @@ int wino_group_launch(const StConvDesc* d, int n, hipStream_t stream) {
     long long blocks = 0;
     ST_CHECK(wino_fill_args(d[k], false, g.p[k], &blocks));
     g.first[k] = (unsigned)total;
-    total += blocks;
-    ST_REQUIRE(total < (1ll << 31), "winograd group: grid too large");
+    total += (g.p[k].grid + 7u) / 8u * 8u;       // the next problem starts at a multiple of 8 (launch order: pad, ids exit)
+    ST_REQUIRE(total + 8 < (1ll << 31), "winograd group: grid too large");
   }
   for (int k = n; k <= WN_GROUP_MAX; ++k) g.first[k] = (unsigned)total;
   constexpr int lds = wn_lds_floats(2) * (int)sizeof(float);
