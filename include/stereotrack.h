@@ -276,11 +276,13 @@ int st_detector_op_times(StDetector* det, int cap, float* ms, int* kind, int* va
 int st_detector_op_desc(const StDetector* det, int i, char* buf, int cap);
 /* Measure every valid conv tile variant on every conv op's real shape and keep the fastest
  * (host-synchronous; call once after st_detector_finalize, never inside a timed region). */
-/* Split-operand instances (tile variants 50 = 128x128, 51 = 64x64, 52 = 128x64 of st_conv2d_nhwc_variant): the same
- * implicit GEMM with every fp32 operand split into three bf16 terms (error-free: 3 x 8 = 24 mantissa bits), six exact
- * term products on v_mfma_f32_32x32x16_bf16, fp32 accumulate - 2.67x the fp32 matrix rate, error against float64
- * BELOW the fp32-input MFMA's (profiles/r04_bf16x3_microbench.txt).  Off by default: st_detector_autotune considers
- * them only after st_detector_set_split(det, 1). */
+/* Split-operand instances (tile variants 50-55 of st_conv2d_nhwc_variant): the same implicit GEMM with every fp32 operand
+ * split into three bf16 terms (error-free: 3 x 8 = 24 mantissa bits), six exact term products on
+ * v_mfma_f32_32x32x16_bf16, fp32 accumulate.  PARKED (round 5): the plan built from them did not pass the frozen parity
+ * gate (profiles/r05_gpu_tests_split_plan.log) and bought +0.7 % in flight, so they exist in the TOOLS build only
+ * (make ABLATION=1).  st_split_instances_available() = 1 there, 0 in the product library, where
+ * st_detector_set_split(det, allow != 0) and variants 50-55 return an error; st_detector_set_split(det, 0) is a no-op. */
+int st_split_instances_available(void);
 int st_detector_set_split(StDetector* det, int allow);
 int st_detector_autotune(StDetector* det, void* workspace_dev, size_t workspace_bytes,
                          float* head_out_dev, st_stream_t stream, int reps);

@@ -452,6 +452,12 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(ConvKArgs p) {
   conv_epilogue<TM, TN>(p, acc, m0, n0, wm, wn, l31, lh, BM, BN);
 }
 
+// ==== TOOLS-ONLY from here to the matching #endif (make ABLATION=1; round-5 decision) ====================
+// The split-operand instances below did not pass the round's frozen parity gate (`ST_SPLIT_BF16=1 pytest -m gpu`:
+// profiles/r05_gpu_tests_split_plan.log - the two white-noise configs[2] cases read 1.59e-3 from float64 against a bound
+// of 1.29e-3) and bought +0.7 % under the in-flight loop: they are PARKED.  The product library contains no bf16 MFMA
+// and no way to select one; tools/split_*.py and the split tests run against the tools build (ST_LIBRARY=...ablation.so).
+#ifdef ST_ABLATION
 // ---- split-operand instance ("bf16x3"): the same implicit GEMM on the BF16 matrix pipes ------------------------------
 // fp32 operands are split into three bf16 terms, x = hi + mid + lo (3 x 8 = 24 mantissa bits: the split is error-free),
 // and the product is assembled from 6 of the 9 term products (hi.hi, hi.mid, mid.hi, hi.lo, lo.hi, mid.mid; the dropped
@@ -750,6 +756,8 @@ static int launch_split(const ConvKArgs& a, int m_tiles, hipStream_t stream) {
   return ST_OK;
 }
 
+#endif   // ST_ABLATION: split-operand instances
+
 #ifdef ST_ABLATION   // tools-only build: the wave-specialised experiment (instances 22..29) lives in its own file
 #include "experiments/conv_igemm_ws.inc"
 #endif
@@ -901,6 +909,11 @@ int conv2d_launch(const StConvDesc& d, hipStream_t stream, int force_variant, in
     static const int sbm[3] = {128, 64, 128}, sbn[3] = {128, 64, 64};
     const int vi = (force_variant - 50) % 3, k16 = (force_variant - 50) / 3;
     ST_REQUIRE(cout_pad % sbn[vi] == 0, "conv: split variant %d does not divide Cout=%d", force_variant, d.Cout);
+#ifndef ST_ABLATION
+    (void)sbm; (void)k16;
+    return set_error(ST_ERR_INVALID, "conv: the split-operand (bf16x3) instances 50-55 are parked in the tools-only build "
+                                     "(make ABLATION=1, ST_LIBRARY=...libstereotrack_hip_ablation.so)");
+#else
     if (picked_variant) *picked_variant = force_variant;
     a.n_tiles = cout_pad / sbn[vi];
     const int m_tiles = ceil_div(a.M, sbm[vi]);
@@ -913,6 +926,7 @@ int conv2d_launch(const StConvDesc& d, hipStream_t stream, int force_variant, in
       case 4: return pw ? launch_split<1, 1, 2, 2, 1, 16>(a, m_tiles, stream) : launch_split<1, 1, 2, 2, 0, 16>(a, m_tiles, stream);
       default: return pw ? launch_split<1, 2, 4, 1, 1, 16>(a, m_tiles, stream) : launch_split<1, 2, 4, 1, 0, 16>(a, m_tiles, stream);
     }
+#endif
   }
   int pick = -1;
   if (force_variant >= 0) {

@@ -1090,9 +1090,22 @@ extern "C" int st_detector_autotune(StDetector* det, void* workspace_dev, size_t
   return rc;
 }
 
-// Allow (1) / forbid (0, default) the split-operand (bf16x3) instances in st_detector_autotune's search.
+// Allow (1) / forbid (0, default) the split-operand (bf16x3) instances in st_detector_autotune's search.  The instances
+// are PARKED in the tools-only build (round 5: they do not pass the frozen parity gate): the product library
+// accepts 0 only.
+extern "C" int st_split_instances_available(void) {
+#ifdef ST_ABLATION
+  return 1;
+#else
+  return 0;
+#endif
+}
+
 extern "C" int st_detector_set_split(StDetector* det, int allow) {
   if (!det) return set_error(ST_ERR_INVALID, "st_detector_set_split: null detector");
+  if (allow != 0 && !st_split_instances_available())
+    return set_error(ST_ERR_INVALID, "st_detector_set_split: the split-operand (bf16x3) instances are not part of the product "
+                                     "library (parked in the tools build: make ABLATION=1, ST_LIBRARY=<that library>)");
   det->allow_split = allow == 1 ? 0x3F : (allow & 0x3F);   // 1 = all six instances; otherwise a mask (bit i = variant 50 + i)
   return ST_OK;
 }

@@ -320,14 +320,16 @@ __device__ __forceinline__ void wino_conv3x3_body(const WinoArgs& p, int b_) {
 #endif
 }
 
-// XCD-aware tile order.  Workgroup ids are dealt round-robin to the 8 XCDs (each with an L2 of its own), and the block
-// decomposition has the cout block fastest, then the window column: in launch order the `ncb` workgroups that DMA the
-// SAME 18 x 10 window sat behind different L2s and the window was fetched from memory once per cout block (round 4
-// counters: the 256-cout head conv0 fetched 3.7 x its input).  Order 2 (shipped) keeps the round-robin walk over the
-// WINDOWS - the chip advances through the map exactly as before - but gives all cout blocks of a window to ONE XCD in
-// consecutive slots: id = (xcd, slot) -> window (slot / ncb) * 8 + xcd, cout block slot % ncb.  Order 1 (every XCD
-// walks a contiguous range of blocks, halo columns shared too) measured 0.6 % slower under the in-flight loop than
-// launch order (profiles/r05_wino_order_ab.txt); order 0 = launch order.  Bijective on [0, nblocks); the padding ids exit.
+// Block order over the grid (measured A/B: profiles/r05_wino_order_ab.txt).  Workgroup ids are dealt round-robin to
+// the 8 XCDs (each with an L2 of its own) and the block decomposition has the cout block fastest, so in LAUNCH order
+// (order 0) the `ncb` workgroups that DMA the same 18 x 10 window sit behind different L2s: the 256-cout head conv0
+// pulls 445 MB per launch through its L2s for 119 MB of input (round-4 counters: 3.7 x).  Two XCD-aware orders were
+// built: order 1 (every XCD walks a contiguous range of blocks: 247 MB) and order 2 (round-robin over the WINDOWS, all
+// cout blocks of a window on one XCD in consecutive slots: 283 MB).  Both make the kernels ~1 % faster ALONE and the
+// pipeline 0.6-0.8 % SLOWER under the in-flight loop (1832-1837 against 1844-1847 pairs/s, two runs each on one box):
+// the re-fetches of launch order are hits in the memory-side Infinity Cache, not HBM reads, and with four contexts in
+// flight the chip-wide walk of launch order co-runs better.  The product ships order 0; the others stay selectable
+// in the tools build (ST_WINO_ORDER).  Every order is bijective on [0, nblocks); padding ids exit.
 __device__ __forceinline__ bool wn_block_of(unsigned bid, unsigned order, unsigned per_xcd, unsigned ncb, unsigned nblocks,
                                             unsigned& b) {
   if (order == 2) {
@@ -344,7 +346,7 @@ static unsigned wn_order() {
 #ifdef ST_ABLATION
   if (const char* e = getenv("ST_WINO_ORDER")) return (unsigned)atoi(e);
 #endif
-  return 2u;
+  return 0u;
 }
 // grid size of `blocks` workgroups (ncb cout blocks per window) under an order; per_xcd is order 1's range length
 static unsigned wn_grid(long long blocks, unsigned ncb, unsigned order, unsigned* per_xcd) {

@@ -110,12 +110,16 @@ class StereoDensePipeline:
         self.agg_layers = self.stereo_module.agg_layers
         self.agg3d_layers = self.stereo_module.agg3d_layers
         # split_bf16: the autotuner may pick the split-operand (bf16x3) conv instances (fp32 operands as three bf16 terms,
-        # six exact products on the bf16 MFMA, fp32 accumulate: 2.67x the fp32 matrix rate, error vs float64 below the
-        # fp32-input MFMA's).  Off by default: the default plan is exact-fp32 MFMA only.
+        # six exact products on the bf16 MFMA, fp32 accumulate).  PARKED in round 5 (frozen parity gate not passed, +0.7 % in
+        # flight: DESIGN.md 5): the instances exist in the TOOLS build of the library only ($ST_LIBRARY pointing at
+        # libstereotrack_hip_ablation.so); with the product library the request is an error, not a silent fallback.
         if split_bf16 is None:
             import os
             split_bf16 = os.environ.get('ST_SPLIT_BF16', '0') == '1'
         self.split_bf16 = bool(split_bf16)
+        if self.split_bf16 and not self.lib.st_split_instances_available():
+            raise RuntimeError('split_bf16 / ST_SPLIT_BF16=1: the split-operand (bf16x3) conv instances are parked in the '
+                               'tools build (make -C stereotracking_amd/csrc ABLATION=1; ST_LIBRARY=<...>_ablation.so)')
         self.max_disp, self.feat_stride = int(max_disp), int(feat_stride)
         self.disp_buffers, self.disp_guard, self.disp_slot, self._disp_turn = 1, [None], 0, 0
         self.D = self.stereo_module.levels

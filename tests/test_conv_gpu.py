@@ -688,7 +688,32 @@ def test_chained_resident_pointwise_pair_matches_torch(cin, N, H, W, cuda):
 
 
 # ---- split-operand (bf16x3) instances of the implicit GEMM: variants 50 (128x128), 51 (64x64), 52 (128x64) -----------
+# PARKED in the tools build since round 5: these tests run when $ST_LIBRARY points at
+# libstereotrack_hip_ablation.so and are skipped on the product library, where the variants must be REFUSED.
 SPLIT_BN = {50: 128, 51: 64, 52: 64, 53: 128, 54: 64, 55: 64}
+
+
+def _need_split_instances():
+    if not _lib.load().st_split_instances_available():
+        pytest.skip('split-operand instances are parked in the tools build (ST_LIBRARY=...ablation.so)')
+
+
+def test_product_library_refuses_the_parked_split_instances(cuda):
+    lib = _lib.load()
+    if lib.st_split_instances_available():
+        pytest.skip('tools build')
+    x = torch.randn(1, 64, 8, 8)
+    w = torch.randn(128, 64, 1, 1) / 8.0
+    with pytest.raises(RuntimeError, match='parked'):
+        run_conv(x, w, torch.zeros(128), 1, 0, 1, cuda, variant=51)
+    from stereotracking_amd.engine import HipDetector
+    det = HipDetector(1, 64, 64, 0.375, 0.33, 1)
+    det.set_split(False)                                  # 0 stays a no-op
+    with pytest.raises(RuntimeError, match='tools build'):
+        det.set_split(True)
+    from stereotracking_amd.pipeline import StereoDensePipeline
+    with pytest.raises(RuntimeError, match='tools build'):
+        StereoDensePipeline(1, (64, 64), 0.375, 0.33, 1, stereo=False, split_bf16=True)
 
 
 @pytest.mark.parametrize('variant', [50, 51, 52, 53, 54, 55])
@@ -697,6 +722,7 @@ def test_conv_split_bf16x3_matches_torch(variant, case, cuda):
     """fp32 operands split into three bf16 terms, six exact term products on v_mfma_f32_32x32x16_bf16, fp32 accumulate:
     the same 1e-4-of-scale bar as every exact-fp32 instance (the split is error-free; measured error against float64 is
     BELOW the fp32-input MFMA's, asserted in test_conv_split_is_at_least_as_accurate_as_fp32_mfma)."""
+    _need_split_instances()
     N, Cin, H, W, Cout, k, stride = case
     if ((Cout + 31) // 32 * 32) % SPLIT_BN[variant]:
         pytest.skip('tile does not divide Cout')
@@ -711,6 +737,7 @@ def test_conv_split_bf16x3_matches_torch(variant, case, cuda):
 def test_conv_split_epilogues(cuda):
     """The split instances share conv_epilogue with the fp32 ones: residual + post_scale, split stores, upsampled store,
     input channel slice."""
+    _need_split_instances()
     torch.manual_seed(11)
     x = torch.randn(2, 64, 8, 12)
     w = torch.randn(128, 64, 1, 1) / 8.0
@@ -727,6 +754,7 @@ def test_conv_split_epilogues(cuda):
 def test_conv_split_is_at_least_as_accurate_as_fp32_mfma(cuda):
     """The argument for the split instances is accuracy, not only speed: on a head-tower-sized reduction (K = 1152) the
     error against a float64 evaluation must not exceed the exact-fp32 MFMA instance's (measured: about 0.6x)."""
+    _need_split_instances()
     torch.manual_seed(3)
     x = torch.randn(2, 128, 24, 40) * torch.randn(2, 128, 24, 40).abs()     # activation-like magnitudes
     w = torch.randn(128, 128, 3, 3) / (128 * 9) ** 0.5

@@ -436,3 +436,7 @@ def test_shipped_code_has_no_packed_fp32_operand_select():
     assert n_packed > 0          # the Winograd transforms do use packed fp32 (default operand selection)
     bad = [(sym, ins) for sym, lines in code.items() for ins in lines if ins.startswith('v_pk_') and 'op_sel' in ins]
     assert not bad, f'{len(bad)} packed instructions with op_sel, e.g. {bad[:3]}'
+    # and the product library brings no bf16 MFMA of its own (the split-operand instances are parked in the tools build)
+    bf16 = [(sym, ins) for sym, lines in code.items() for ins in lines if ins.startswith('v_mfma') and 'bf16' in ins]
+    assert not bf16 and not any('conv_split' in sym for sym in code), bf16[:3]
+    assert _lib.load().st_split_instances_available() == 0

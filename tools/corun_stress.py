@@ -8,6 +8,9 @@ import sys
 
 import torch
 
+_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+# the split-operand (bf16x3) instances are parked in the TOOLS build of the library (round 5)
+os.environ.setdefault('ST_LIBRARY', os.path.join(_ROOT, 'stereotracking_amd', 'lib', 'libstereotrack_hip_ablation.so'))
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from stereotracking_amd import _lib  # noqa: E402
 from stereotracking_amd._lib import StConvDesc, check, ptr  # noqa: E402

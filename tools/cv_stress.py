@@ -7,6 +7,9 @@ import sys
 
 import torch
 
+_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+# the split-operand (bf16x3) instances are parked in the TOOLS build of the library (round 5)
+os.environ.setdefault('ST_LIBRARY', os.path.join(_ROOT, 'stereotracking_amd', 'lib', 'libstereotrack_hip_ablation.so'))
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from stereotracking_amd import _lib  # noqa: E402
 from stereotracking_amd._lib import StConvDesc, check, ptr  # noqa: E402
@@ -61,7 +64,12 @@ ds.Cout, ds.KH, ds.KW, ds.stride, ds.pad = 128, 1, 1, 1, 0
 ds.out1_dev = outs_s.data_ptr(); ds.out1_ld, ds.out1_off, ds.split = 128, 0, 128
 ds.act, ds.post_scale = 1, 1.0
 extra = [torch.cuda.Stream() for _ in range(2)]
-SPLITV = [int(v) for v in (sys.argv[1:] or ['53', '54', '50', '51'])]
+# aggressor: the library's split instances (default), or `torch`: bf16 GEMMs of ANOTHER library in the process
+# (torch.matmul -> hipBLASLt / rocBLAS kernels issuing bf16 MFMAs) - the case the product library has to survive
+TORCH_AGG = len(sys.argv) > 1 and sys.argv[1] == 'torch'
+SPLITV = [] if TORCH_AGG else [int(v) for v in (sys.argv[1:] or ['53', '54', '50', '51'])]
+ga = torch.randn(4096, 4096, device=dev).to(torch.bfloat16)
+gb = torch.randn(4096, 4096, device=dev).to(torch.bfloat16)
 
 ref = []
 refvol = []
@@ -79,6 +87,10 @@ for rep in range(60):
         if i < len(extra):
             for v in SPLITV:
                 check(lib.st_conv2d_nhwc_variant(C.byref(ds), C.c_void_p(extra[i].cuda_stream), v))
+            if TORCH_AGG:
+                with torch.cuda.stream(extra[i]):
+                    for _ in range(3):
+                        torch.matmul(ga, gb)
         launch(i, s)
     torch.cuda.synchronize()
     for i in range(NS):

@@ -7,6 +7,9 @@ import sys
 import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+# the split-operand (bf16x3) instances are parked in the TOOLS build of the library (round 5)
+os.environ.setdefault('ST_LIBRARY', os.path.join(_ROOT, 'stereotracking_amd', 'lib', 'libstereotrack_hip_ablation.so'))
 sys.path.insert(0, ROOT)
 from stereotracking_amd.pipeline import InflightPipelines  # noqa: E402
 from stereotracking_amd.synthetic import synthetic_batch, synthetic_state_dict  # noqa: E402
