@@ -152,7 +152,10 @@ static inline int cvt_row(int n) {  // >= n, multiple of 4, (row / 4) odd
 // FMA: how the diagonal accumulator pairs (below) are evaluated.  Every form runs the same fmaf chains, bit-identical:
 //   0  two scalar v_fma_f32 per pair;
 //   1  one v_pk_fma_f32 with the R operand broadcast by op_sel / op_sel_hi (what the compiler makes of f32x2{r, r});
-//   2  one v_pk_fma_f32 WITHOUT op_sel on an explicit (r, r) register pair (one v_mov pair per window element and channel).
+//   2  one v_pk_fma_f32 WITHOUT op_sel on an explicit (r, r) register pair (one v_mov pair per window element and channel);
+//   3  ROW pairs: (acc[p][k], acc[p][k-1]) += (L[p], L[p]) * (R[i], R[i+1]) with i = DG + p - k EVEN, so that the R pair is an
+//      aligned 64-bit half of the ds_read_b128 result and only the four L values need an explicit (l, l) pair: one
+//      v_pk_fma_f32 without op_sel, 22 packed + 4 scalar FMAs + 8 moves per channel (form 0: 48, form 1: 22 + 4 + 3).
 // Round 4 found form 1 returning wrong sums while bf16 MFMAs of another kernel execute on the chip (tools/cv_stress.py,
 // tools/micro/pkfma_corun.hip): the product library instantiates and launches form 0 only (see
 // st_costvolume_softargmin; tests/test_cpu_oracle_and_abi.py checks the built code object for packed-fp32 op_sel).
@@ -199,6 +202,17 @@ __global__ __launch_bounds__(128) void costvolume_tiled_kernel(const float* __re
 #pragma unroll
     for (int k = 0; k < DG - 1; ++k) accd[q][k] = f32x2{0.f, 0.f};
     accs[q][0] = accs[q][1] = 0.f;
+  }
+  // Form 3, ROW pairs: accr[p][j] = (acc[p][k], acc[p][k-1]) with k = 2j + 2 for the even pixels (j < DG/2 - 1; k = 0 and
+  // k = DG-1 stay scalar in acce[p/2][0..1]) and k = 2j + 1 for the odd pixels (j < DG/2): then the window index
+  // i = DG + p - k of the pair's first element is even and (R[i], R[i+1]) is one aligned register pair.
+  f32x2 accr[FMA == 3 ? 4 : 1][FMA == 3 ? DG / 2 : 1];
+  float acce[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
+  if (FMA == 3) {
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+#pragma unroll
+      for (int j = 0; j < DG / 2; ++j) accr[p][j] = f32x2{0.f, 0.f};
   }
 
   // Staging of one channel chunk, transposed to [c][x].  Lane order: 16 consecutive lanes = 16 consecutive
@@ -275,6 +289,27 @@ __global__ __launch_bounds__(128) void costvolume_tiled_kernel(const float* __re
         lv[h ^ 1] = *reinterpret_cast<const f32x4*>(lp + cn * rowL);
 #pragma unroll
         for (int q = 0; q < NW / 4; ++q) rv[h ^ 1][q] = *reinterpret_cast<const f32x4*>(rp + cn * rowR + 4 * q);
+        if (FMA == 3) {
+#pragma unroll
+          for (int p = 0; p < 4; ++p) {
+            const float l = lv[h][p];
+            f32x2 ld = {l, l};
+            asm volatile("" : "+v"(ld));   // an explicit (l, l) register pair: the broadcast must not become op_sel
+            const int odd = p & 1;
+#pragma unroll
+            for (int j = 0; j < DG / 2 - 1 + odd; ++j) {
+              const int k = 2 * j + 2 - odd;          // the pair's first disparity; i = window index of (p, k), even
+              const int i = DG + p - k;
+              const f32x4 w = rv[h][i >> 2];
+              const f32x2 rp = (i & 2) ? f32x2{w[2], w[3]} : f32x2{w[0], w[1]};
+              accr[p][j] = __builtin_elementwise_fma(ld, rp, accr[p][j]);
+            }
+            if (!odd) {   // k = 0 (i = DG + p) and k = DG - 1 (i = p + 1) of the even pixels
+              acce[p >> 1][0] = fmaf(l, rv[h][(DG + p) >> 2][(DG + p) & 3], acce[p >> 1][0]);
+              acce[p >> 1][1] = fmaf(l, rv[h][(p + 1) >> 2][(p + 1) & 3], acce[p >> 1][1]);
+            }
+          }
+        } else {
         // FMA == 2: window elements 2 .. DG+2 as explicit (r, r) pairs; the empty asm makes each pair an opaque value, so
         // the compiler has to build it in a register pair of its own instead of folding the broadcast into op_sel
         f32x2 rdup[FMA == 2 ? DG + 1 : 1];
@@ -301,6 +336,7 @@ __global__ __launch_bounds__(128) void costvolume_tiled_kernel(const float* __re
           accs[q][0] = fmaf(lpair[0], rv[h][(ilo + 2 * q) >> 2][(ilo + 2 * q) & 3], accs[q][0]);
           accs[q][1] = fmaf(lpair[1], rv[h][(ihi + 2 * q) >> 2][(ihi + 2 * q) & 3], accs[q][1]);
         }
+        }
       }
     }
     if (more) stage_store(buf ^ 1);
@@ -317,6 +353,22 @@ __global__ __launch_bounds__(128) void costvolume_tiled_kernel(const float* __re
     }
     acc[2 * q][DG - 1] = accs[q][0];
     acc[2 * q + 1][0] = accs[q][1];
+  }
+  if (FMA == 3) {
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const int odd = p & 1;
+#pragma unroll
+      for (int j = 0; j < DG / 2 - 1 + odd; ++j) {
+        const int k = 2 * j + 2 - odd;
+        acc[p][k] = accr[p][j][0];
+        acc[p][k - 1] = accr[p][j][1];
+      }
+      if (!odd) {
+        acc[p][0] = acce[p >> 1][0];
+        acc[p][DG - 1] = acce[p >> 1][1];
+      }
+    }
   }
   // ---- cost = acc / C (0 where the match falls left of the image), optional volume store, fused soft-argmin
   const float fC = (float)C;
@@ -513,6 +565,7 @@ extern "C" int st_costvolume_softargmin(const float* featL_dev, const float* fea
   do {                                                                                                         \
     if (fma_mode == 1) ST_CVT_LAUNCH_I(DGV, 1);                                                                \
     else if (fma_mode == 2) ST_CVT_LAUNCH_I(DGV, 2);                                                           \
+    else if (fma_mode == 3) ST_CVT_LAUNCH_I(DGV, 3);                                                           \
     else ST_CVT_LAUNCH_I(DGV, 0);                                                                              \
   } while (0)
 #else

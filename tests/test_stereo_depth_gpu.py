@@ -55,16 +55,34 @@ def test_costvolume_bit_exact_and_softargmin(N, Hf, Wf, Cc, ld, D, cuda):
     assert np.array_equal(o.cpu().numpy().view(np.uint32), ref_disp.view(np.uint32))
 
 
+def _mfma_aggressor():
+    """tests/helpers/libmfma_aggressor.so (built by __graft_entry__.build(); rebuilt here when hipcc is at hand and the
+    file is missing): a kernel that keeps every SIMD busy with v_mfma_f32_16x16x32_bf16."""
+    import os
+    import subprocess
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'helpers')
+    so = os.path.join(here, 'libmfma_aggressor.so')
+    if not os.path.exists(so):
+        subprocess.check_call(['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-O3', '-shared', '-fPIC',
+                               os.path.join(here, 'mfma_aggressor.hip'), '-o', so])
+    lib = C.CDLL(so)
+    lib.st_test_bf16_mfma_busy.restype = C.c_int
+    lib.st_test_bf16_mfma_busy.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+    return lib
+
+
 def test_costvolume_beside_bf16_mfma_kernels_equals_serial_run(cuda):
     """Round-4 finding, closed structurally in round 5: a v_pk_fma_f32 whose source is broadcast by op_sel drops single
     16-lane passes of its low result half while bf16 MFMAs of ANY kernel execute on the chip (tools/micro/pkfma_corun.hip
     reproduces it in registers, profiles/r05_pkfma_corun.txt); the cost-volume kernel built that way returned a wrong
-    volume in 236 of 240 co-runs (profiles/r05_corun_cv_stress.txt).  The library ships the scalar-FMA form only and
-    contains no bf16 MFMA of its own any more, so the aggressor here is what a host process can always bring along:
-    bf16 GEMMs of another library (torch.matmul) on two side streams.  ONE co-run: four cost volumes on four streams
-    beside them; every volume must equal the one the same call gives alone, bit for bit (consumer contract:
-    ocsort_disparity.py:115,132-134 reads this disparity per box)."""
+    volume in 236 of 240 co-runs (profiles/r05_corun_cv_stress.txt).  The library ships a form without such operands and
+    contains no bf16 MFMA of its own any more, so the test brings the aggressor along (tests/helpers/mfma_aggressor.hip:
+    the register-only v_mfma_f32_16x16x32_bf16 loop that triggered the defect in 11 of 12 launches of the reproducer;
+    the old kernel form fails THIS test - verified with the tools build, profiles/r05_corun_cv_stress.txt).  ONE co-run:
+    four cost volumes on four streams beside the aggressor on two more; every volume must equal the one the same call
+    gives alone, bit for bit (consumer contract: ocsort_disparity.py:115,132-134 reads this disparity per box)."""
     lib = _lib.load()
+    agg = _mfma_aggressor()
     N, Hf, Wf, Cc, D = 8, 184, 320, 64, 48
     NS = 4
     g = torch.Generator(device='cpu').manual_seed(5)
@@ -83,17 +101,13 @@ def test_costvolume_beside_bf16_mfma_kernels_equals_serial_run(cuda):
         torch.cuda.synchronize()
         ref.append(vols[i].clone())
         vols[i].fill_(float('nan'))
-    ga = torch.randn(4096, 4096, generator=g).to(cuda).to(torch.bfloat16)
-    gb = torch.randn(4096, 4096, generator=g).to(cuda).to(torch.bfloat16)
-    torch.matmul(ga, gb)                                   # library warm-up (kernel selection) outside the co-run
+    scratch = torch.zeros(1024, device=cuda)
     streams = [torch.cuda.Stream() for _ in range(NS)]
     extra = [torch.cuda.Stream() for _ in range(2)]
     torch.cuda.synchronize()
     for i, s in enumerate(streams):
         if i < len(extra):
-            with torch.cuda.stream(extra[i]):
-                for _ in range(3):
-                    torch.matmul(ga, gb)                   # ~0.3 ms each of bf16 MFMAs on every CU
+            assert agg.st_test_bf16_mfma_busy(scratch.data_ptr(), 6000, extra[i].cuda_stream) == 0   # ~3 ms of bf16 MFMAs
         cost_volume(i, s)
     torch.cuda.synchronize()
     for i in range(NS):

@@ -66,8 +66,15 @@ ds.act, ds.post_scale = 1, 1.0
 extra = [torch.cuda.Stream() for _ in range(2)]
 # aggressor: the library's split instances (default), or `torch`: bf16 GEMMs of ANOTHER library in the process
 # (torch.matmul -> hipBLASLt / rocBLAS kernels issuing bf16 MFMAs) - the case the product library has to survive
+# or `micro`: the register-only v_mfma_f32_16x16x32_bf16 loop of tests/helpers/mfma_aggressor.hip (what the -m gpu co-run
+# test uses)
 TORCH_AGG = len(sys.argv) > 1 and sys.argv[1] == 'torch'
-SPLITV = [] if TORCH_AGG else [int(v) for v in (sys.argv[1:] or ['53', '54', '50', '51'])]
+MICRO_AGG = len(sys.argv) > 1 and sys.argv[1] == 'micro'
+SPLITV = [] if (TORCH_AGG or MICRO_AGG) else [int(v) for v in (sys.argv[1:] or ['53', '54', '50', '51'])]
+if MICRO_AGG:
+    agg_lib = C.CDLL(os.path.join(_ROOT, 'tests', 'helpers', 'libmfma_aggressor.so'))
+    agg_lib.st_test_bf16_mfma_busy.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+    agg_scratch = torch.zeros(1024, device=dev)
 ga = torch.randn(4096, 4096, device=dev).to(torch.bfloat16)
 gb = torch.randn(4096, 4096, device=dev).to(torch.bfloat16)
 
@@ -87,6 +94,8 @@ for rep in range(60):
         if i < len(extra):
             for v in SPLITV:
                 check(lib.st_conv2d_nhwc_variant(C.byref(ds), C.c_void_p(extra[i].cuda_stream), v))
+            if MICRO_AGG:
+                agg_lib.st_test_bf16_mfma_busy(agg_scratch.data_ptr(), 6000, extra[i].cuda_stream)
             if TORCH_AGG:
                 with torch.cuda.stream(extra[i]):
                     for _ in range(3):
