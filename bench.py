@@ -57,6 +57,10 @@ def parse():
     ap.add_argument('--agg3d-leg', action='store_true',
                     help='also time the workload with ONE 3-D aggregation layer (3x3x3 over d, y, x) in front of the 2-D '
                          'ones (secondary line; pair 0 checked against the CPU oracle)')
+    ap.add_argument('--fullres-leg', action='store_true',
+                    help='also time the workload with the stereo module in its FULL-RESOLUTION mode (a D=192 x 720 x 1280 volume '
+                         'per pair, one 3-D aggregation layer, soft-argmin at image resolution; secondary line, pair 0 checked '
+                         'against the CPU oracle: ~1 min of host time)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-test-step', action='store_true',
                     help='skip the second leg through Config.fromfile -> MODELS.build -> model.test_step')
@@ -506,6 +510,80 @@ def agg3d_leg(args, inputs, batch_cpu, headline, dev):
         return dict(error=repr(e))
 
 
+def fullres_leg(args, inputs, batch_cpu, headline, plan, dev):
+    """SECONDARY line, never `value`: north_star's literal sizing as a product path - StereoCostVolume(full_res=True):
+    stage-1 features reduced to 8 channels and brought to image resolution, a D = 192 level volume per pair at 736 x 1280
+    (181 M cells, 694 MB; materialised in two slabs of 96), ONE 3x3x3 aggregation layer over (d, y, x), soft-argmin in
+    pixels; then the same detector / decode / depth as the headline.  Two contexts in flight (11.6 GB of volumes each).
+    Pair 0's disparity is checked against the CPU oracle (oracle/stereo.py::disparity_fullres)."""
+    from oracle import stereo as ostereo
+    from oracle.torch_model import OracleDetector
+    from stereotracking_amd.pipeline import InflightPipelines
+    from stereotracking_amd.synthetic import synthetic_state_dict
+    try:
+        B, D = args.batch, args.max_disp
+        runner = InflightPipelines(2, B, (720, 1280), 0.5, 0.33, 1, stereo=True, max_disp=D, max_det=args.max_det,
+                                   agg_layers=0, agg3d_layers=1, full_res=True)
+        sd = synthetic_state_dict(runner.param_table(), seed=0)
+        g = torch.Generator().manual_seed(3)
+        w3 = torch.randn(1, 1, 3, 3, 3, generator=g) * 0.15
+        w3[0, 0, 1, 1, 1] += 1.0
+        sd['stereo.agg3d.0.weight'], sd['stereo.agg3d.0.bias'] = w3, torch.zeros(1)
+        runner.load_state_dict(sd, autotune=False)
+        for p in runner.pipes:                     # the detector graph is the headline's: reuse its committed plan
+            p.det.set_tuning(plan)
+        nb = len(inputs)
+        steps, warm = max(4, args.steps // 5), 2
+        for i in range(warm):
+            runner.submit(*inputs[i % nb])
+        runner.synchronize()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            runner.submit(*inputs[i % nb])
+        runner.synchronize()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        v = B * steps / dt
+        pipe = runner.pipes[0]
+        pipe.stereo_module.timing = True
+        out = pipe.run(*inputs[0])
+        torch.cuda.synchronize()
+        stages = pipe.stereo_module.pop_full_res_times()
+        pipe.stereo_module.timing = False
+        disp0 = out['disp_postp'][0, 0].cpu()
+        H, W = pipe.height, pipe.width
+        vol_bytes = 4.0 * B * H * W * D
+        cv_b = vol_bytes + 2 * 4.0 * B * H * W * 8
+        kern = dict(
+            cost_volume=dict(ms=round(stages['cost_volume'], 3), bytes=int(cv_b), frac_of_8TBs=round(cv_b / (stages['cost_volume'] * 1e-3) / 8e12, 4)),
+            agg3d=dict(ms=round(stages['agg3d'], 3), bytes=int(2 * vol_bytes), frac_of_8TBs=round(2 * vol_bytes / (stages['agg3d'] * 1e-3) / 8e12, 4)),
+            softargmin_pack=dict(ms=round(stages['softargmin_pack'], 3), bytes=int(vol_bytes), frac_of_8TBs=round(vol_bytes / (stages['softargmin_pack'] * 1e-3) / 8e12, 4)),
+            features_reduce_upsample_ms=round(stages['features_reduce_upsample'], 3))
+        # oracle, pair 0 (the C oracle walks 181 M cells three times: tens of seconds)
+        ora = OracleDetector(0.33, 0.5, 1).eval()
+        ora.load_state_dict(sd, strict=False)
+        img, right = batch_cpu['img'][:1], batch_cpu['right'][:1]
+        t1 = time.perf_counter()
+        with torch.no_grad():
+            fl = ora.backbone.stage1_features(img).permute(0, 2, 3, 1).contiguous().numpy()
+            fr = ora.backbone.stage1_features(right).permute(0, 2, 3, 1).contiguous().numpy()
+        ref = torch.from_numpy(ostereo.disparity_fullres(fl, fr, fl.shape[-1], D, 32.0, sd, 1, valid_hw=(720, 1280))[2])[0, 0]
+        ad = (disp0 - ref).abs()
+        return dict(value=round(v, 3), unit='stereo frame-pairs/s', ms_per_step=round(dt / steps * 1e3, 3), steps=steps,
+                    vs_headline=round(v / headline, 4), inflight_contexts=2,
+                    volume=dict(levels=D, height=H, width=W, cells_per_pair=D * H * W, bytes_per_pair=int(vol_bytes / B)),
+                    stage_ms_per_step_serialized=kern,
+                    disparity_vs_oracle_pair0=dict(l1_px=float(ad.mean()), max_abs_px=float(ad.max()),
+                                                   max_rel=float((ad / ref.abs().clamp(min=1.0)).max()),
+                                                   oracle_seconds=round(time.perf_counter() - t1, 1)),
+                    note='NOT the headline: the stereo module in full-resolution mode (reduce 64 -> 8, bilinear x4, D=192 levels at '
+                         '736x1280, one 3x3x3 aggregation layer, soft-argmin in pixels); the benched default correlates 64-channel '
+                         'features at 1/4 resolution (48 levels = the same 192 px range)')
+    except Exception as e:   # a secondary line must never cost the headline
+        return dict(error=repr(e))
+
+
 def test_step_leg(args, sd, batch_cpu, dev, pairs_target):
     """The SAME workload through the reference's plugin surface (SURVEY.md §8b "Callers"): Config.fromfile of the
     stereo config -> MODELS.build -> model.test_step(data), data = what a dataset pipeline yields (lists of (1,3,h,w)
@@ -842,6 +920,8 @@ def main():
         line['roofline'] = roof
         if world == 1 and args.agg3d_leg:
             line['secondary_agg3d'] = agg3d_leg(args, inputs, batch_cpu, line['value'], dev)
+        if world == 1 and args.fullres_leg:
+            line['secondary_full_resolution'] = fullres_leg(args, inputs, batch_cpu, line['value'], pipe.det.get_tuning(), dev)
         if world == 1 and not args.no_test_step:
             del runner   # its three workspaces are not needed any more
             line['test_step'] = test_step_leg(args, sd, batch_cpu, dev, B * args.steps)

@@ -374,6 +374,15 @@ int st_disp_upsample_pack(const float* disp_lr_dev, int N, int Hf, int Wf, int s
                           int W, int valid_h, int valid_w, float* disp_postp_dev,
                           st_stream_t stream);
 
+/* Bilinear x`scale` upsampling (align_corners=False) of an NHWC feature map [N][Hf][Wf][C] (pixel stride feat_ld floats)
+ * to [N][Hf*scale][Wf*scale][C] dense: the feature side of the stereo module's FULL-RESOLUTION mode
+ * (StereoCostVolume(full_res=True): the D = max_disp level volume of north_star's sizing, D x H x W, built at image
+ * resolution from reduced + upsampled stage-1 features).  NEW, no reference function; specification
+ * oracle/st_oracle.c::oracle_feat_upsample (bit-exact).  Consumer contract of the module's output as for
+ * st_disp_upsample_pack: mmtrack/datasets/transforms/loading_disparity.py:85-86,129-134. */
+int st_feat_upsample(const float* feat_dev, int N, int Hf, int Wf, int C, int feat_ld, int scale,
+                     float* out_dev, st_stream_t stream);
+
 /* ------------------------------------------------------------------------
  * 6. Per-box depth (disp2depth + extract_depth + scale), reference
  *    mmtrack/models/mot/ocsort_disparity.py:113-175 and

@@ -113,6 +113,19 @@ def disp_upsample(lr, scale, valid_h, valid_w):
     return out
 
 
+def feat_upsample(feat, scale, C_=None):
+    """feat (N,Hf,Wf,ld) float32, the first C_ channels of every pixel (default: all) -> (N,Hf*scale,Wf*scale,C_)
+    (oracle_feat_upsample: bilinear, align_corners=False)."""
+    lib = load()
+    feat = np.ascontiguousarray(feat, np.float32)
+    N, Hf, Wf, ld = feat.shape
+    C_ = ld if C_ is None else int(C_)
+    out = np.zeros((N, Hf * scale, Wf * scale, C_), np.float32)
+    lib.oracle_feat_upsample(_p(feat), C.c_int(N), C.c_int(Hf), C.c_int(Wf), C.c_int(C_), C.c_int(ld), C.c_int(scale),
+                             _p(out))
+    return out
+
+
 def agg3d(vol, weight, bias, act):
     """One 3-D aggregation layer (oracle_agg3d): vol (N,Hf,Wf,D) float32, weight (3,3,3) in (kD,kH,kW) order (a Conv3d
     (1,1,3,3,3) weight squeezed), bias scalar, act: SiLU or not -> (N,Hf,Wf,D)."""

@@ -339,6 +339,36 @@ int oracle_disp_upsample(const float* lr, int N, int Hf, int Wf, int scale, int 
   return 0;
 }
 
+/* Bilinear x`scale` upsampling of an NHWC feature map (align_corners=False, the index arithmetic of
+ * oracle_disp_upsample above, no value scaling): in [N][Hf][Wf][C] (row stride in_ld floats per pixel) -> out
+ * [N][Hf*scale][Wf*scale][C] dense.  The feature side of the stereo module's FULL-RESOLUTION mode (spec:
+ * stereotracking_amd/stereo.py): the reduced stage-1 features are brought to image resolution, where the D = max_disp
+ * level volume of north_star's sizing is built. */
+int oracle_feat_upsample(const float* in, int N, int Hf, int Wf, int C, int in_ld, int scale, float* out) {
+  const int H = Hf * scale, W = Wf * scale;
+  const float inv = 1.0f / (float)scale;
+  for (int n = 0; n < N; ++n)
+    for (int Y = 0; Y < H; ++Y)
+      for (int X = 0; X < W; ++X) {
+        float sy = ((float)Y + 0.5f) * inv - 0.5f, sx = ((float)X + 0.5f) * inv - 0.5f;
+        if (sy < 0.0f) sy = 0.0f;
+        if (sx < 0.0f) sx = 0.0f;
+        int y0 = (int)sy, x0 = (int)sx;
+        if (y0 > Hf - 1) y0 = Hf - 1;
+        if (x0 > Wf - 1) x0 = Wf - 1;
+        const int y1 = y0 + 1 < Hf ? y0 + 1 : Hf - 1, x1 = x0 + 1 < Wf ? x0 + 1 : Wf - 1;
+        const float ly = sy - (float)y0, lx = sx - (float)x0, hy = 1.0f - ly, hx = 1.0f - lx;
+        const float* b = in + (size_t)n * Hf * Wf * in_ld;
+        const float* p00 = b + ((size_t)y0 * Wf + x0) * in_ld;
+        const float* p01 = b + ((size_t)y0 * Wf + x1) * in_ld;
+        const float* p10 = b + ((size_t)y1 * Wf + x0) * in_ld;
+        const float* p11 = b + ((size_t)y1 * Wf + x1) * in_ld;
+        float* o = out + (((size_t)n * H + Y) * W + X) * C;
+        for (int c = 0; c < C; ++c) o[c] = hy * (hx * p00[c] + lx * p01[c]) + ly * (hx * p10[c] + lx * p11[c]);
+      }
+  return 0;
+}
+
 /* ---- 3-D aggregation of the cost volume (specification; north_star: "3D/2D aggregation") -------------------------
  * One layer = a single-channel 3x3x3 convolution over (d, y, x) of the volume [N][Hf][Wf][D] with zero padding in all
  * three dimensions, optional SiLU:

@@ -277,7 +277,11 @@ __global__ __launch_bounds__(128) void costvolume_tiled_kernel(const float* __re
     lv[0] = *reinterpret_cast<const f32x4*>(lp);
 #pragma unroll
     for (int q = 0; q < NW / 4; ++q) rv[0][q] = *reinterpret_cast<const f32x4*>(rp + 4 * q);
-    for (int c = 0; c < cc; c += 2) {
+    // A wave whose 64 pixels all lie right of the image (the second wave of a row's last segment when Wf % 128 is in
+    // 1..64, e.g. Wf = 320 = 2.5 segments: one wave in six) stages and synchronises like the others but multiplies
+    // nothing: its accumulators stay 0 and every store of it is masked anyway.  Wave-uniform.
+    const int cend = (x0 + wave * 64 < Wf) ? cc : 0;
+    for (int c = 0; c < cend; c += 2) {
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
         // UNCONDITIONAL prefetch of channel c+h+1: after the chunk's last channel it reads one row past the
@@ -520,6 +524,42 @@ __global__ __launch_bounds__(256) void disp_upsample_pack_kernel(const float* __
   }
 }
 
+// Bilinear x`scale` upsampling of an NHWC feature map (align_corners=False; the arithmetic of oracle_feat_upsample, bit
+// for bit): the feature side of the stereo module's full-resolution mode.  A thread produces one float4 (4 channels of
+// one output pixel): 4 16-byte gathers from the small low-resolution map (L2-resident), one 16-byte store.
+__global__ __launch_bounds__(256) void feat_upsample_kernel(const float* __restrict__ in, int N, int Hf, int Wf, int C4,
+                                                            int in_ld, int scale, float* __restrict__ out) {
+  const int H = Hf * scale, W = Wf * scale;
+  const long long total = (long long)N * H * W * C4;
+  const float inv = 1.0f / (float)scale;
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (long long)gridDim.x * blockDim.x) {
+    const int q = (int)(idx % C4);
+    long long t = idx / C4;
+    const int X = (int)(t % W);
+    t /= W;
+    const int Y = (int)(t % H);
+    const int n = (int)(t / H);
+    float sy = ((float)Y + 0.5f) * inv - 0.5f;
+    float sx = ((float)X + 0.5f) * inv - 0.5f;
+    sy = sy < 0.f ? 0.f : sy;
+    sx = sx < 0.f ? 0.f : sx;
+    const int y0 = min((int)sy, Hf - 1), x0 = min((int)sx, Wf - 1);
+    const int y1 = min(y0 + 1, Hf - 1), x1 = min(x0 + 1, Wf - 1);
+    const float ly = sy - (float)y0, lx = sx - (float)x0;
+    const float hy = 1.0f - ly, hx = 1.0f - lx;
+    const float* b = in + (size_t)n * Hf * Wf * in_ld + 4 * q;
+    const f32x4 v00 = *reinterpret_cast<const f32x4*>(b + ((size_t)y0 * Wf + x0) * in_ld);
+    const f32x4 v01 = *reinterpret_cast<const f32x4*>(b + ((size_t)y0 * Wf + x1) * in_ld);
+    const f32x4 v10 = *reinterpret_cast<const f32x4*>(b + ((size_t)y1 * Wf + x0) * in_ld);
+    const f32x4 v11 = *reinterpret_cast<const f32x4*>(b + ((size_t)y1 * Wf + x1) * in_ld);
+    f32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = hy * (hx * v00[e] + lx * v01[e]) + ly * (hx * v10[e] + lx * v11[e]);
+    *reinterpret_cast<f32x4*>(out + (size_t)idx * 4) = o;
+  }
+}
+
 static int row_len(int n) { return ((n + 30) / 32) * 32 + 1; }  // >= n, = 1 mod 32
 
 }  // namespace st
@@ -658,6 +698,22 @@ extern "C" int st_disp_upsample_pack(const float* disp_lr_dev, int N, int Hf, in
   const int blocks = (int)std::min<long long>((total + 255) / 256, 256 * 16);
   hipLaunchKernelGGL(disp_upsample_pack_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream_),
                      disp_lr_dev, N, Hf, Wf, scale, H, W, valid_h, valid_w, disp_postp_dev);
+  ST_CHECK_HIP(hipGetLastError());
+  return ST_OK;
+}
+
+extern "C" int st_feat_upsample(const float* feat_dev, int N, int Hf, int Wf, int C, int feat_ld, int scale,
+                                float* out_dev, st_stream_t stream_) {
+  using namespace st;
+  ST_REQUIRE(feat_dev && out_dev, "st_feat_upsample: null pointer");
+  ST_REQUIRE(N > 0 && Hf > 0 && Wf > 0 && scale > 0 && C > 0 && C % 4 == 0 && feat_ld % 4 == 0 && feat_ld >= C,
+             "st_feat_upsample: C and feat_ld must be positive multiples of 4");
+  ST_REQUIRE(((reinterpret_cast<uintptr_t>(feat_dev) | reinterpret_cast<uintptr_t>(out_dev)) & 15) == 0,
+             "st_feat_upsample: pointers must be 16-byte aligned");
+  const long long total = (long long)N * Hf * scale * Wf * scale * (C / 4);
+  const int blocks = (int)std::min<long long>((total + 255) / 256, 256 * 32);
+  hipLaunchKernelGGL(feat_upsample_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream_), feat_dev, N,
+                     Hf, Wf, C / 4, feat_ld, scale, out_dev);
   ST_CHECK_HIP(hipGetLastError());
   return ST_OK;
 }

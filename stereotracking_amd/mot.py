@@ -301,6 +301,10 @@ class OCSORT_Disparity(nn.Module):
         self.motion = TASK_UTILS.build(motion) if motion is not None else None
         self.tracker = MODELS.build(tracker) if tracker is not None else None
         self.baseline, self.focal_length = baseline, focal_length
+        if (stereo is not None and stereo.get('full_res') and 'feat_channels' not in stereo and self.detector is not None):
+            # the full-resolution mode's reduce conv reads the detector's stage-1 features: make_divisible(128, widen)
+            import math
+            stereo = dict(stereo, feat_channels=int(math.ceil(128 * self.detector.widen_factor / 8) * 8))
         self.stereo = MODELS.build(stereo) if stereo is not None else None  # StereoCostVolume (new module)
         if self.stereo is not None and self.detector is not None:
             self.detector.__dict__['stereo'] = self.stereo   # plain reference: registered once, under the shell
@@ -387,7 +391,9 @@ class OCSORT_Disparity(nn.Module):
                 pad_size_divisor=getattr(self.data_preprocessor, 'pad_size_divisor', 32) or 32,
                 agg_layers=sm.agg_layers if stereo else 0, agg3d_layers=sm.agg3d_layers if stereo else 0,
                 split_bf16=self.split_bf16, multi_label=getattr(det, 'multi_label', True),
-                rgb_only=getattr(det, 'rgb_only', False))
+                rgb_only=getattr(det, 'rgb_only', False),
+                full_res=bool(getattr(sm, 'full_res', False)) if stereo else False,
+                full_res_channels=(sm.reduce.out_channels if stereo and getattr(sm, 'full_res', False) else 8))
             for p in runner.pipes:     # the track-box depth reads run k's disparity while later runs are in flight
                 p.disp_buffers = self.queue_depth + 1
             ent = self._dense[key] = [runner, None]

@@ -93,7 +93,7 @@ class StereoDensePipeline:
     def __init__(self, batch, ori_shape=(720, 1280), widen_factor=0.5, deepen_factor=0.33, num_classes=1,
                  stereo=True, max_disp=192, feat_stride=4, temperature=32.0, score_thr=0.01, iou_thr=0.5,
                  max_det=1000, baseline=0.25, focal_length=640, pad_size_divisor=32, agg_layers=0, agg3d_layers=0,
-                 split_bf16=None, multi_label=True, rgb_only=False):
+                 split_bf16=None, multi_label=True, rgb_only=False, full_res=False, full_res_channels=8):
         """max_det: rows of the fixed-size detection buffer per frame.  The reference applies NO cap on the
         kept boxes (yolox_style=True => max_per_img = len(results)), so this is a
         capacity, not a threshold: `run()` reports `overflow` whenever a frame kept more boxes than fit, and
@@ -105,8 +105,14 @@ class StereoDensePipeline:
         self.height = (self.ori_h + d - 1) // d * d
         self.width = (self.ori_w + d - 1) // d * d
         self.stereo = bool(stereo)
+        # full_res: the stereo module's full-resolution mode (D = max_disp levels at image resolution, 3-D aggregation
+        # only; stereo.py) - north_star's literal D x H x W sizing as a product path
+        self.full_res = bool(full_res) and bool(stereo)
+        import math
+        feat_channels = int(math.ceil(128 * widen_factor / 8) * 8)
         self.stereo_module = StereoCostVolume(max_disp, feat_stride, temperature, agg_layers if stereo else 0,
-                                              agg3d_layers if stereo else 0)
+                                              agg3d_layers if stereo else 0, full_res=self.full_res,
+                                              full_res_channels=full_res_channels, feat_channels=feat_channels)
         self.agg_layers = self.stereo_module.agg_layers
         self.agg3d_layers = self.stereo_module.agg3d_layers
         # split_bf16: the autotuner may pick the split-operand (bf16x3) conv instances (fp32 operands as three bf16 terms,
@@ -152,7 +158,8 @@ class StereoDensePipeline:
             return
         import os
         key = (f'v{self.det.lib.st_version()}_b{self.batch}_{self.height}x{self.width}_w{self.det.widen_factor:g}'
-               f'_d{self.det.deepen_factor:g}_s{int(self.stereo)}{"r" if self.rgb_only else ""}_a{self.agg_layers}_D{self.D}'
+               f'_d{self.det.deepen_factor:g}_s{int(self.stereo)}{"r" if self.rgb_only else ""}_a{self.agg_layers}'
+               f'_D{self.max_disp // self.feat_stride if self.full_res else self.D}'
                f'_ops{self.det.lib.st_detector_num_ops(self.det.handle)}_{_device_tag()}'
                + ('_split' + os.environ.get('ST_SPLIT_MASK', '') if self.split_bf16 else ''))
         # (the 3-D aggregation layers run on a kernel of their own: no tile choice, not part of the key)
@@ -307,7 +314,7 @@ class InflightPipelines:
 
     def __getattr__(self, name):   # geometry / thresholds of the (identical) contexts: batch, max_det, stereo, ...
         if name in ('batch', 'max_det', 'stereo', 'height', 'width', 'ori_h', 'ori_w', 'agg_layers', 'agg3d_layers', 'split_bf16',
-                    'rgb_only'):
+                    'rgb_only', 'full_res'):
             return getattr(self.pipes[0], name)
         raise AttributeError(name)
 

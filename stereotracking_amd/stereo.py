@@ -17,6 +17,20 @@ Specification (frozen; the executable spec is oracle/st_oracle.c + oracle/stereo
              every layer but the last (parameters `agg.{l}.weight` (D',D',3,3), `agg.{l}.bias` (D',))
   disparity  d_lr = sum_d d * softmax_d(temperature * cost);  disp = 4 * bilinear_x4(d_lr)
              inside the original image, 0 in the padding
+
+FULL-RESOLUTION mode (`full_res=True`, round 5): north_star's literal sizing - "a D x H x W cost volume, its 3D ...
+aggregation and soft-argmin" with D = max_disp levels at IMAGE resolution (192 x 720 x 1280: 177 M cells, 708 MB per pair):
+  features   G = reduce(F): a 1x1 convolution C -> `full_res_channels` (8), bias, no activation (`reduce.weight`,
+             `reduce.bias`), then bilinear x4 (align_corners=False) to H x W  (st_feat_upsample)
+  cost       cost[d,Y,X] = (1/8) sum_c G_L[c,Y,X] * G_R[c,Y,X-d], d in [0, max_disp) pixels; 0 where X-d < 0
+             (st_costvolume_softargmin, materialised in slabs of <= 128 levels)
+  aggregate  `agg3d_layers` 3x3x3 layers over (d, Y, X) (st_volume_agg3d); no 2-D stage (a 3x3 convolution over 192
+             levels-as-channels at image resolution is 625 GFLOP per pair)
+  disparity  disp = sum_d d * softmax_d(temperature * cost) in pixels, no upsampling step (st_softargmin), 0 outside the
+             original image, three identical channels (st_disp_upsample_pack with scale 1)
+A raw-pixel correlation at full resolution was withdrawn in round 3 (not a matcher); this mode correlates learned stage-1
+FEATURES brought to image resolution.  It is ~3 x slower than the default module (bench.py --fullres-leg) and exists so
+that the literal sizing is a tested, benched product path, not only a kernel measurement.
 """
 import ctypes as C
 
@@ -34,14 +48,30 @@ class StereoCostVolume(nn.Module):
     """Parameter holder + launcher (like the detector modules: no CPU forward).  Parameters are named
     `agg.{l}.weight` / `agg.{l}.bias`, so under the MOT shell a checkpoint carries `stereo.agg.{l}.*`."""
 
-    def __init__(self, max_disp=192, feat_stride=4, temperature=32.0, agg_layers=0, agg3d_layers=0):
+    def __init__(self, max_disp=192, feat_stride=4, temperature=32.0, agg_layers=0, agg3d_layers=0, full_res=False,
+                 full_res_channels=8, feat_channels=64):
         super().__init__()
         if feat_stride != 4:
             raise NotImplementedError('only feat_stride=4 (stage1 features) is wired up')
         if max_disp % feat_stride:
             raise ValueError('max_disp must be a multiple of feat_stride')
         self.max_disp, self.feat_stride = int(max_disp), int(feat_stride)
-        self.levels = self.max_disp // self.feat_stride
+        self.full_res = bool(full_res)
+        self.levels = self.max_disp if self.full_res else self.max_disp // self.feat_stride
+        self.reduce = None
+        if self.full_res:
+            if agg_layers:
+                raise ValueError('full_res aggregates with 3-D layers only (agg_layers must be 0)')
+            if self.levels % 16 or not 16 <= self.levels <= 192:
+                raise ValueError('full_res needs max_disp to be a multiple of 16 in [16, 192]')
+            if full_res_channels % 4 or feat_channels % 4:
+                raise ValueError('full_res_channels / feat_channels must be multiples of 4')
+            self.reduce = nn.Conv2d(int(feat_channels), int(full_res_channels), 1)
+            with torch.no_grad():   # until a checkpoint is loaded: the first channels pass through
+                self.reduce.weight.zero_()
+                idx = torch.arange(int(full_res_channels))
+                self.reduce.weight[idx, idx, 0, 0] = 1.0
+                self.reduce.bias.zero_()
         if self.levels % 4 and (agg_layers or agg3d_layers):
             raise ValueError('aggregation needs max_disp / feat_stride to be a multiple of 4')
         self.temperature = float(temperature)
@@ -63,6 +93,8 @@ class StereoCostVolume(nn.Module):
             p.requires_grad_(False)
         self.lib = _lib.load()
         self._packed = None    # (device, weights version, [(wgt, bias)])
+        self._red = None       # (device, weights version, packed reduce weights, bias)
+        self._fr = None        # full-resolution buffers: reduced features, upsampled features, two volumes, disparity
         self._taps3d = None    # (weights version, [(27 host floats as a ctypes array, bias)])
         self._vol = None
         self.variant = -1      # conv tile variant of the aggregation layers (-1 = library default, or autotune())
@@ -200,6 +232,8 @@ class StereoCostVolume(nn.Module):
         if disp_postp is None:
             disp_postp = torch.empty(N, 3, H, W, dtype=torch.float32, device=dev)
         stream = current_stream()
+        if self.full_res:
+            return self._compute_full_res(feat, N, Hf, Wf, Cf, ld, valid_hw, disp_postp, cost_out, stream, dev, H, W)
         if self.timing:
             cv0, cv1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             cv0.record()
@@ -241,3 +275,85 @@ class StereoCostVolume(nn.Module):
         check(self.lib.st_disp_upsample_pack(ptr(disp_lr), N, Hf, Wf, s, H, W, int(valid_hw[0]), int(valid_hw[1]),
                                              ptr(disp_postp), stream), 'st_disp_upsample_pack')
         return disp_postp
+
+    # ---- full-resolution mode -------------------------------------------------------------------------------
+    def _pack_reduce(self, dev):
+        ver = tuple(p._version for p in self.reduce.parameters())
+        if self._red is not None and self._red[0] == dev and self._red[1] == ver:
+            return self._red[2], self._red[3]
+        w = self.reduce.weight.detach().to('cpu', torch.float32).contiguous()
+        b = self.reduce.bias.detach().to('cpu', torch.float32).contiguous()
+        Cr, Cf = w.shape[0], w.shape[1]
+        wp = torch.empty(self.lib.st_conv_packed_floats(Cr, Cf, 1, 1), dtype=torch.float32)
+        bp = torch.empty((Cr + 31) // 32 * 32, dtype=torch.float32)
+        check(self.lib.st_conv_pack_weights(ptr(w), ptr(b), None, None, None, None, 0.0, Cr, Cf, 1, 1, ptr(wp), ptr(bp)),
+              'st_conv_pack_weights')
+        self._red = (dev, ver, wp.to(dev), bp.to(dev))
+        return self._red[2], self._red[3]
+
+    def full_res_buffers(self, dev, N, Hf, Wf):
+        """Persistent buffers of the full-resolution mode: reduced features (2N,Hf,Wf,Cr), upsampled features
+        (2N,H,W,Cr), two volumes (N,H,W,D) (cost / aggregation ping-pong) and the disparity (N,H,W)."""
+        Cr, D, s = self.reduce.out_channels, self.levels, self.feat_stride
+        H, W = Hf * s, Wf * s
+        if self._fr is None or self._fr['red'].device != dev or self._fr['red'].shape != (2 * N, Hf, Wf, Cr):
+            f32 = dict(dtype=torch.float32, device=dev)
+            self._fr = dict(red=torch.empty(2 * N, Hf, Wf, Cr, **f32), up=torch.empty(2 * N, H, W, Cr, **f32),
+                            va=torch.empty(N, H, W, D, **f32), disp=torch.empty(N, H, W, **f32))
+            self._fr['vb'] = torch.empty(N, H, W, D, **f32) if self.agg3d_layers else None
+        return self._fr
+
+    def _compute_full_res(self, feat, N, Hf, Wf, Cf, ld, valid_hw, disp_postp, cost_out, stream, dev, H, W):
+        if Cf != self.reduce.in_channels:
+            raise ValueError(f'full_res: the detector\'s stage-1 features have {Cf} channels, the module was built for '
+                             f'feat_channels={self.reduce.in_channels}')
+        s, D, Cr = self.feat_stride, self.levels, self.reduce.out_channels
+        b = self.full_res_buffers(dev, N, Hf, Wf)
+        wp, bp = self._pack_reduce(dev)
+        ev = []
+
+        def mark():
+            if self.timing:
+                e = torch.cuda.Event(enable_timing=True)
+                e.record()
+                ev.append(e)
+        mark()
+        d = StConvDesc()                                   # G = reduce(F): 1x1, C -> Cr, bias, no activation, 2N images
+        d.in_dev = feat.data_ptr(); d.N, d.Hi, d.Wi, d.Cin, d.in_ld, d.in_off = 2 * N, Hf, Wf, Cf, ld, 0
+        d.wgt_dev = wp.data_ptr(); d.bias_dev = bp.data_ptr()
+        d.Cout, d.KH, d.KW, d.stride, d.pad = Cr, 1, 1, 1, 0
+        d.out1_dev = b['red'].data_ptr(); d.out1_ld, d.out1_off, d.split = Cr, 0, Cr
+        d.act, d.post_scale = 0, 1.0
+        check(self.lib.st_conv2d_nhwc(C.byref(d), stream), 'st_conv2d_nhwc(reduce)')
+        check(self.lib.st_feat_upsample(ptr(b['red']), 2 * N, Hf, Wf, Cr, Cr, s, ptr(b['up']), stream), 'st_feat_upsample')
+        mark()
+        gl = b['up'].data_ptr()
+        gr = gl + N * H * W * Cr * 4
+        va, vb = b['va'], b['vb']
+        check(self.lib.st_costvolume_softargmin(C.c_void_p(gl), C.c_void_p(gr), N, H, W, Cr, Cr, D, self.temperature,
+                                                ptr(va), None, stream), 'st_costvolume_softargmin')
+        mark()
+        for l, (w27, b3) in enumerate(self._pack3d()):
+            check(self.lib.st_volume_agg3d(ptr(va), ptr(vb), N, H, W, D, w27, b3,
+                                           1 if l < self.agg3d_layers - 1 else 0, stream), 'st_volume_agg3d')
+            va, vb = vb, va
+        mark()
+        if cost_out is not None:
+            cost_out.copy_(va)
+        check(self.lib.st_softargmin(ptr(va), N, H, W, D, self.temperature, ptr(b['disp']), stream), 'st_softargmin')
+        check(self.lib.st_disp_upsample_pack(ptr(b['disp']), N, H, W, 1, H, W, int(valid_hw[0]), int(valid_hw[1]),
+                                             ptr(disp_postp), stream), 'st_disp_upsample_pack')
+        mark()
+        if self.timing:
+            self._fr_events = ev
+        return disp_postp
+
+    def pop_full_res_times(self):
+        """ms of the stages of the last full-resolution compute (timing=True): features (reduce + upsample), cost
+        volume, 3-D aggregation, soft-argmin + pack."""
+        ev = getattr(self, '_fr_events', None)
+        if not ev:
+            return None
+        ev[-1].synchronize()
+        names = ('features_reduce_upsample', 'cost_volume', 'agg3d', 'softargmin_pack')
+        return {n: ev[i].elapsed_time(ev[i + 1]) for i, n in enumerate(names)}

@@ -84,6 +84,10 @@ def synthetic_state_dict(param_table, seed=0, img_stats=(127.5, 73.9), disp_stat
             w[0, 0, 1, 1, 1] += 1.0
             sd[name] = w
             sd[name[:-len('.weight')] + '.bias'] = randn((1,), 0.01)
+        elif '.reduce.' in '.' + name and name.endswith('.weight') and len(shape) == 4:
+            # channel reduction of the stereo module's full-resolution mode (1x1, no activation): a random projection
+            sd[name] = randn(shape, 1.0 / math.sqrt(shape[1]))
+            sd[name[:-len('.weight')] + '.bias'] = randn((shape[0],), 0.01)
         elif name.endswith('.weight') and len(shape) == 4:  # bare prediction Conv2d
             fan_in = shape[1] * shape[2] * shape[3]
             prefix = name[:-len('.weight')]

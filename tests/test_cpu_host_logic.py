@@ -483,3 +483,14 @@ def test_checkpoint_loading_and_color_pretrained_init(tmp_path):
     if shipped.init_cfg:
         with pytest.raises(RuntimeError, match='local|download'):
             shipped.init_weights()
+
+
+def test_full_resolution_mode_rejects_2d_aggregation_and_bad_sizes():
+    from stereotracking_amd.stereo import StereoCostVolume
+    with pytest.raises(ValueError, match='agg_layers'):
+        StereoCostVolume(192, 4, 32.0, agg_layers=1, full_res=True)
+    with pytest.raises(ValueError, match='multiple of 16'):
+        StereoCostVolume(200, 4, 32.0, full_res=True)
+    m = StereoCostVolume(192, 4, 32.0, agg3d_layers=1, full_res=True)
+    assert m.levels == 192 and [n for n, _ in m.param_table()] == ['reduce.weight', 'reduce.bias', 'agg3d.0.weight',
+                                                                    'agg3d.0.bias']

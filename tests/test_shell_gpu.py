@@ -22,6 +22,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 GOLD = os.path.join(ROOT, 'tests', 'golden')
 CFG = os.path.join(ROOT, 'configs', 'stereo_tracking', 'ocsort', 'yolox_s_mmyolo_mot_airdrone_disp.py')
 CFG_RGB = os.path.join(ROOT, 'configs', 'stereo_tracking', 'ocsort', 'yolox_s_mmyolo_mot_airdrone.py')
+CFG_FULLRES = os.path.join(ROOT, 'configs', 'stereo_tracking', 'ocsort', 'stereo_yolox_s_mot_airdrone_costvolume_fullres.py')
 CFG_STEREO = os.path.join(ROOT, 'configs', 'stereo_tracking', 'ocsort', 'stereo_yolox_s_mot_airdrone_costvolume.py')
 
 
@@ -219,6 +220,53 @@ def test_rgb_only_config_shell_matches_oracle_composition(cuda):
             assert set(trk.keys()) >= {'bboxes', 'labels', 'scores', 'scales', 'depth', 'gt_depth', 'instances_id'}
             assert bool(torch.isfinite(trk.depth.cpu()).any())    # the loaded disparity reached the depth step
     assert n_tracked > 0
+
+
+def test_full_resolution_stereo_config_through_the_shell(cuda):
+    """configs/.../stereo_yolox_s_mot_airdrone_costvolume_fullres.py -> MODELS.build -> model.test_step on left / right
+    frames: the shell's detections, depths and disparity equal what StereoDensePipeline(full_res=True) gives on the same
+    frames with the same weights (the module itself is pinned against the oracle in test_stereo_depth_gpu.py)."""
+    from stereotracking_amd.pipeline import StereoDensePipeline
+    from stereotracking_amd.structures import TrackDataSample
+    from stereotracking_amd import mot  # noqa: F401
+    from stereotracking_amd.config import Config
+    from stereotracking_amd.registry import MODELS
+    cfg = Config.fromfile(CFG_FULLRES)
+    for part in ('backbone', 'neck'):
+        cfg.model.detector[part]['widen_factor'] = 0.375
+    cfg.model.detector.bbox_head.head_module['widen_factor'] = 0.375
+    cfg.model.stereo['max_disp'] = 32
+    cfg.model.tracker['init_track_thr'], cfg.model.tracker['obj_score_thr'] = 0.03, 0.02
+    model = MODELS.build(dict(cfg.model, autotune=False, dense_batch=2, inflight=2))
+    assert model.stereo.full_res and model.stereo.reduce.in_channels == 48 and model.stereo.levels == 32
+    table = list(model.detector._table) + [('stereo.' + n, shp) for n, shp in model.stereo.param_table()]
+    sd = synthetic_state_dict(table, seed=8, prior_prob=0.2, logit_std=2.5)
+    model.detector.load_state_dict(sd, strict=False)
+    model.stereo.load_state_dict({k[len('stereo.'):]: v for k, v in sd.items() if k.startswith('stereo.')})
+    ori = (80, 160)
+    frames = [synthetic_batch([70 + t], ori[0], ori[1], 32) for t in range(4)]
+    data = dict(inputs=dict(img=[f['img'][0:1, :, :ori[0]].to(torch.uint8) for f in frames],
+                            right=[f['right'][0:1, :, :ori[0]].to(torch.uint8) for f in frames]),
+                data_samples=[TrackDataSample(dict(frame_id=t, ori_shape=ori, img_shape=ori, scale_factor=(1.0, 1.0)))
+                              for t in range(4)])
+    outs = model.test_step(data)
+    torch.cuda.synchronize()
+    pipe = StereoDensePipeline(2, ori, 0.375, 0.33, 1, stereo=True, max_disp=32, max_det=model.max_det, agg3d_layers=1,
+                               full_res=True)
+    pipe.load_state_dict(sd, autotune=False)
+    for c in range(2):
+        l = torch.cat([torch.nn.functional.pad(frames[2 * c + i]['img'][0:1, :, :ori[0]].to(torch.uint8).float(), [0, 0, 0, 16],
+                                               value=0.0) for i in range(2)]).to(cuda)
+        r = torch.cat([torch.nn.functional.pad(frames[2 * c + i]['right'][0:1, :, :ori[0]].to(torch.uint8).float(), [0, 0, 0, 16],
+                                               value=0.0) for i in range(2)]).to(cuda)
+        ref = pipe.run(l, r)
+        torch.cuda.synchronize()
+        for i in range(2):
+            det = outs[2 * c + i].pred_det_instances
+            k = int(ref['counts'][i])
+            assert len(det) == k and k > 0
+            assert torch.equal(det.bboxes.cpu(), ref['boxes'][i, :k].cpu())
+            assert torch.equal(det.scores.cpu(), ref['scores'][i, :k].cpu())
 
 
 def test_batched_predict_equals_sequential_and_stereo_module(cuda):

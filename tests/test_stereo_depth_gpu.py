@@ -55,6 +55,9 @@ def test_costvolume_bit_exact_and_softargmin(N, Hf, Wf, Cc, ld, D, cuda):
     assert np.array_equal(o.cpu().numpy().view(np.uint32), ref_disp.view(np.uint32))
 
 
+AGG_VARIANT = 1    # the aggressor form that made 236 of 240 volumes of the OLD kernel form wrong (tests/helpers/mfma_aggressor.hip)
+
+
 def _mfma_aggressor():
     """tests/helpers/libmfma_aggressor.so (built by __graft_entry__.build(); rebuilt here when hipcc is at hand and the
     file is missing): a kernel that keeps every SIMD busy with v_mfma_f32_16x16x32_bf16."""
@@ -67,7 +70,7 @@ def _mfma_aggressor():
                                os.path.join(here, 'mfma_aggressor.hip'), '-o', so])
     lib = C.CDLL(so)
     lib.st_test_bf16_mfma_busy.restype = C.c_int
-    lib.st_test_bf16_mfma_busy.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+    lib.st_test_bf16_mfma_busy.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
     return lib
 
 
@@ -77,8 +80,8 @@ def test_costvolume_beside_bf16_mfma_kernels_equals_serial_run(cuda):
     reproduces it in registers, profiles/r05_pkfma_corun.txt); the cost-volume kernel built that way returned a wrong
     volume in 236 of 240 co-runs (profiles/r05_corun_cv_stress.txt).  The library ships a form without such operands and
     contains no bf16 MFMA of its own any more, so the test brings the aggressor along (tests/helpers/mfma_aggressor.hip:
-    the register-only v_mfma_f32_16x16x32_bf16 loop that triggered the defect in 11 of 12 launches of the reproducer;
-    the old kernel form fails THIS test - verified with the tools build, profiles/r05_corun_cv_stress.txt).  ONE co-run:
+    a v_mfma_f32_16x16x32_bf16 loop with LDS-fed operands; beside it the OLD kernel form returned 236 of 240 volumes
+    wrong and fails THIS test - verified with the tools build, profiles/r05_corun_cv_stress.txt).  ONE co-run:
     four cost volumes on four streams beside the aggressor on two more; every volume must equal the one the same call
     gives alone, bit for bit (consumer contract: ocsort_disparity.py:115,132-134 reads this disparity per box)."""
     lib = _lib.load()
@@ -101,13 +104,17 @@ def test_costvolume_beside_bf16_mfma_kernels_equals_serial_run(cuda):
         torch.cuda.synchronize()
         ref.append(vols[i].clone())
         vols[i].fill_(float('nan'))
-    scratch = torch.zeros(1024, device=cuda)
+    scratch = torch.zeros(65536, device=cuda)
     streams = [torch.cuda.Stream() for _ in range(NS)]
     extra = [torch.cuda.Stream() for _ in range(2)]
+    # the aggressor's FIRST launch loads its code object and starts late: warm it up, or nothing overlaps (the old kernel
+    # form passes a cold co-run and fails this one - checked with the tools build, profiles/r05_corun_cv_stress.txt)
+    for e in extra:
+        assert agg.st_test_bf16_mfma_busy(scratch.data_ptr(), 10, AGG_VARIANT, e.cuda_stream) == 0
     torch.cuda.synchronize()
     for i, s in enumerate(streams):
         if i < len(extra):
-            assert agg.st_test_bf16_mfma_busy(scratch.data_ptr(), 6000, extra[i].cuda_stream) == 0   # ~3 ms of bf16 MFMAs
+            assert agg.st_test_bf16_mfma_busy(scratch.data_ptr(), 3000, AGG_VARIANT, extra[i].cuda_stream) == 0
         cost_volume(i, s)
     torch.cuda.synchronize()
     for i in range(NS):
@@ -454,3 +461,82 @@ def test_stereo_module_with_3d_aggregation_matches_oracle(agg3d_layers, agg_laye
     else:
         assert rel_err(vol, ref_vol) <= 1e-3 and rel_err(lr, ref_lr) <= 1e-3 and rel_err(out, ref_out) <= 1e-3
     assert (out[:, :, H:, :] == 0).all() and (out[:, :, :, W:] == 0).all()
+
+
+# ---- the stereo module's FULL-RESOLUTION mode (north_star's literal D x H x W sizing as a product path) ------------------
+@pytest.mark.parametrize('N,Hf,Wf,C_,ld,scale', [(2, 5, 7, 8, 8, 4), (1, 3, 9, 4, 12, 4), (1, 4, 4, 16, 16, 2)])
+def test_feat_upsample_bit_exact(N, Hf, Wf, C_, ld, scale, cuda):
+    """st_feat_upsample (bilinear, align_corners=False, NHWC) BIT-EXACT against oracle_feat_upsample, and within float
+    rounding of torch's interpolate; a channel slice of wider pixels (ld > C) included."""
+    lib = _lib.load()
+    rng = np.random.RandomState(Hf * 10 + Wf)
+    feat = rng.normal(0, 1, (N, Hf, Wf, ld)).astype(np.float32)
+    ref = c_oracle.feat_upsample(feat, scale, C_)
+    src = torch.from_numpy(feat).to(cuda)
+    dst = torch.full((N, Hf * scale, Wf * scale, C_), float('nan'), device=cuda)
+    check(lib.st_feat_upsample(ptr(src), N, Hf, Wf, C_, ld, scale, ptr(dst), current_stream()), 'st_feat_upsample')
+    torch.cuda.synchronize()
+    got = dst.cpu().numpy()
+    assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))
+    t = torch.nn.functional.interpolate(torch.from_numpy(feat[..., :C_]).permute(0, 3, 1, 2), scale_factor=scale,
+                                        mode='bilinear', align_corners=False).permute(0, 2, 3, 1).numpy()
+    assert np.abs(got - t).max() <= 1e-6
+    assert lib.st_feat_upsample(ptr(src), N, Hf, Wf, 6, ld, scale, ptr(dst), current_stream()) != 0   # C % 4
+
+
+@pytest.mark.parametrize('agg3d_layers', [0, 1, 2])
+def test_stereo_full_resolution_mode_matches_oracle(agg3d_layers, cuda):
+    """StereoCostVolume(full_res=True): reduce (1x1, 48 -> 8) -> bilinear x4 -> a D = max_disp level volume at IMAGE
+    resolution (slab-wise for D > 128) -> 3-D aggregation -> soft-argmin in pixels -> disp_postp.  The reduced features
+    against a float32 matrix product (MFMA summation order: 1e-5 of scale); everything after them BIT FOR BIT against
+    oracle/stereo.py::disparity_fullres fed the GPU's own image-resolution features; and the all-oracle path end to end
+    within north_star's 1e-3."""
+    from oracle import stereo as ostereo
+    from stereotracking_amd.pipeline import StereoDensePipeline
+    from stereotracking_amd.synthetic import synthetic_batch, synthetic_state_dict
+    N, H, W, D = 2, 88, 152, 48
+    pipe = StereoDensePipeline(N, (H, W), 0.375, 0.33, 1, stereo=True, max_disp=D, max_det=32,
+                               agg3d_layers=agg3d_layers, full_res=True)
+    sm = pipe.stereo_module
+    assert sm.full_res and sm.levels == D and pipe.agg_layers == 0
+    table = pipe.param_table()
+    assert dict(table)['stereo.reduce.weight'] == (8, 48, 1, 1)
+    sd = synthetic_state_dict(table, seed=2)
+    g = torch.Generator().manual_seed(6)
+    for l in range(agg3d_layers):
+        sd[f'stereo.agg3d.{l}.weight'] = torch.randn(1, 1, 3, 3, 3, generator=g) * 0.2
+        sd[f'stereo.agg3d.{l}.bias'] = torch.randn(1, generator=g) * 0.05
+    pipe.load_state_dict(sd, autotune=False)
+    batch = synthetic_batch([5, 6], H, W, D)
+    img, right = batch['img'].to(cuda), batch['right'].to(cuda)
+    Hp, Wp = pipe.height, pipe.width
+    vol = torch.full((N, Hp, Wp, D), float('nan'), device=cuda)
+    out = torch.full((N, 3, Hp, Wp), float('nan'), device=cuda)
+    sm.compute(pipe.det, img, right, (H, W), None, out, cost_out=vol)
+    torch.cuda.synchronize()
+    feat = pipe.det.tap('stage1_rgb').cpu().numpy()
+    Cf = feat.shape[-1]
+    fr = sm.full_res_buffers(cuda, N, Hp // 4, Wp // 4)
+    red, up = fr['red'].cpu().numpy(), fr['up'].cpu().numpy()
+    # (1) the reduction: 2N images, float matrix product
+    ref_red = np.concatenate([ostereo.reduce_features(feat[:N], Cf, sd), ostereo.reduce_features(feat[N:], Cf, sd)])
+    assert np.abs(red - ref_red).max() <= 1e-5 * max(1.0, np.abs(ref_red).max())
+    # (2) the upsampling of the GPU's own reduced features: bit-exact
+    assert np.array_equal(up.view(np.uint32), c_oracle.feat_upsample(red, 4).view(np.uint32))
+    # (3) volume, 3-D aggregation, soft-argmin, pack on the GPU's own image-resolution features: bit-exact
+    ref_vol, ref_disp, ref_out = ostereo.disparity_fullres(None, None, Cf, D, pipe.temperature, sd, agg3d_layers,
+                                                           valid_hw=(H, W), upsampled=(up[:N], up[N:]))
+    assert np.array_equal(vol.cpu().numpy().view(np.uint32), ref_vol.view(np.uint32))
+    assert np.array_equal(fr['disp'].cpu().numpy().view(np.uint32), ref_disp.view(np.uint32))
+    got = out.cpu().numpy()
+    assert np.array_equal(got.view(np.uint32), ref_out.view(np.uint32))
+    assert (got[:, :, H:, :] == 0).all() and (got[:, :, :, W:] == 0).all() and np.isfinite(got).all()
+    assert (got[:, 0] == got[:, 1]).all() and (got[:, 0] == got[:, 2]).all() and got.max() <= D - 1
+    # (4) end to end from the features with the ORACLE's reduction: north_star's float tolerance
+    _, _, ref_all = ostereo.disparity_fullres(feat[:N], feat[N:], Cf, D, pipe.temperature, sd, agg3d_layers,
+                                              valid_hw=(H, W))
+    assert rel_err(got, ref_all) <= 1e-3
+    # (5) the whole pipeline consumes it: detector + decode + depth run on the full-resolution disparity
+    res = pipe.run(img, right)
+    torch.cuda.synchronize()
+    assert torch.equal(res['disp_postp'].cpu(), torch.from_numpy(got)) and torch.isfinite(res['head']).all()

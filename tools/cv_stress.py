@@ -73,8 +73,9 @@ MICRO_AGG = len(sys.argv) > 1 and sys.argv[1] == 'micro'
 SPLITV = [] if (TORCH_AGG or MICRO_AGG) else [int(v) for v in (sys.argv[1:] or ['53', '54', '50', '51'])]
 if MICRO_AGG:
     agg_lib = C.CDLL(os.path.join(_ROOT, 'tests', 'helpers', 'libmfma_aggressor.so'))
-    agg_lib.st_test_bf16_mfma_busy.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
-    agg_scratch = torch.zeros(1024, device=dev)
+    agg_lib.st_test_bf16_mfma_busy.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+    agg_scratch = torch.zeros(65536, device=dev)
+    AGG_VARIANT = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 ga = torch.randn(4096, 4096, device=dev).to(torch.bfloat16)
 gb = torch.randn(4096, 4096, device=dev).to(torch.bfloat16)
 
@@ -95,7 +96,7 @@ for rep in range(60):
             for v in SPLITV:
                 check(lib.st_conv2d_nhwc_variant(C.byref(ds), C.c_void_p(extra[i].cuda_stream), v))
             if MICRO_AGG:
-                agg_lib.st_test_bf16_mfma_busy(agg_scratch.data_ptr(), 6000, extra[i].cuda_stream)
+                agg_lib.st_test_bf16_mfma_busy(agg_scratch.data_ptr(), 3000, AGG_VARIANT, extra[i].cuda_stream)
             if TORCH_AGG:
                 with torch.cuda.stream(extra[i]):
                     for _ in range(3):
