@@ -488,6 +488,79 @@ __global__ __launch_bounds__(256) void softargmin_lds_kernel(const float* __rest
   out_disp[p0 + threadIdx.x] = t / s;
 }
 
+// WIDE volumes (D >= 112: the full-resolution mode's 192 levels).  The LDS kernel above keeps a pixel's whole row in
+// LDS (784 B at D = 192: 64 pixels = one wave per 50 KB, three waves per CU - measured 5.8 ms for the 5.8 GB volume of 8
+// pairs, 0.12 of 8 TB/s).  Here the row lives in REGISTERS, split over K = 2 neighbouring lanes when D / 16 is even (96
+// registers per lane at D = 192): a wave owns 64 / K pixels and brings their rows in through a private 5 KB LDS tile, 16
+// disparities per lane at a time (coalesced 16-byte loads: four lanes cover one 64-byte chunk; tile rows of 20
+// floats: conflict-free 16-byte reads).  The maximum is exact in any order (lanes combine by shuffle); every lane
+// evaluates the exponentials of ITS values (exact per element, in parallel); only the two running sums are a serial
+// chain in the oracle's order - lane 0 of a pixel runs d = 0 .. D/K-1, hands (s, t) to lane 1 by shuffle, which
+// continues: bit-identical to the sequential evaluation.
+template <int NCH, int K>
+__global__ __launch_bounds__(256) void softargmin_reg_kernel(const float* __restrict__ cost, long long npix,
+                                                             float temperature, float* __restrict__ out_disp) {
+  constexpr int D = 16 * NCH, LCH = NCH / K, DL = 16 * LCH, PPW = 64 / K;   // chunks / values per lane, pixels per wave
+  static_assert(NCH % K == 0, "the row must split evenly over the K lanes of a pixel");
+  __shared__ __attribute__((aligned(16))) float tile[4][64 * 20];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int sub = lane % K;
+  float* tw = tile[wave];
+  const long long nwave = (npix + PPW - 1) / PPW;
+  for (long long wv = (long long)blockIdx.x * 4 + wave; wv < nwave; wv += (long long)gridDim.x * 4) {
+    const long long p0 = wv * PPW;
+    float v[DL];
+#pragma unroll
+    for (int ch = 0; ch < LCH; ++ch) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int e = lane + 64 * i, row = e >> 2, q = e & 3;     // tile row = the lane that will read it
+        const int px = row / K, sb = row % K;
+        f32x4 x = {0.f, 0.f, 0.f, 0.f};
+        if (p0 + px < npix) x = *reinterpret_cast<const f32x4*>(cost + (p0 + px) * D + sb * DL + ch * 16 + 4 * q);
+        *reinterpret_cast<f32x4*>(tw + row * 20 + 4 * q) = x;
+      }
+      // the tile is private to this wave and LDS executes a wave's instructions in order: no workgroup barrier, the
+      // fences keep the compiler from reordering and make it wait for the writes before the reads' data is used
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const f32x4 r = *reinterpret_cast<const f32x4*>(tw + lane * 20 + 4 * j);
+        v[ch * 16 + 4 * j + 0] = r[0]; v[ch * 16 + 4 * j + 1] = r[1];
+        v[ch * 16 + 4 * j + 2] = r[2]; v[ch * 16 + 4 * j + 3] = r[3];
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();     // the next chunk overwrites the tile: every lane has read its row
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+    float m = -__builtin_inff();
+#pragma unroll
+    for (int i = 0; i < DL; ++i) m = fmaxf(m, temperature * v[i]);
+    if (K == 2) m = fmaxf(m, __shfl_xor(m, 1));
+#pragma unroll
+    for (int i = 0; i < DL; ++i) v[i] = cv_expf(temperature * v[i] - m);    // this lane's exponentials
+    float s = 0.f, t = 0.f;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      if (k > 0) {                        // the chain continues in the pixel's next lane
+        const float su = __shfl_up(s, 1), tu = __shfl_up(t, 1);
+        if (sub == k) { s = su; t = tu; }
+      }
+      if (sub == k) {
+#pragma unroll
+        for (int i = 0; i < DL; ++i) {
+          s += v[i];
+          t = fmaf((float)(k * DL + i), v[i], t);
+        }
+      }
+    }
+    const long long p = p0 + lane / K;
+    if (sub == K - 1 && p < npix) out_disp[p] = t / s;
+  }
+}
+
 // bilinear x`scale` (align_corners=False, PyTorch area_pixel_compute_source_index), times scale,
 // zero outside (valid_h, valid_w), replicated to 3 channels NCHW.
 __global__ __launch_bounds__(256) void disp_upsample_pack_kernel(const float* __restrict__ lr, int N, int Hf, int Wf,
@@ -668,6 +741,26 @@ extern "C" int st_softargmin(const float* cost_dev, int N, int Hf, int Wf, int D
   ST_REQUIRE(cost_dev && out_disp_dev && N > 0 && Hf > 0 && Wf > 0 && D > 0, "st_softargmin: bad argument");
   const long long npix = (long long)N * Hf * Wf;
   hipStream_t stream = static_cast<hipStream_t>(stream_);
+  if (D % 16 == 0 && D >= 112 && D <= 192 && (reinterpret_cast<uintptr_t>(cost_dev) & 15) == 0) {
+    // wide volumes: rows in registers (softargmin_reg_kernel)
+    const int ppw = (D / 16) % 2 == 0 ? 32 : 64;                     // pixels per wave (K = 2 lanes per pixel, or 1)
+    const long long nwave = (npix + ppw - 1) / ppw;
+    const unsigned blocks = (unsigned)std::min<long long>((nwave + 3) / 4, 256 * 16);
+#define ST_SA_LAUNCH(NCHV, KV)                                                                              \
+  hipLaunchKernelGGL((softargmin_reg_kernel<NCHV, KV>), dim3(blocks), dim3(256), 0, stream, cost_dev, npix,  \
+                     temperature, out_disp_dev)
+    switch (D / 16) {
+      case 7: ST_SA_LAUNCH(7, 1); break;
+      case 8: ST_SA_LAUNCH(8, 2); break;
+      case 9: ST_SA_LAUNCH(9, 1); break;
+      case 10: ST_SA_LAUNCH(10, 2); break;
+      case 11: ST_SA_LAUNCH(11, 1); break;
+      default: ST_SA_LAUNCH(12, 2); break;
+    }
+#undef ST_SA_LAUNCH
+    ST_CHECK_HIP(hipGetLastError());
+    return ST_OK;
+  }
   if (D % 4 == 0 && (reinterpret_cast<uintptr_t>(cost_dev) & 15) == 0) {
     const int ldsw = D + (((D >> 2) & 1) ? 8 : 4);
     int pb = 256;

@@ -374,6 +374,23 @@ def test_agg3d_layer_bit_exact(N, Hf, Wf, D, act, cuda):
     assert lib.st_volume_agg3d(ptr(src), ptr(dst), N, Hf, Wf, 6, w27, bias, act, current_stream()) != 0
 
 
+@pytest.mark.parametrize('N,Hf,Wf,D', [(1, 3, 37, 192), (2, 2, 45, 128), (1, 5, 13, 112), (1, 1, 70, 144), (1, 2, 33, 176)])
+def test_softargmin_wide_volumes_bit_exact(N, Hf, Wf, D, cuda):
+    """st_softargmin on volumes of 112 .. 192 levels (the full-resolution mode): rows held in registers, split over two
+    lanes when D / 16 is even, the two running sums chained through the lanes in the oracle's order - BIT-EXACT against
+    oracle_softargmin; pixel counts that are no multiple of the 32 / 64 pixels of a wave included."""
+    lib = _lib.load()
+    rng = np.random.RandomState(D + Wf)
+    vol = rng.normal(0, 0.6, (N, Hf, Wf, D)).astype(np.float32)
+    for T in (4.0, 32.0):
+        ref = c_oracle.softargmin(vol, T)
+        c = torch.from_numpy(vol).to(cuda)
+        o = torch.full((N, Hf, Wf), float('nan'), device=cuda)
+        check(lib.st_softargmin(ptr(c), N, Hf, Wf, D, T, ptr(o), current_stream()))
+        torch.cuda.synchronize()
+        assert np.array_equal(o.cpu().numpy().view(np.uint32), ref.view(np.uint32)), (D, T)
+
+
 def test_full_resolution_sizing_composition_d192_bit_exact(cuda):
     """north_star's literal sizing as a TESTED composition, not only a timed kernel: a D = 192-level volume at full
     resolution (a 64 x 256 crop; C = 8 features) built by st_costvolume_softargmin in slabs (2 x 96 disparities),
