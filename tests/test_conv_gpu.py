@@ -490,6 +490,8 @@ def test_experimental_variants_are_not_in_the_product_library(stlib, cuda):
     (32, 64, True, 1, (2, 7, 5), None, 0),         # single K-chunk, image smaller than one tile block
     (48, 48, False, 1, (2, 23, 41), None, 0),      # cost-volume aggregation conv: Cin tail (48 = 32 + 16), Cout padded to 64
     (32, 32, True, 1, (1, 46, 80), 64, 32),        # stage-1 bottleneck conv2 + identity: 32-cout workgroups
+    (32, 32, True, 1, (2, 23, 41), None, 0),       # the same instance on ragged tile blocks (residual tile staged in LDS)
+    (16, 32, True, 0, (1, 9, 9), None, 0),         # half a K-chunk + residual, no activation
     (64, 96, False, 0, (1, 12, 20), None, 0),      # three 32-cout blocks
     (16, 32, False, 1, (1, 9, 9), None, 0),        # half a K-chunk
 ])
