@@ -141,7 +141,7 @@ __global__ __launch_bounds__(256) void costvolume_kernel(const float* __restrict
 // stays bit-identical to the oracle.  Workgroup = 2 waves = 128 pixels of one feature row; channels are staged
 // in chunks of CVT_CC (transposed [c][x], float4-aligned rows with an odd float4 stride: conflict-free b128
 // reads AND conflict-free transposing writes with the lane = (16 pixels x 4 channel-quads) staging order).
-constexpr int CVT_TX = 128;   // pixels per workgroup
+constexpr int CVT_TX = 128;   // pixels per workgroup of the 2-wave form (NW waves: 64 * NW)
 constexpr int CVT_CC = 16;    // channels per staging chunk (two LDS buffers)
 static inline int cvt_row(int n) {  // >= n, multiple of 4, (row / 4) odd
   int r = (n + 3) & ~3;
@@ -159,8 +159,11 @@ static inline int cvt_row(int n) {  // >= n, multiple of 4, (row / 4) odd
 // Round 4 found form 1 returning wrong sums while bf16 MFMAs of another kernel execute on the chip (tools/cv_stress.py,
 // tools/micro/pkfma_corun.hip): the product library instantiates and launches form 0 only (see
 // st_costvolume_softargmin; tests/test_cpu_oracle_and_abi.py checks the built code object for packed-fp32 op_sel).
-template <int DG, int FMA>
-__global__ __launch_bounds__(128) void costvolume_tiled_kernel(const float* __restrict__ featL,
+// NWV: waves per workgroup (64 pixels each).  2 = round 2's form (40 KB of LDS per 128 pixels: three workgroups = 6 waves per
+// CU, LDS-limited); 4 = 256 pixels share one R tile (9 % fewer staged floats, 73 KB per workgroup: two workgroups = 8
+// waves per CU, register-limited).
+template <int DG, int FMA, int NWV>
+__global__ __launch_bounds__(64 * NWV) void costvolume_tiled_kernel(const float* __restrict__ featL,
                                                                const float* __restrict__ featR, int Hf, int Wf,
                                                                int C, int ld, int D, float temperature, int rowL,
                                                                int rowR, float* __restrict__ out_cost,
@@ -176,6 +179,7 @@ __global__ __launch_bounds__(128) void costvolume_tiled_kernel(const float* __re
   // fetched twice: 1.22x the algorithmic bytes, profiles/r03_hbm_traffic.txt).
   const int w = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
   if (w >= total) return;                    // uniform
+  constexpr int CVT_TX = 64 * NWV, NT = 64 * NWV;   // (shadows the namespace constant: pixels / threads of THIS form)
   const int x0 = (w % gx) * CVT_TX;
   const int y = (w / gx) % Hf, n = w / (gx * Hf);
   const size_t rowbase = ((size_t)n * Hf + y) * Wf;
@@ -188,7 +192,7 @@ __global__ __launch_bounds__(128) void costvolume_tiled_kernel(const float* __re
   constexpr int RW = CVT_TX + 4 * DG;    // R columns of the block: column j <-> x' = x0 - dbase - 4*DG + j
   constexpr int RW16 = (RW + 15) & ~15;
   constexpr int CC4 = CVT_CC / 4;
-  constexpr int NL = CVT_TX * CC4 / 128, NR = (RW16 * CC4 + 127) / 128;   // float4 per thread per chunk
+  constexpr int NL = CVT_TX * CC4 / NT, NR = (RW16 * CC4 + NT - 1) / NT;   // float4 per thread per chunk
 
   // Accumulators in DIAGONAL pairs: cost[x+p][d0+k] and cost[x+p+1][d0+k+1] both multiply R window element
   // i = DG + p - k, so (acc[p][k], acc[p+1][k+1]) += (L[p], L[p+1]) * R[i] is ONE v_pk_fma_f32 with the R operand
@@ -225,7 +229,7 @@ __global__ __launch_bounds__(128) void costvolume_tiled_kernel(const float* __re
     const int cc4 = min(CVT_CC, C - cb) >> 2;
 #pragma unroll
     for (int i = 0; i < NL; ++i) {
-      const int e = tid + 128 * i;
+      const int e = tid + NT * i;
       const int px = (e & 15) + 16 * (e / (16 * CC4)), c4 = (e >> 4) % CC4;
       const int x = x0 + px;
       stL[i] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -233,7 +237,7 @@ __global__ __launch_bounds__(128) void costvolume_tiled_kernel(const float* __re
     }
 #pragma unroll
     for (int i = 0; i < NR; ++i) {
-      const int e = tid + 128 * i;
+      const int e = tid + NT * i;
       const int j = (e & 15) + 16 * (e / (16 * CC4)), c4 = (e >> 4) % CC4;
       const int x = x0 - dbase - 4 * DG + j;
       stR[i] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -246,14 +250,14 @@ __global__ __launch_bounds__(128) void costvolume_tiled_kernel(const float* __re
     float* Rs = Ls + CVT_CC * rowL;
 #pragma unroll
     for (int i = 0; i < NL; ++i) {
-      const int e = tid + 128 * i;
+      const int e = tid + NT * i;
       const int px = (e & 15) + 16 * (e / (16 * CC4)), c4 = (e >> 4) % CC4;
 #pragma unroll
       for (int k = 0; k < 4; ++k) Ls[(4 * c4 + k) * rowL + px] = stL[i][k];
     }
 #pragma unroll
     for (int i = 0; i < NR; ++i) {
-      const int e = tid + 128 * i;
+      const int e = tid + NT * i;
       const int j = (e & 15) + 16 * (e / (16 * CC4)), c4 = (e >> 4) % CC4;
       if (j < rowR) {
 #pragma unroll
@@ -659,34 +663,47 @@ extern "C" int st_costvolume_softargmin(const float* featL_dev, const float* fea
     dgt = D / slabs / 4;
   }
   if (dgt <= 32 && (out_cost_dev == nullptr || (reinterpret_cast<uintptr_t>(out_cost_dev) & 15) == 0)) {
-    const int rowLt = cvt_row(CVT_TX), rowRt = cvt_row(CVT_TX + 4 * dgt);
+    // waves per workgroup (see the kernel): 4 (256-pixel segments) when at most one wave of a row's last segment idles.
+    // Measured (profiles/r05_cv_nwv_ab.txt): W = 1280 (the full-resolution sizing) 330 -> 295 us; Wf = 320 (the bench
+    // volume: 1.25 segments of 256, three of eight waves idle while their workgroup holds 73 KB) 102 -> 122 us.
+    int nwv = (Wf > 128 && round_up(Wf, 256) - Wf <= 64) ? 4 : 2;
+#ifdef ST_ABLATION
+    if (const char* e = getenv("ST_CV_NWV")) nwv = atoi(e) == 4 ? 4 : 2;   // A/B (tools/cv_bench.py)
+#endif
+    const int TX = 64 * nwv;
+    const int rowLt = cvt_row(TX), rowRt = cvt_row(TX + 4 * dgt);
     const size_t ldst = ((size_t)2 * CVT_CC * (rowLt + rowRt) + rowRt) * sizeof(float);   // + the prefetch slack row
-    const int gxt = (Wf + CVT_TX - 1) / CVT_TX;
+    const int gxt = (Wf + TX - 1) / TX;
     const long long totalt = (long long)gxt * Hf * N;
     ST_REQUIRE(totalt + 8 < (1ll << 31), "st_costvolume_softargmin: grid too large");
     const int per_xcd = (int)((totalt + 7) / 8);
-    const dim3 gridt((unsigned)(8 * per_xcd)), blockt(128);
+    const dim3 gridt((unsigned)(8 * per_xcd)), blockt((unsigned)(64 * nwv));
     // The product launches form 0 (scalar FMAs) ALWAYS: form 1 goes wrong whenever a bf16 MFMA of any kernel on the chip -
     // this library's split instances, another library, another process - executes beside it (the op_sel / op_sel_hi
     // bit of a v_pk_fma_f32 source is dropped for single steps: tools/micro/pkfma_corun.hip reproduces it in registers,
     // profiles/r05_pkfma_corun.txt), and form 2 costs more vector instructions than form 0.  No process state, no
-    // launch-order dependence; forms 1 / 2 exist in the tools build for the reproducer only.
+    // launch-order dependence; forms 1 - 3 exist in the tools build (2-wave workgroups) for the reproducer only.
 #ifdef ST_ABLATION
     int fma_mode = 0;
     if (const char* e = getenv("ST_CV_FMA")) fma_mode = atoi(e);   // tools/cv_stress.py
+    if (fma_mode != 0 && nwv != 2) return set_error(ST_ERR_INVALID, "ST_CV_FMA forms 1-3 exist for ST_CV_NWV=2 only");
 #define ST_CVT_LAUNCH(DGV)                                                                                    \
   do {                                                                                                         \
-    if (fma_mode == 1) ST_CVT_LAUNCH_I(DGV, 1);                                                                \
-    else if (fma_mode == 2) ST_CVT_LAUNCH_I(DGV, 2);                                                           \
-    else if (fma_mode == 3) ST_CVT_LAUNCH_I(DGV, 3);                                                           \
-    else ST_CVT_LAUNCH_I(DGV, 0);                                                                              \
+    if (fma_mode == 1) ST_CVT_LAUNCH_I(DGV, 1, 2);                                                             \
+    else if (fma_mode == 2) ST_CVT_LAUNCH_I(DGV, 2, 2);                                                        \
+    else if (fma_mode == 3) ST_CVT_LAUNCH_I(DGV, 3, 2);                                                        \
+    else if (nwv == 4) ST_CVT_LAUNCH_I(DGV, 0, 4);                                                             \
+    else ST_CVT_LAUNCH_I(DGV, 0, 2);                                                                           \
   } while (0)
 #else
-#define ST_CVT_LAUNCH(DGV) ST_CVT_LAUNCH_I(DGV, 0)
-#endif
-#define ST_CVT_LAUNCH_I(DGV, PKV)                                                                             \
+#define ST_CVT_LAUNCH(DGV)                                                                                    \
   do {                                                                                                         \
-    auto kern = costvolume_tiled_kernel<DGV, PKV>;                                                             \
+    if (nwv == 4) ST_CVT_LAUNCH_I(DGV, 0, 4); else ST_CVT_LAUNCH_I(DGV, 0, 2);                                 \
+  } while (0)
+#endif
+#define ST_CVT_LAUNCH_I(DGV, PKV, NWVV)                                                                       \
+  do {                                                                                                         \
+    auto kern = costvolume_tiled_kernel<DGV, PKV, NWVV>;                                                       \
     static int lds_set = 0;                                                                                    \
     ST_ENSURE_DYNAMIC_LDS(kern, ldst, lds_set);                                                                \
     for (int sl = 0; sl < slabs; ++sl)                                                                         \
