@@ -751,6 +751,11 @@ def batched_association_line(dev, B=1024, T=32, M=16):
 
 def main():
     args = parse()
+    # stdout carries exactly ONE line, the JSON of rank 0: libraries that print to file descriptor 1 (RCCL writes a
+    # version banner there when its communicator initialises) are sent to stderr for the duration of the run
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     rank = int(os.environ.get('RANK', 0))
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
@@ -765,9 +770,14 @@ def main():
     torch.cuda.set_device(dev_index)
     dev = torch.device('cuda', dev_index)
     dist = None
-    if world > 1:
+    # ST_BENCH_WORLD1_PG=1: a process group of ONE rank - the one-GPU box then executes the RCCL branches of the N-rank
+    # run for real (communicator init, one all-gather of the frame records per step on the communication stream,
+    # barriers, the all-reduce of the timing); a rehearsal like ST_BENCH_BACKEND=gloo, never used for reported numbers
+    pg = world > 1 or os.environ.get('ST_BENCH_WORLD1_PG') == '1'
+    if pg:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29517')
         if backend == 'nccl':
             dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
         else:
@@ -799,14 +809,14 @@ def main():
     img, right = inputs[0]
     step_no = [0]
     from stereotracking_amd.dist import DetectionGatherer
-    gathered = [torch.empty(world * B, pipe.max_det + 1, 8, device=cdev) for _ in runner.pipes] if world > 1 else None
+    gathered = [torch.empty(world * B, pipe.max_det + 1, 8, device=cdev) for _ in runner.pipes] if pg else None
     # ONE communication stream for every all-gather of this rank: collectives are issued in host program order (step
     # i on every rank), behind an event of the producing context's stream - never from inside a context stream
-    gatherer = DetectionGatherer(dev)
+    gatherer = DetectionGatherer(dev, single_rank_collective=pg and world == 1)
 
     def post(out, ctx):   # runs under the context's stream
         dets = pipe.pack_detections(out)   # self-describing frame records: header row (true count) + max_det rows
-        if world > 1:  # ONE collective per shard of frames: the fixed-size records (8 x 32 KB / rank)
+        if pg:  # ONE collective per shard of frames: the fixed-size records (8 x 32 KB / rank)
             out['records'], out['records_ready'] = gatherer.gather(dets, gathered[ctx])
         else:
             out['records'] = dets
@@ -820,18 +830,18 @@ def main():
     for _ in range(args.warmup):
         out = step()
     torch.cuda.synchronize()
-    if world > 1:
+    if pg:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = step()
     torch.cuda.synchronize()
-    if world > 1:
+    if pg:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if pg:
         t = torch.tensor([dt], device=cdev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -843,7 +853,7 @@ def main():
     props = torch.cuda.get_device_properties(dev)
     me = dict(rank=rank, device_index=dev_index, uuid=str(getattr(props, 'uuid', '')), name=props.name)
     ranks_seen = [me]
-    if world > 1:
+    if pg:
         ranks_seen = [None] * world
         dist.all_gather_object(ranks_seen, me)
         if backend == 'nccl' and len({(r['uuid'] or r['device_index']) for r in ranks_seen}) != world:
@@ -858,14 +868,14 @@ def main():
             n_s += args.steps
             torch.cuda.synchronize()
             go_on = time.perf_counter() - t1 < args.sustain_seconds
-            if world > 1:   # every step carries a collective: the ranks must agree on how many more rounds they run
+            if pg:   # every step carries a collective: the ranks must agree on how many more rounds they run
                 flag = torch.tensor([1 if go_on else 0], device=cdev, dtype=torch.int32)
                 dist.all_reduce(flag, op=dist.ReduceOp.MIN)
                 go_on = bool(flag.item())
             if not go_on:
                 break
         dts = time.perf_counter() - t1
-        if world > 1:
+        if pg:
             t = torch.tensor([dts], device=cdev, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dts = float(t.item())
@@ -895,7 +905,11 @@ def main():
                    'global_batch': world * B, 'inflight_contexts': len(runner), 'distinct_input_batches': nb, 'gpu_max_hw_queues': os.environ.get('GPU_MAX_HW_QUEUES'),
                    'hip_force_dev_kernarg': os.environ.get('HIP_FORCE_DEV_KERNARG'),
                    'parallelism': (f'frames sharded x{world}, one all-gather of detections per step ({backend})'
-                                   if world > 1 else 'single process, no process group (no collective in the step)'),
+                                   if world > 1 else
+                                   (f'ONE rank with a process group ({backend}): the all-gather of the step runs through the '
+                                    'communicator (rehearsal of the collective code path)' if pg else
+                                    'single process, no process group (no collective in the step)')),
+                   'collectives_issued': gatherer.seq if pg else 0,
                    'ranks_seen': ranks_seen, 'hw_queues': hw_queues,
                    'tuning_plan': os.path.relpath(pipe.tuning_source, ROOT) if os.path.isabs(str(getattr(pipe, 'tuning_source', ''))) else str(getattr(pipe, 'tuning_source', None)),
                    'detections_kept_rank0': counts, 'max_det': pipe.max_det, 'detections_overflow': False},
@@ -946,8 +960,9 @@ def main():
                 l1_px=float(ad.mean()), max_abs_px=float(ad.max()),
                 max_rel=float((ad / ref_d.abs().clamp(min=1.0)).max()), mean_disp_px=float(ref_d.mean()),
                 pair='rank 0 pair 0 of the timed workload', ref='oracle (CPU fp32 restatement of the stereo module)')
-        print(json.dumps(line), flush=True)
-    if world > 1:
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(line) + '\n').encode())
+    if pg:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -141,8 +141,9 @@ extern "C" int st_volume_agg3d(const float* vol_in_dev, float* vol_out_dev, int 
   // 16 beyond (55 KB at D = 192) - two to three workgroups per CU in every case
   const int TW = D <= 48 ? 64 : (D <= 96 ? 32 : 16);
   const int strips = ceil_div(Wf, TW);
-  // band height: enough workgroups for ~4 per CU, bands of at least 8 rows (halo re-read (RY + 2) / RY <= 1.25)
-  const int want_bands = std::max(1, ceil_div(4 * 256, N * strips));
+  // band height: enough workgroups for ~8 per CU (whole launch rounds matter: 2.5 rounds of 368-row bands cost the
+  // full-resolution volume a half-empty last round), bands of at least 8 rows (halo re-read (RY + 2) / RY <= 1.25)
+  const int want_bands = std::max(1, ceil_div(8 * 256, N * strips));
   int RY = std::max(8, ceil_div(Hf, want_bands));
   RY = std::min(RY, Hf);
   a.RY = RY;

@@ -67,18 +67,24 @@ class DetectionGatherer:
     ((max_det + 1) x 8 fp32 per frame, 256 KB per 8-frame shard) - latency-bound over xGMI, so one collective per
     shard, never per frame.  'gloo' (CPU rehearsal) gathers through host memory."""
 
-    def __init__(self, device=None):
+    def __init__(self, device=None, single_rank_collective=False):
+        """single_rank_collective: with a process group of ONE rank, still issue the collective (RCCL all-gather of one
+        shard = a device copy through the communicator) instead of returning the records as they are - the way the
+        one-GPU box executes the RCCL code path of the N-rank run (tests/test_multirank_gpu.py, bench.py
+        ST_BENCH_WORLD1_PG=1)."""
         self.device = torch.device(device) if device is not None else None
         self.stream = None
         self.seq = 0
         _, self.world = world()
-        self.on_device = self.world > 1 and dist.get_backend() == 'nccl'
+        self.single_rank_collective = bool(single_rank_collective) and dist.is_available() and dist.is_initialized()
+        self.on_device = ((self.world > 1 or self.single_rank_collective) and dist.is_initialized()
+                          and dist.get_backend() == 'nccl')
 
     def gather(self, records, out=None):
         """records: this rank's (F, M + 1, C) frame records, produced on the CURRENT stream.
         -> (gathered (world * F, M + 1, C), event or None).  world 1: (records, None)."""
         self.seq += 1
-        if self.world == 1:
+        if self.world == 1 and not self.single_rank_collective:
             return records, None
         if not self.on_device:                 # gloo rehearsal: host memory, synchronous
             host = records.cpu()

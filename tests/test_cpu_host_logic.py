@@ -494,3 +494,29 @@ def test_full_resolution_mode_rejects_2d_aggregation_and_bad_sizes():
     m = StereoCostVolume(192, 4, 32.0, agg3d_layers=1, full_res=True)
     assert m.levels == 192 and [n for n, _ in m.param_table()] == ['reduce.weight', 'reduce.bias', 'agg3d.0.weight',
                                                                     'agg3d.0.bias']
+
+
+def test_detection_gatherer_single_rank_collective_gloo():
+    """dist.DetectionGatherer(single_rank_collective=True) with a process group of ONE rank issues the collective (here
+    through gloo / host memory; on the GPU box through RCCL: tests/test_multirank_gpu.py) and returns the records
+    unchanged; without the flag, or without a process group, a single rank returns its records as they are."""
+    import socket
+    import torch.distributed as dist
+    from stereotracking_amd.dist import DetectionGatherer
+    rec = torch.arange(2 * 5 * 8, dtype=torch.float32).view(2, 5, 8)
+    g0 = DetectionGatherer()
+    out, ev = g0.gather(rec)
+    assert out is rec and ev is None and g0.seq == 1
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    dist.init_process_group('gloo', init_method=f'tcp://127.0.0.1:{port}', rank=0, world_size=1)
+    try:
+        g1 = DetectionGatherer(single_rank_collective=True)
+        assert g1.single_rank_collective and not g1.on_device
+        out, ev = g1.gather(rec)
+        assert out is not rec and torch.equal(out, rec) and g1.seq == 1
+        g2 = DetectionGatherer()            # a single rank without the flag: no collective
+        assert g2.gather(rec)[0] is rec
+    finally:
+        dist.destroy_process_group()

@@ -74,3 +74,29 @@ def test_bench_multirank_path_world2(cuda):
     assert line['n_gpus'] == 2 and line['scaling'] == 'weak' and line['value'] > 0
     assert line['config']['global_batch'] == 16 and line['config']['detections_overflow'] is False
     assert 'roofline' in line and 'cpu_baseline' not in line
+
+
+def test_bench_rccl_process_group_of_one_rank_executes_the_collectives(cuda):
+    """What one GPU can execute of the RCCL path: bench.py with a process group of ONE rank on the 'nccl' backend
+    (ST_BENCH_WORLD1_PG=1) - RCCL communicator init on the device, one `all_gather_into_tensor` of the frame records per
+    step issued by dist.DetectionGatherer on its communication stream behind the producing context's event, the barriers
+    and the all-reduce of the timing; the gathered records must equal the local counts (bench.py checks it and aborts
+    otherwise).  The N > 1 exchange itself needs N devices (the driver's 8-GPU run); this pins that the code path RUNS
+    (reference collectives: mmtrack/evaluation/metrics/mot_drone_metrics.py:336-358)."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0', ST_BENCH_WORLD1_PG='1', MASTER_ADDR='127.0.0.1',
+               MASTER_PORT=str(_free_port()))
+    for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE'):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--steps', '6', '--warmup', '2', '--no-cpu-baseline',
+                        '--no-test-step', '--sustain-seconds', '0'], cwd=ROOT, env=env, capture_output=True, text=True,
+                       timeout=600)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+    # stdout is exactly ONE line (RCCL prints a version banner to file descriptor 1 at communicator init: bench.py sends
+    # everything but its JSON to stderr, or the driver's parser would meet five lines of banner first)
+    assert len([l for l in p.stdout.splitlines() if l.strip()]) == 1, p.stdout[:600]
+    outs = _json_lines(p.stdout)
+    assert len(outs) == 1
+    line = outs[0]
+    assert line['n_gpus'] == 1 and line['value'] > 0
+    assert 'nccl' in line['config']['parallelism'] and line['config']['collectives_issued'] >= 8
+    assert line['config']['detections_overflow'] is False
