@@ -89,8 +89,7 @@ for name, args, variant, exec_frac in CASES:
         us.append(e0.elapsed_time(e1) / nl * 1e3); ws.append(w); cs.append(c)
     ws, cs, us = ws[2:] or ws, cs[2:] or cs, us[2:] or us
     w, c, u = sum(ws) / len(ws), sum(cs) / len(cs), sum(us) / len(us)
-    tf = gf / u * 1e-3 * 1e3 / 1e0 / 1e3 * 1e3   # GF / us -> TFLOP/s: gf / (u * 1e-6) / 1e3
-    tf = gf / (u * 1e-6) / 1e3
+    tf = gf / (u * 1e-6) / 1e3          # GFLOP per launch / us per launch -> TFLOP/s
     print(f'{name:54s} {u:7.1f} us  {tf:6.1f} TF/s direct ({tf * exec_frac:5.1f} executed)  {w:5.0f} W  sclk {c:.0f}  '
           f'{(w - idle_w) * u * 1e-6 / (gf * exec_frac) * 1e3:6.2f} mJ per executed GFLOP above idle')
     del keep
