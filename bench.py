@@ -316,6 +316,7 @@ def cpu_baseline(sd, batch_cpu, max_disp, seconds, agg_layers, max_det=1000):
     from oracle.torch_model import OracleDetector, head_to_rows
     # a 1-GPU box shares its host: use its CPU share (16), not every core the OS reports
     torch.set_num_threads(min(os.cpu_count() or 1, 16))
+    c_oracle.set_threads(min(os.cpu_count() or 1, 16))     # the C oracle's element loops (OpenMP): the same 16
     ora = OracleDetector(0.33, 0.5, 1).eval()
     ora.load_state_dict(sd, strict=False)
     img, right, = batch_cpu['img'][:1], batch_cpu['right'][:1]
@@ -359,10 +360,12 @@ def cpu_baseline(sd, batch_cpu, max_disp, seconds, agg_layers, max_det=1000):
     dt = time.perf_counter() - t0
     threads = torch.get_num_threads()
     torch.set_num_threads(1)          # SURVEY.md §8d also asks for the 1-thread figure (one pair)
+    c_oracle.set_threads(1)
     t1 = time.perf_counter()
     one_pair()
     dt1 = time.perf_counter() - t1
     torch.set_num_threads(threads)
+    c_oracle.set_threads(threads)
     return dict(oracle_disp_pair0=keep['disp'], value=round(n / dt, 4), unit='stereo frame-pairs/s', cores=threads, kind='port',
                 value_1_thread=round(1.0 / dt1, 4),
                 sample=f'{n} x 1 synthetic 1280x720 pair (D={max_disp}, {agg_layers} aggregation convs, full YOLOX-s '

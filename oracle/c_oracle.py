@@ -17,8 +17,8 @@ _lib = None
 def build(force=False):
     os.makedirs(OUT_DIR, exist_ok=True)
     if force or not os.path.exists(LIB) or (os.path.exists(SRC) and os.path.getmtime(LIB) < os.path.getmtime(SRC)):
-        subprocess.check_call(['gcc', '-O2', '-std=c11', '-ffp-contract=off', '-fno-fast-math', '-fPIC', '-shared',
-                               '-o', LIB, SRC, '-lm'])
+        subprocess.check_call(['gcc', '-O2', '-std=c11', '-ffp-contract=off', '-fno-fast-math', '-fopenmp', '-fPIC',
+                               '-shared', '-o', LIB, SRC, '-lm'])
     return LIB
 
 
@@ -32,11 +32,21 @@ def load():
         _lib.oracle_expf.argtypes = [C.c_float]
         _lib.oracle_sigmoidf.restype = C.c_float
         _lib.oracle_sigmoidf.argtypes = [C.c_float]
+        # OpenMP threads of the element loops: a GPU box reports every CPU of its host (256) but shares 16 of them
+        if 'OMP_NUM_THREADS' not in os.environ:
+            _lib.oracle_set_threads(C.c_int(min(os.cpu_count() or 1, 16)))
     return _lib
 
 
 def _p(a):
     return a.ctypes.data_as(C.c_void_p)
+
+
+def set_threads(n):
+    """Bound the OpenMP threads of the stereo loops (results do not depend on it); returns the count in effect."""
+    lib = load()
+    lib.oracle_set_threads.restype = C.c_int
+    return int(lib.oracle_set_threads(C.c_int(int(n))))
 
 
 def head_row_floats(num_classes):

@@ -33,6 +33,16 @@
 
 /* Cephes-style expf: range reduction by ln2 (hi/lo), degree-5 polynomial, exact ldexp.
  * Not libm's expf on purpose: this sequence is reproducible on any IEEE machine. */
+/* The element loops of the stereo functions below run on OpenMP threads (every output element is computed by the same
+ * sequential code, so results do not depend on the thread count); oracle_set_threads bounds them (bench.py's
+ * cpu_baseline states the threads it used). */
+#ifdef _OPENMP
+#include <omp.h>
+int oracle_set_threads(int n) { if (n > 0) omp_set_num_threads(n); return omp_get_max_threads(); }
+#else
+int oracle_set_threads(int n) { (void)n; return 1; }
+#endif
+
 static float st_expf(float x) {
   if (x > 88.72283f) return INFINITY;
   if (x < -103.0f) return 0.0f;
@@ -277,6 +287,7 @@ int oracle_decode_nms(const float* head, int N, int num_levels, const int* lvl_h
  */
 int oracle_costvolume(const float* featL, const float* featR, int N, int Hf, int Wf, int C, int ld, int D,
                       float* out_cost) {
+#pragma omp parallel for collapse(2) schedule(static)
   for (int n = 0; n < N; ++n)
     for (int y = 0; y < Hf; ++y)
       for (int x = 0; x < Wf; ++x) {
@@ -295,6 +306,7 @@ int oracle_costvolume(const float* featL, const float* featR, int N, int Hf, int
 
 /* disp[p] = sum_d d*e_d / sum_d e_d, e_d = exp(T*cost_d - max_d(T*cost_d)), sequential in d. */
 int oracle_softargmin(const float* cost, long long npix, int D, float temperature, float* out_disp) {
+#pragma omp parallel for schedule(static)
   for (long long p = 0; p < npix; ++p) {
     const float* c = cost + p * D;
     float m = -INFINITY;
@@ -316,6 +328,7 @@ int oracle_softargmin(const float* cost, long long npix, int D, float temperatur
 int oracle_disp_upsample(const float* lr, int N, int Hf, int Wf, int scale, int H, int W, int valid_h,
                          int valid_w, float* out) {
   const float inv = 1.0f / (float)scale;
+#pragma omp parallel for collapse(2) schedule(static)
   for (int n = 0; n < N; ++n)
     for (int Y = 0; Y < H; ++Y)
       for (int X = 0; X < W; ++X) {
@@ -347,6 +360,7 @@ int oracle_disp_upsample(const float* lr, int N, int Hf, int Wf, int scale, int 
 int oracle_feat_upsample(const float* in, int N, int Hf, int Wf, int C, int in_ld, int scale, float* out) {
   const int H = Hf * scale, W = Wf * scale;
   const float inv = 1.0f / (float)scale;
+#pragma omp parallel for collapse(2) schedule(static)
   for (int n = 0; n < N; ++n)
     for (int Y = 0; Y < H; ++Y)
       for (int X = 0; X < W; ++X) {
@@ -377,6 +391,7 @@ int oracle_feat_upsample(const float* in, int N, int Hf, int Wf, int C, int in_l
  * for j (row), for k (column), for i (disparity): acc = fmaf(w[i][j][k], v, acc) with v = 0 outside the volume (the
  * fmaf is executed for padded taps, too).  SiLU = v / (1 + st_expf(-v)). */
 int oracle_agg3d(const float* vol, int N, int Hf, int Wf, int D, const float* w27, float bias, int act, float* out) {
+#pragma omp parallel for collapse(2) schedule(static)
   for (int n = 0; n < N; ++n)
     for (int y = 0; y < Hf; ++y)
       for (int x = 0; x < Wf; ++x)
