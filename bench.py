@@ -355,7 +355,7 @@ def cpu_baseline(sd, batch_cpu, max_disp, seconds, agg_layers, max_det=1000):
     while True:
         one_pair()
         n += 1
-        if time.perf_counter() - t0 >= seconds or n >= 64:
+        if time.perf_counter() - t0 >= seconds or n >= 512:
             break
     dt = time.perf_counter() - t0
     threads = torch.get_num_threads()
