@@ -157,7 +157,7 @@ static inline int cvt_row(int n) {  // >= n, multiple of 4, (row / 4) odd
 //      aligned 64-bit half of the ds_read_b128 result and only the four L values need an explicit (l, l) pair: one
 //      v_pk_fma_f32 without op_sel, 22 packed + 4 scalar FMAs + 8 moves per channel (form 0: 48, form 1: 22 + 4 + 3).
 // Round 4 found form 1 returning wrong sums while bf16 MFMAs of another kernel execute on the chip (tools/cv_stress.py,
-// tools/micro/pkfma_corun.hip): the product library instantiates and launches form 0 only (see
+// tools/micro/pkfma_corun.hip): the product library instantiates and launches form 3 only (see
 // st_costvolume_softargmin; tests/test_cpu_oracle_and_abi.py checks the built code object for packed-fp32 op_sel).
 // NWV: waves per workgroup (64 pixels each).  2 = round 2's form (40 KB of LDS per 128 pixels: three workgroups = 6 waves per
 // CU, LDS-limited); 4 = 256 pixels share one R tile (9 % fewer staged floats, 73 KB per workgroup: two workgroups = 8
@@ -678,27 +678,29 @@ extern "C" int st_costvolume_softargmin(const float* featL_dev, const float* fea
     ST_REQUIRE(totalt + 8 < (1ll << 31), "st_costvolume_softargmin: grid too large");
     const int per_xcd = (int)((totalt + 7) / 8);
     const dim3 gridt((unsigned)(8 * per_xcd)), blockt((unsigned)(64 * nwv));
-    // The product launches form 0 (scalar FMAs) ALWAYS: form 1 goes wrong whenever a bf16 MFMA of any kernel on the chip -
-    // this library's split instances, another library, another process - executes beside it (the op_sel / op_sel_hi
-    // bit of a v_pk_fma_f32 source is dropped for single steps: tools/micro/pkfma_corun.hip reproduces it in registers,
-    // profiles/r05_pkfma_corun.txt), and form 2 costs more vector instructions than form 0.  No process state, no
-    // launch-order dependence; forms 1 - 3 exist in the tools build (2-wave workgroups) for the reproducer only.
+    // The product launches form 3 ALWAYS (packed FMAs on aligned R pairs x explicit L pairs: no op_sel operand anywhere -
+    // tests/test_cpu_oracle_and_abi.py checks the built code object).  Form 1 goes wrong whenever a bf16 MFMA of any
+    // kernel on the chip executes beside it (the op_sel bit of a v_pk_fma_f32 source is dropped for single passes:
+    // tools/micro/pkfma_corun.hip, profiles/r05_pkfma_corun.txt); form 2 costs more vector instructions than the scalar
+    // form 0; form 3 is bit-identical to all of them, as fast as form 1 in the pipeline (92 us against 98.5 us for
+    // form 0, profiles/r05_cv_form_inflight_ab.txt) and clean beside the aggressors that break form 1.  No process
+    // state, no launch-order dependence; forms 0 - 2 exist in the tools build (2-wave workgroups) for the reproducer.
 #ifdef ST_ABLATION
-    int fma_mode = 0;
+    int fma_mode = 3;
     if (const char* e = getenv("ST_CV_FMA")) fma_mode = atoi(e);   // tools/cv_stress.py
-    if (fma_mode != 0 && nwv != 2) return set_error(ST_ERR_INVALID, "ST_CV_FMA forms 1-3 exist for ST_CV_NWV=2 only");
+    if (fma_mode != 3 && nwv != 2) return set_error(ST_ERR_INVALID, "ST_CV_FMA forms 0-2 exist for ST_CV_NWV=2 only");
 #define ST_CVT_LAUNCH(DGV)                                                                                    \
   do {                                                                                                         \
     if (fma_mode == 1) ST_CVT_LAUNCH_I(DGV, 1, 2);                                                             \
     else if (fma_mode == 2) ST_CVT_LAUNCH_I(DGV, 2, 2);                                                        \
-    else if (fma_mode == 3) ST_CVT_LAUNCH_I(DGV, 3, 2);                                                        \
-    else if (nwv == 4) ST_CVT_LAUNCH_I(DGV, 0, 4);                                                             \
-    else ST_CVT_LAUNCH_I(DGV, 0, 2);                                                                           \
+    else if (fma_mode == 0) ST_CVT_LAUNCH_I(DGV, 0, 2);                                                        \
+    else if (nwv == 4) ST_CVT_LAUNCH_I(DGV, 3, 4);                                                             \
+    else ST_CVT_LAUNCH_I(DGV, 3, 2);                                                                           \
   } while (0)
 #else
 #define ST_CVT_LAUNCH(DGV)                                                                                    \
   do {                                                                                                         \
-    if (nwv == 4) ST_CVT_LAUNCH_I(DGV, 0, 4); else ST_CVT_LAUNCH_I(DGV, 0, 2);                                 \
+    if (nwv == 4) ST_CVT_LAUNCH_I(DGV, 3, 4); else ST_CVT_LAUNCH_I(DGV, 3, 2);                                 \
   } while (0)
 #endif
 #define ST_CVT_LAUNCH_I(DGV, PKV, NWVV)                                                                       \

@@ -78,7 +78,7 @@ def test_costvolume_beside_bf16_mfma_kernels_equals_serial_run(cuda):
     """Round-4 finding, closed structurally in round 5: a v_pk_fma_f32 whose source is broadcast by op_sel drops single
     16-lane passes of its low result half while bf16 MFMAs of ANY kernel execute on the chip (tools/micro/pkfma_corun.hip
     reproduces it in registers, profiles/r05_pkfma_corun.txt); the cost-volume kernel built that way returned a wrong
-    volume in 236 of 240 co-runs (profiles/r05_corun_cv_stress.txt).  The library ships a form without such operands and
+    volume in 236 of 240 co-runs (profiles/r05_corun_cv_stress.txt).  The library ships a packed form without such operands and
     contains no bf16 MFMA of its own any more, so the test brings the aggressor along (tests/helpers/mfma_aggressor.hip:
     a v_mfma_f32_16x16x32_bf16 loop with LDS-fed operands; beside it the OLD kernel form returned 236 of 240 volumes
     wrong and fails THIS test - verified with the tools build, profiles/r05_corun_cv_stress.txt).  ONE co-run:
