@@ -62,28 +62,35 @@ __global__ __launch_bounds__(256) void agg3d_kernel(const Agg3dArgs a) {
   const int nrow4 = TC * DQ;        // float4 per staged pixel row
   f32x4 st[NST];
   // one pixel row gy (columns x0-1 .. x0+TW, zero outside the image) from memory into registers / registers into slot
-  auto load_row = [&](int gy) {
+  auto load_row_into = [&](int gy, f32x4 (&r)[NST]) {
 #pragma unroll
     for (int i = 0; i < NST; ++i) {
       const int e = tid + 256 * i;
       const int q = e % DQ, c = e / DQ;
       const int gx = x0 + c - 1;
-      st[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+      r[i] = f32x4{0.f, 0.f, 0.f, 0.f};
       if (e < nrow4 && gy >= 0 && gy < a.Hf && gx >= 0 && gx < a.Wf)
-        st[i] = *reinterpret_cast<const f32x4*>(a.in + (((size_t)n * a.Hf + gy) * a.Wf + gx) * D + 4 * q);
+        r[i] = *reinterpret_cast<const f32x4*>(a.in + (((size_t)n * a.Hf + gy) * a.Wf + gx) * D + 4 * q);
     }
   };
-  auto store_row = [&](int gy) {
+  auto store_row_from = [&](int gy, const f32x4 (&r)[NST]) {
     float* dst = lds + (size_t)((gy + 4) & 3) * rowf;
 #pragma unroll
     for (int i = 0; i < NST; ++i) {
       const int e = tid + 256 * i;
-      if (e < nrow4) *reinterpret_cast<f32x4*>(dst + 4 * e) = st[i];
+      if (e < nrow4) *reinterpret_cast<f32x4*>(dst + 4 * e) = r[i];
     }
   };
-  for (int r = -1; r <= 1; ++r) {
-    load_row(y0 + r);
-    store_row(y0 + r);
+  auto load_row = [&](int gy) { load_row_into(gy, st); };
+  auto store_row = [&](int gy) { store_row_from(gy, st); };
+  {   // prologue: the three rows of the first output row with all their loads in flight at once (one memory round trip)
+    f32x4 p0[NST], p1[NST];
+    load_row_into(y0 - 1, p0);
+    load_row_into(y0, p1);
+    load_row(y0 + 1);
+    store_row_from(y0 - 1, p0);
+    store_row_from(y0, p1);
+    store_row(y0 + 1);
   }
   __syncthreads();
   const int nitem = TW * DQ;
@@ -141,15 +148,24 @@ extern "C" int st_volume_agg3d(const float* vol_in_dev, float* vol_out_dev, int 
   // 16 beyond (55 KB at D = 192) - two to three workgroups per CU in every case
   const int TW = D <= 48 ? 64 : (D <= 96 ? 32 : 16);
   const int strips = ceil_div(Wf, TW);
-  // band height: enough workgroups for ~8 per CU (whole launch rounds matter: 2.5 rounds of 368-row bands cost the
-  // full-resolution volume a half-empty last round), bands of at least 8 rows (halo re-read (RY + 2) / RY <= 1.25)
-  const int want_bands = std::max(1, ceil_div(8 * 256, N * strips));
-  int RY = std::max(8, ceil_div(Hf, want_bands));
-  RY = std::min(RY, Hf);
+  // Band height.  A workgroup's prologue (three rows) and its halo rows are overhead per band, a half-empty last launch
+  // round is overhead per launch: pick the band count b (rows RY = ceil(Hf / b) >= 4) that maximises
+  // (workgroups / slots rounded up to whole rounds) x RY / (RY + 3), slots = 256 CUs x workgroups per CU by LDS.
+  const int lds = 4 * (TW + 2) * D * (int)sizeof(float);
+  const long long slots = 256ll * std::max(1, (160 * 1024) / lds);
+  int best_b = 1;
+  double best_e = -1.0;
+  for (int b = 1; b <= 64 && ceil_div(Hf, b) >= 4; ++b) {
+    const int ry = ceil_div(Hf, b), nb = ceil_div(Hf, ry);
+    const long long wgs = (long long)N * strips * nb;
+    const double fill = (double)wgs / (double)(ceil_div((int)std::min<long long>(wgs, 1 << 30), (int)slots) * slots);
+    const double e = fill * ry / (ry + 3.0);
+    if (e > best_e + 1e-9) { best_e = e; best_b = b; }
+  }
+  int RY = std::min(Hf, ceil_div(Hf, best_b));
   a.RY = RY;
   const int bands = ceil_div(Hf, RY);
   ST_REQUIRE(bands < 65536, "st_volume_agg3d: grid too large");
-  const int lds = 4 * (TW + 2) * D * (int)sizeof(float);
   const dim3 grid((unsigned)strips, (unsigned)bands, (unsigned)N);
   hipStream_t stream = static_cast<hipStream_t>(stream_);
 #define ST_A3_LAUNCH(TWV, NSTV)                                                                      \
