@@ -465,9 +465,21 @@ __global__ __launch_bounds__(256) void softargmin_lds_kernel(const float* __rest
   const int D4 = D >> 2;
   const float4* src = reinterpret_cast<const float4*>(cost + p0 * D);
   const int nf4 = np * D4;
-  for (int f = threadIdx.x; f < nf4; f += PB) {
-    const int pix = f / D4, k = f - pix * D4;
-    *reinterpret_cast<float4*>(sm + pix * ldsw + 4 * k) = src[f];
+  for (int f0 = threadIdx.x; f0 < nf4; f0 += 4 * PB) {   // four loads in flight per thread, then their LDS writes
+    float4 t[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int f = f0 + j * PB;
+      if (f < nf4) t[j] = src[f];
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int f = f0 + j * PB;
+      if (f < nf4) {
+        const int pix = f / D4, k = f - pix * D4;
+        *reinterpret_cast<float4*>(sm + pix * ldsw + 4 * k) = t[j];
+      }
+    }
   }
   __syncthreads();
   if ((int)threadIdx.x >= np) return;
@@ -514,15 +526,27 @@ __global__ __launch_bounds__(256) void softargmin_reg_kernel(const float* __rest
   for (long long wv = (long long)blockIdx.x * 4 + wave; wv < nwave; wv += (long long)gridDim.x * 4) {
     const long long p0 = wv * PPW;
     float v[DL];
-#pragma unroll
-    for (int ch = 0; ch < LCH; ++ch) {
+    // chunk ch + 1 is requested from memory BEFORE chunk ch goes through the tile: one round trip in flight behind the
+    // LDS transposition of the previous one (a wave has few neighbours here: two waves per SIMD)
+    f32x4 xa[4];
+    auto load_chunk = [&](int ch, f32x4 (&x)[4]) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int e = lane + 64 * i, row = e >> 2, q = e & 3;     // tile row = the lane that will read it
         const int px = row / K, sb = row % K;
-        f32x4 x = {0.f, 0.f, 0.f, 0.f};
-        if (p0 + px < npix) x = *reinterpret_cast<const f32x4*>(cost + (p0 + px) * D + sb * DL + ch * 16 + 4 * q);
-        *reinterpret_cast<f32x4*>(tw + row * 20 + 4 * q) = x;
+        x[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (p0 + px < npix) x[i] = *reinterpret_cast<const f32x4*>(cost + (p0 + px) * D + sb * DL + ch * 16 + 4 * q);
+      }
+    };
+    load_chunk(0, xa);
+#pragma unroll
+    for (int ch = 0; ch < LCH; ++ch) {
+      f32x4 xb[4];
+      if (ch + 1 < LCH) load_chunk(ch + 1, xb);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int e = lane + 64 * i, row = e >> 2, q = e & 3;
+        *reinterpret_cast<f32x4*>(tw + row * 20 + 4 * q) = xa[i];
       }
       // the tile is private to this wave and LDS executes a wave's instructions in order: no workgroup barrier, the
       // fences keep the compiler from reordering and make it wait for the writes before the reads' data is used
@@ -538,6 +562,10 @@ __global__ __launch_bounds__(256) void softargmin_reg_kernel(const float* __rest
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();     // the next chunk overwrites the tile: every lane has read its row
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      if (ch + 1 < LCH) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) xa[i] = xb[i];
+      }
     }
     float m = -__builtin_inff();
 #pragma unroll
