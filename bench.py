@@ -558,11 +558,16 @@ def fullres_leg(args, inputs, batch_cpu, headline, plan, dev):
         H, W = pipe.height, pipe.width
         vol_bytes = 4.0 * B * H * W * D
         cv_b = vol_bytes + 2 * 4.0 * B * H * W * 8
-        kern = dict(
-            cost_volume=dict(ms=round(stages['cost_volume'], 3), bytes=int(cv_b), frac_of_8TBs=round(cv_b / (stages['cost_volume'] * 1e-3) / 8e12, 4)),
-            agg3d=dict(ms=round(stages['agg3d'], 3), bytes=int(2 * vol_bytes), frac_of_8TBs=round(2 * vol_bytes / (stages['agg3d'] * 1e-3) / 8e12, 4)),
-            softargmin_pack=dict(ms=round(stages['softargmin_pack'], 3), bytes=int(vol_bytes), frac_of_8TBs=round(vol_bytes / (stages['softargmin_pack'] * 1e-3) / 8e12, 4)),
-            features_reduce_upsample_ms=round(stages['features_reduce_upsample'], 3))
+        def hbm(ms, nbytes):
+            return dict(ms=round(ms, 3), bytes=int(nbytes), frac_of_8TBs=round(nbytes / (ms * 1e-3) / 8e12, 4))
+        kern = dict(softargmin_pack=hbm(stages['softargmin_pack'], vol_bytes),
+                    features_reduce_upsample_ms=round(stages['features_reduce_upsample'], 3))
+        if 'cost_volume_agg3d_first' in stages:     # one pass: features in, aggregated volume out (st_costvolume_agg3d)
+            kern['cost_volume_agg3d_fused'] = dict(hbm(stages['cost_volume_agg3d_first'], cv_b),
+                                                   valu_tflops=round(2.0 * (27 + 8) * B * H * W * D / (stages['cost_volume_agg3d_first'] * 1e-3) / 1e12, 1))
+        else:
+            kern['cost_volume'] = hbm(stages['cost_volume'], cv_b)
+            kern['agg3d'] = hbm(stages['agg3d'], 2 * vol_bytes)
         # oracle, pair 0 (the C oracle walks 181 M cells three times: tens of seconds)
         ora = OracleDetector(0.33, 0.5, 1).eval()
         ora.load_state_dict(sd, strict=False)

@@ -364,6 +364,15 @@ int st_costvolume_softargmin(const float* featL_dev, const float* featR_dev, int
  * kernel arguments).  vol_in != vol_out, 16-byte aligned, D a multiple of 4 (<= 192). */
 int st_volume_agg3d(const float* vol_in_dev, float* vol_out_dev, int N, int Hf, int Wf, int D,
                     const float* weight27_host, float bias, int act, st_stream_t stream);
+/* Cost volume and the FIRST 3-D aggregation layer in one pass (the volume between them never reaches memory):
+ * vol_out = agg3d(costvolume(featL, featR)), cell for cell the arithmetic of st_costvolume_softargmin's volume followed by
+ * st_volume_agg3d (specification: oracle_costvolume then oracle_agg3d, bit-exact).  featL/featR: NHWC [N][H][W][ld],
+ * channels [0, C) used.  Built for the full-resolution mode of the stereo module (north_star's D = 192 sizing; no
+ * reference function, consumer contract as for st_costvolume_softargmin).  C in {4, 8, 16}, D a multiple of 4 (<= 192):
+ * st_costvolume_agg3d_supported(C, D) tells (1/0); other shapes take the two calls above. */
+int st_costvolume_agg3d_supported(int C, int D);
+int st_costvolume_agg3d(const float* featL_dev, const float* featR_dev, int N, int H, int W, int C, int feat_ld, int D,
+                        const float* weight27_host, float bias, int act, float* vol_out_dev, st_stream_t stream);
 /* soft-argmin only, on an (aggregated) volume [N][Hf][Wf][D] */
 int st_softargmin(const float* cost_dev, int N, int Hf, int Wf, int D, float temperature,
                   float* out_disp_dev, st_stream_t stream);

@@ -12,6 +12,8 @@
 // produces 4 consecutive disparities of one pixel from 9 aligned 16-byte LDS reads + the two neighbours across the quad
 // borders, and stores 16 bytes.
 #include <algorithm>
+#include <cstdlib>
+#include <type_traits>
 
 #include "st_common.h"
 
@@ -19,6 +21,7 @@ namespace st {
 namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ float a3_expf(float x) {  // same polynomial as decode_nms.hip / costvolume.hip / oracle
   if (x > 88.72283f) return __builtin_inff();
@@ -128,6 +131,208 @@ __global__ __launch_bounds__(256) void agg3d_kernel(const Agg3dArgs a) {
   }
 }
 
+
+// ---- fused first layer: cost volume from the feature maps -> 3x3x3 layer ------------------------------------------
+// st_costvolume_agg3d: out = agg3d(costvolume(featL, featR)) without the volume in between ever reaching memory (at the
+// full-resolution sizing the materialised form writes 6.3 GB and reads them back, per 8 pairs).  Arithmetic per cell
+// is that of costvolume.hip followed by the kernel above, fmaf for fmaf (oracle_costvolume, then oracle_agg3d).
+//
+// A workgroup owns a strip of TW pixel columns x all D levels and walks down a band of rows.  Per row r:
+//   produce   cost row r for columns x0-1 .. x0+TW from the staged feature rows (LDS, channel-major so that four
+//             neighbouring pixels of one channel are one 16-byte read): a thread computes a 4 pixel x 4 level tile (7
+//             right-image pixels feed its 16 cells), 2 * D/4 threads add the two halo columns;
+//   (barrier) every thread takes the 6 columns x 6 levels it needs of the new cost row into registers;
+//   stencil   output row r-1 from rows r-2, r-1 (kept in registers from the two iterations before) and r: 4 pixels x 4
+//             levels per thread, 16-byte stores; the feature row r+1 (requested from memory before `produce`) goes
+//             into the stage;
+//   (barrier)
+// The three register rows rotate by name (the loop body is instantiated three times), not by copies.
+struct CvAggArgs {
+  const float* fl;
+  const float* fr;
+  float* out;
+  int N, H, W, ld, D, RY;
+  float w[27];
+  float bias;
+  int act;
+};
+
+// DFIX: D == DMAX, known at compile time (every offset an immediate)
+template <int TW, int C, int DMAX, bool DFIX, int MODE = 0>   // MODE: timing-only ablations of the tools build (0 in the product)
+__global__ __launch_bounds__(192) __attribute__((amdgpu_waves_per_eu(3))) void cv_agg3d_kernel(const CvAggArgs a) {
+  constexpr int NT = 192, CQ = C / 4, NG = TW / 4, FLW = TW + 8;
+  extern __shared__ float4 a3_smem4[];
+  float* lds = reinterpret_cast<float*>(a3_smem4);
+  const int D = DFIX ? DMAX : a.D, DQ = D >> 2, FRW = D + TW + 4;
+  float* costrow = lds;                          // [TW + 2][D]
+  float* frs = costrow + (TW + 2) * D;           // [C][FRW]: right-image pixels x0 - D .. x0 + TW + 3
+  float* fls = frs + C * FRW;                    // [C][FLW]: left-image pixels x0 - 4 .. x0 + TW + 3
+  const int x0 = blockIdx.x * TW, y0 = blockIdx.y * a.RY, n = blockIdx.z;
+  const int y1 = min(y0 + a.RY, a.H);
+  const int tid = threadIdx.x;
+  const int q = tid % DQ, g = tid / DQ;
+  const bool active = (DFIX && TW * DMAX / 16 == NT) ? true : g < NG;
+  constexpr float invC = 1.0f / (float)C;        // C is a power of two: the product equals the oracle's quotient
+
+  // staging plan of a feature row (per thread, fixed for the whole band): NFR float4 of the right image, one of the left
+  constexpr int NFR = ((DMAX + TW + 4) * CQ + NT - 1) / NT;
+  constexpr int NFL = (FLW * CQ + NT - 1) / NT;
+  // float4 i of a thread: channel quad tid % CQ of stage pixel tid / CQ + i * (NT / CQ); a pixel left of the image gives a
+  // negative (= huge unsigned) byte offset, one right of it an offset beyond the row: both outside the descriptor
+  static_assert(NT % CQ == 0, "staging plan");
+  constexpr int PSTEP = NT / CQ;
+  const int scq = tid % CQ, spx = tid / CQ;
+  const int fr_off0 = ((x0 - D + spx) * a.ld + 4 * scq) * 4, fl_off0 = ((x0 - 4 + spx) * a.ld + 4 * scq) * 4;   // bytes
+  const int off_step = PSTEP * a.ld * 4;
+  const int fr_dst0 = (4 * scq) * FRW + spx, fl_dst0 = (4 * scq) * FLW + spx;                                    // floats
+  f32x4 stg[NFR], stl[NFL];
+  // Feature rows travel through buffer loads: the descriptor is the ROW (uniform base, num_records = its bytes), a
+  // thread's part is a fixed 32-bit byte offset; pixels left or right of the image carry an offset beyond the row and
+  // read as zero by the descriptor's range check.
+  const int rowbytes = a.W * a.ld * 4;
+  auto load_feat = [&](int gy) {                 // feature row gy -> registers (zero outside the image)
+    if (gy < 0 || gy >= a.H) {                   // uniform
+#pragma unroll
+      for (int i = 0; i < NFR; ++i) stg[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int i = 0; i < NFL; ++i) stl[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+      return;
+    }
+    const size_t rowbase = ((size_t)n * a.H + gy) * a.W * a.ld;
+    const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.fr + rowbase), 0, rowbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rl = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.fl + rowbase), 0, rowbytes, 0x00020000);
+#pragma unroll
+    for (int i = 0; i < NFR; ++i) stg[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rr, fr_off0 + i * off_step, 0, 0));
+#pragma unroll
+    for (int i = 0; i < NFL; ++i) stl[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rl, fl_off0 + i * off_step, 0, 0));
+  };
+  auto store_feat = [&]() {                      // registers -> channel-major stage
+#pragma unroll
+    for (int i = 0; i < NFR; ++i)
+      if (spx + i * PSTEP < FRW) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) frs[fr_dst0 + i * PSTEP + t * FRW] = stg[i][t];
+      }
+#pragma unroll
+    for (int i = 0; i < NFL; ++i)
+      if (spx + i * PSTEP < FLW) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) fls[fl_dst0 + i * PSTEP + t * FLW] = stl[i][t];
+      }
+  };
+  auto produce = [&]() {                         // staged feature row -> cost row in LDS
+    if (active) {
+      float acc[4][4];
+#pragma unroll
+      for (int pi = 0; pi < 4; ++pi)
+#pragma unroll
+        for (int dj = 0; dj < 4; ++dj) acc[pi][dj] = 0.0f;
+#pragma unroll 1
+      for (int c = 0; c < ((MODE & 2) ? 0 : C); ++c) {
+        const f32x4 L = *reinterpret_cast<const f32x4*>(fls + c * FLW + 4 * g + 4);
+        const float* rp = frs + c * FRW + (D + 4 * g - 4 * q - 4);
+        const f32x4 ra = *reinterpret_cast<const f32x4*>(rp), rb = *reinterpret_cast<const f32x4*>(rp + 4);
+        const float R[8] = {ra[0], ra[1], ra[2], ra[3], rb[0], rb[1], rb[2], rb[3]};
+#pragma unroll
+        for (int pi = 0; pi < 4; ++pi)
+#pragma unroll
+          for (int dj = 0; dj < 4; ++dj) acc[pi][dj] = fmaf(L[pi], R[4 + pi - dj], acc[pi][dj]);
+      }
+#pragma unroll
+      for (int pi = 0; pi < 4; ++pi)
+        *reinterpret_cast<f32x4*>(costrow + (1 + 4 * g + pi) * D + 4 * q) =
+            f32x4{acc[pi][0] * invC, acc[pi][1] * invC, acc[pi][2] * invC, acc[pi][3] * invC};
+    }
+    if (tid < 2 * DQ) {                          // halo columns x0 - 1 (side 0) and x0 + TW (side 1)
+      const int side = tid / DQ, hq = tid % DQ;
+      const int pxo = side ? TW + 4 : 3;         // in fls
+      // right-image pixels px - 4 hq - 3 .. px - 4 hq; relative to x0 - D: aligned (side 0) or one past a boundary
+      const int roff = side ? D + TW - 4 * hq - 4 : D - 4 * hq - 4, sh = side ? 1 : 0;
+      float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+      for (int c = 0; c < C; ++c) {
+        const float l = fls[c * FLW + pxo];
+        const float* rp = frs + c * FRW + roff;
+        const f32x4 ra = *reinterpret_cast<const f32x4*>(rp), rb = *reinterpret_cast<const f32x4*>(rp + 4);
+        const float R[8] = {ra[0], ra[1], ra[2], ra[3], rb[0], rb[1], rb[2], rb[3]};
+#pragma unroll
+        for (int dj = 0; dj < 4; ++dj) acc[dj] = fmaf(l, sh ? R[4 - dj] : R[3 - dj], acc[dj]);
+      }
+      *reinterpret_cast<f32x4*>(costrow + (side ? TW + 1 : 0) * D + 4 * hq) =
+          f32x4{acc[0] * invC, acc[1] * invC, acc[2] * invC, acc[3] * invC};
+    }
+  };
+  // one iteration; (ra, rb) hold cost rows r-2, r-1, rc receives row r
+  auto step = [&](auto out_tag, int r, float (&ra)[6][6], float (&rb)[6][6], float (&rc)[6][6]) {
+    constexpr bool OUT = decltype(out_tag)::value;
+    produce();
+    __syncthreads();
+    if (active) {
+#pragma unroll
+      for (int col = 0; col < 6; ++col) {
+        const float* p = costrow + (4 * g + col) * D + 4 * q;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(p);
+        rc[col][0] = q > 0 ? p[-1] : 0.0f;
+        rc[col][1] = v[0]; rc[col][2] = v[1]; rc[col][3] = v[2]; rc[col][4] = v[3];
+        rc[col][5] = q < DQ - 1 ? p[4] : 0.0f;
+      }
+    }
+    // feature row r+1 is requested now (the stage still holds row r, which `produce` is done with), travels during the
+    // stencil and is written to the stage behind it: the wait in front of that write allows the four output stores
+    // issued after the loads to be still in flight (vmcnt counts both)
+    if (r + 1 <= y1 && !((MODE & 8) && OUT)) load_feat(r + 1);
+    const int y = r - 1;
+    if (OUT && active) {
+      // the strip's output row as a buffer: pixels beyond the image fall outside the descriptor and are dropped
+      const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(
+          a.out + (((size_t)n * a.H + y) * a.W + x0) * D, 0, min(TW, a.W - x0) * D * 4, 0x00020000);
+#pragma unroll
+      for (int pi = 0; pi < 4; ++pi) {
+        float acc[4] = {a.bias, a.bias, a.bias, a.bias};
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+#pragma unroll
+          for (int k = 0; k < 3; ++k) {
+            const float* vals = j == 0 ? ra[pi + k] : (j == 1 ? rb[pi + k] : rc[pi + k]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+              for (int i = 0; i < ((MODE & 4) ? 1 : 3); ++i) acc[e] = fmaf(a.w[(i * 3 + j) * 3 + k], vals[e + i], acc[e]);
+          }
+        }
+        {
+          f32x4 o;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] = a.act ? acc[e] / (1.0f + a3_expf(-acc[e])) : acc[e];
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), orsrc, ((4 * g + pi) * D + 4 * q) * 4, 0, 0);
+        }
+      }
+    }
+    if (r + 1 <= y1) store_feat();
+    __syncthreads();
+  };
+
+  float r0[6][6], r1[6][6], r2[6][6];
+#pragma unroll
+  for (int c = 0; c < 6; ++c)
+#pragma unroll
+    for (int e = 0; e < 6; ++e) r0[c][e] = r1[c][e] = r2[c][e] = 0.0f;
+  load_feat(y0 - 1);
+  store_feat();
+  __syncthreads();
+  const std::false_type fill{};
+  const std::true_type emit{};
+  step(fill, y0 - 1, r0, r1, r2);                // cost rows y0-1 and y0: no output row yet
+  step(fill, y0, r1, r2, r0);
+  for (int r = y0 + 1; r <= y1; r += 3) {        // row r completes output row r-1; y1 is the row under the last one
+    step(emit, r, r2, r0, r1);
+    if (r + 1 > y1) break;
+    step(emit, r + 1, r0, r1, r2);
+    if (r + 2 > y1) break;
+    step(emit, r + 2, r1, r2, r0);
+  }
+}
+
 }  // namespace
 }  // namespace st
 
@@ -184,6 +389,88 @@ extern "C" int st_volume_agg3d(const float* vol_in_dev, float* vol_out_dev, int 
     ST_A3_LAUNCH(16, 4);
   }
 #undef ST_A3_LAUNCH
+  ST_CHECK_HIP(hipGetLastError());
+  return ST_OK;
+}
+
+extern "C" int st_costvolume_agg3d_supported(int C, int D) {
+  return (C == 4 || C == 8 || C == 16) && D >= 4 && D % 4 == 0 && D <= 192;
+}
+
+extern "C" int st_costvolume_agg3d(const float* featL_dev, const float* featR_dev, int N, int H, int W, int C, int ld,
+                                   int D, const float* weight27_host, float bias, int act, float* vol_out_dev,
+                                   st_stream_t stream_) {
+  using namespace st;
+  ST_REQUIRE(featL_dev && featR_dev && vol_out_dev && weight27_host, "st_costvolume_agg3d: bad pointer");
+  ST_REQUIRE(N > 0 && H > 0 && W > 0, "st_costvolume_agg3d: bad shape");
+  ST_REQUIRE(st_costvolume_agg3d_supported(C, D),
+             "st_costvolume_agg3d: needs C in {4, 8, 16} and D a multiple of 4 in [4, 192] (got C = %d, D = %d)", C, D);
+  ST_REQUIRE(ld >= C && ld % 4 == 0, "st_costvolume_agg3d: ld must be a multiple of 4 and >= C");
+  ST_REQUIRE(((reinterpret_cast<uintptr_t>(featL_dev) | reinterpret_cast<uintptr_t>(featR_dev) |
+               reinterpret_cast<uintptr_t>(vol_out_dev)) & 15) == 0, "st_costvolume_agg3d: buffers must be 16-byte aligned");
+  ST_REQUIRE(H < 65536 && N < 65536, "st_costvolume_agg3d: grid too large");
+  CvAggArgs a;
+  a.fl = featL_dev; a.fr = featR_dev; a.out = vol_out_dev;
+  a.N = N; a.H = H; a.W = W; a.ld = ld; a.D = D;
+  for (int i = 0; i < 27; ++i) a.w[i] = weight27_host[i];
+  a.bias = bias; a.act = act;
+  // strip width: TW x D / 16 threads (<= 192) each own a 4 pixel x 4 level tile
+  const int TW = D <= 48 ? 64 : (D <= 96 ? 32 : 16);
+  const int strips = ceil_div(W, TW);
+  const int lds = ((TW + 2) * D + C * (D + TW + 4) + C * (TW + 8)) * (int)sizeof(float);
+  // band count: whole launch rounds over 256 CUs x 4 workgroups (register-bound), two produce-only rows per band
+  const long long slots = 256ll * 4;
+  int best_b = 1;
+  double best_e = -1.0;
+  for (int b = 1; b <= 64 && ceil_div(H, b) >= 4; ++b) {
+    const int ry = ceil_div(H, b), nb = ceil_div(H, ry);
+    const long long wgs = (long long)N * strips * nb;
+    const double fill = (double)wgs / (double)(ceil_div((int)std::min<long long>(wgs, 1 << 30), (int)slots) * slots);
+    const double e = fill * ry / (ry + 1.0);
+    if (e > best_e + 1e-9) { best_e = e; best_b = b; }
+  }
+  a.RY = std::min(H, ceil_div(H, best_b));
+  const int bands = ceil_div(H, a.RY);
+  ST_REQUIRE(bands < 65536, "st_costvolume_agg3d: grid too large");
+  const dim3 grid((unsigned)strips, (unsigned)bands, (unsigned)N);
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+#define ST_CVA_LAUNCH(TWV, CV, DMAXV)                                                                \
+  do {                                                                                               \
+    auto kern = D == DMAXV ? cv_agg3d_kernel<TWV, CV, DMAXV, true> : cv_agg3d_kernel<TWV, CV, DMAXV, false>; \
+    static int lds_set = 0;                                                                          \
+    ST_ENSURE_DYNAMIC_LDS(kern, lds, lds_set);                                                       \
+    hipLaunchKernelGGL(kern, grid, dim3(192), lds, stream, a);                                       \
+  } while (0)
+#define ST_CVA_BY_C(TWV, DMAXV)                                                                      \
+  do {                                                                                               \
+    if (C == 4) ST_CVA_LAUNCH(TWV, 4, DMAXV);                                                        \
+    else if (C == 8) ST_CVA_LAUNCH(TWV, 8, DMAXV);                                                   \
+    else ST_CVA_LAUNCH(TWV, 16, DMAXV);                                                              \
+  } while (0)
+#ifdef ST_ABLATION
+  if (const char* m = getenv("ST_CVA_MODE")) {     // tools: timing-only ablations at the full-resolution shape
+    const int mode = atoi(m);
+    if (mode > 0 && D == 192 && C == 8) {
+      auto launch = [&](auto kern) -> int {
+        ST_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        hipLaunchKernelGGL(kern, grid, dim3(192), lds, stream, a);
+        return ST_OK;
+      };
+      switch (mode) {
+        case 2: return launch(cv_agg3d_kernel<16, 8, 192, true, 2>);
+        case 4: return launch(cv_agg3d_kernel<16, 8, 192, true, 4>);
+        case 6: return launch(cv_agg3d_kernel<16, 8, 192, true, 6>);
+        case 8: return launch(cv_agg3d_kernel<16, 8, 192, true, 8>);
+        default: break;
+      }
+    }
+  }
+#endif
+  if (TW == 64) ST_CVA_BY_C(64, 48);
+  else if (TW == 32) ST_CVA_BY_C(32, 96);
+  else ST_CVA_BY_C(16, 192);
+#undef ST_CVA_BY_C
+#undef ST_CVA_LAUNCH
   ST_CHECK_HIP(hipGetLastError());
   return ST_OK;
 }

@@ -95,6 +95,8 @@ class StereoCostVolume(nn.Module):
         self._packed = None    # (device, weights version, [(wgt, bias)])
         self._red = None       # (device, weights version, packed reduce weights, bias)
         self._fr = None        # full-resolution buffers: reduced features, upsampled features, two volumes, disparity
+        self.fuse_first_layer = True   # full-resolution mode: cost volume + first 3-D layer in one kernel (tools may clear it)
+        self._fr_fused = False
         self._taps3d = None    # (weights version, [(27 host floats as a ctypes array, bias)])
         self._vol = None
         self.variant = -1      # conv tile variant of the aggregation layers (-1 = library default, or autotune())
@@ -330,12 +332,22 @@ class StereoCostVolume(nn.Module):
         gl = b['up'].data_ptr()
         gr = gl + N * H * W * Cr * 4
         va, vb = b['va'], b['vb']
-        check(self.lib.st_costvolume_softargmin(C.c_void_p(gl), C.c_void_p(gr), N, H, W, Cr, Cr, D, self.temperature,
-                                                ptr(va), None, stream), 'st_costvolume_softargmin')
+        layers = self._pack3d()
+        # cost volume and the first 3-D layer in one pass when the kernel takes the shape (the volume between them - 6.3 GB
+        # per 8 pairs at D = 192 - then never reaches memory); the two-call form otherwise.  Same bits either way.
+        fused = bool(layers) and self.fuse_first_layer and self.lib.st_costvolume_agg3d_supported(Cr, D) == 1
+        if fused:
+            w27, b3 = layers[0]
+            check(self.lib.st_costvolume_agg3d(C.c_void_p(gl), C.c_void_p(gr), N, H, W, Cr, Cr, D, w27, b3,
+                                               1 if self.agg3d_layers > 1 else 0, ptr(va), stream), 'st_costvolume_agg3d')
+            layers = layers[1:]
+        else:
+            check(self.lib.st_costvolume_softargmin(C.c_void_p(gl), C.c_void_p(gr), N, H, W, Cr, Cr, D, self.temperature,
+                                                    ptr(va), None, stream), 'st_costvolume_softargmin')
         mark()
-        for l, (w27, b3) in enumerate(self._pack3d()):
+        for l, (w27, b3) in enumerate(layers):
             check(self.lib.st_volume_agg3d(ptr(va), ptr(vb), N, H, W, D, w27, b3,
-                                           1 if l < self.agg3d_layers - 1 else 0, stream), 'st_volume_agg3d')
+                                           1 if l < len(layers) - 1 else 0, stream), 'st_volume_agg3d')
             va, vb = vb, va
         mark()
         if cost_out is not None:
@@ -346,14 +358,17 @@ class StereoCostVolume(nn.Module):
         mark()
         if self.timing:
             self._fr_events = ev
+            self._fr_fused = fused
         return disp_postp
 
     def pop_full_res_times(self):
         """ms of the stages of the last full-resolution compute (timing=True): features (reduce + upsample), cost
-        volume, 3-D aggregation, soft-argmin + pack."""
+        volume, 3-D aggregation, soft-argmin + pack - or, when the first 3-D layer ran fused with the cost volume:
+        features, cost volume + first layer, remaining layers, soft-argmin + pack."""
         ev = getattr(self, '_fr_events', None)
         if not ev:
             return None
         ev[-1].synchronize()
-        names = ('features_reduce_upsample', 'cost_volume', 'agg3d', 'softargmin_pack')
+        names = (('features_reduce_upsample', 'cost_volume_agg3d_first', 'agg3d_rest', 'softargmin_pack') if self._fr_fused
+                 else ('features_reduce_upsample', 'cost_volume', 'agg3d', 'softargmin_pack'))
         return {n: ev[i].elapsed_time(ev[i + 1]) for i, n in enumerate(names)}

@@ -374,6 +374,45 @@ def test_agg3d_layer_bit_exact(N, Hf, Wf, D, act, cuda):
     assert lib.st_volume_agg3d(ptr(src), ptr(dst), N, Hf, Wf, 6, w27, bias, act, current_stream()) != 0
 
 
+@pytest.mark.parametrize('N,H,W,Cc,ld,D,act', [(2, 20, 70, 8, 8, 192, 0),    # 16-pixel strips, ragged last strip, all threads busy
+                                                (1, 41, 100, 4, 4, 96, 1),    # 32-pixel strips, several bands
+                                                (1, 7, 130, 16, 16, 48, 1),   # 64-pixel strips
+                                                (1, 9, 45, 8, 12, 64, 0),     # D = 64: idle threads in the workgroup; padded rows
+                                                (2, 5, 33, 8, 8, 20, 1),      # D = 20: five quads per pixel
+                                                (1, 1, 1, 4, 4, 4, 1),        # one cell column
+                                                (1, 3, 300, 8, 8, 192, 1)])   # x < d over the first strips only
+def test_costvolume_agg3d_fused_bit_exact(N, H, W, Cc, ld, D, act, cuda):
+    """st_costvolume_agg3d (the volume between the cost kernel and the first 3-D layer never reaches memory) against
+    oracle_costvolume followed by oracle_agg3d: BIT-EXACT, zero padding of the volume in x, y and d, cells with x < d
+    zero, ragged strips and bands, feature rows with padding channels (ld > C)."""
+    lib = _lib.load()
+    rng = np.random.RandomState(D * 3 + W)
+    fl = rng.normal(0, 1.0, (N, H, W, ld)).astype(np.float32)
+    fr = rng.normal(0, 1.0, (N, H, W, ld)).astype(np.float32)
+    w = rng.normal(0, 0.4, (3, 3, 3)).astype(np.float32)
+    bias = -0.0625
+    ref = c_oracle.agg3d(c_oracle.costvolume(fl, fr, Cc, D), w, bias, act)
+    assert lib.st_costvolume_agg3d_supported(Cc, D) == 1
+    gl, gr = torch.from_numpy(fl).to(cuda), torch.from_numpy(fr).to(cuda)
+    out = torch.full((N, H, W, D), float('nan'), device=cuda)
+    w27 = (C.c_float * 27)(*w.reshape(-1).tolist())
+    check(lib.st_costvolume_agg3d(ptr(gl), ptr(gr), N, H, W, Cc, ld, D, w27, bias, act, ptr(out), current_stream()),
+          'st_costvolume_agg3d')
+    torch.cuda.synchronize()
+    got = out.cpu().numpy()
+    assert np.array_equal(got.view(np.uint32), ref.view(np.uint32)), np.abs(got - ref).max()
+    # and the two-call form it replaces gives the same bits
+    vol = torch.empty_like(out)
+    out2 = torch.empty_like(out)
+    check(lib.st_costvolume_softargmin(ptr(gl), ptr(gr), N, H, W, Cc, ld, D, 1.0, ptr(vol), None, current_stream()))
+    check(lib.st_volume_agg3d(ptr(vol), ptr(out2), N, H, W, D, w27, bias, act, current_stream()))
+    torch.cuda.synchronize()
+    assert torch.equal(out, out2)
+    # shapes the fused kernel does not take are refused, not computed differently
+    assert lib.st_costvolume_agg3d_supported(64, 48) == 0 and lib.st_costvolume_agg3d_supported(8, 196) == 0
+    assert lib.st_costvolume_agg3d(ptr(gl), ptr(gr), N, H, W, 5, ld, D, w27, bias, act, ptr(out), current_stream()) != 0
+
+
 @pytest.mark.parametrize('N,Hf,Wf,D', [(1, 3, 37, 192), (2, 2, 45, 128), (1, 5, 13, 112), (1, 1, 70, 144), (1, 2, 33, 176)])
 def test_softargmin_wide_volumes_bit_exact(N, Hf, Wf, D, cuda):
     """st_softargmin on volumes of 112 .. 192 levels (the full-resolution mode): rows held in registers, split over two

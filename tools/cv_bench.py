@@ -49,3 +49,32 @@ for label, (n, hf, wf, d) in (('bench volume 8x184x320x48', (8, 184, 320, 48)), 
     nbytes = 2.0 * vin.numel() * 4
     print(f'agg3d ({label}): {us:.1f} us, algorithmic {nbytes / 1e6:.1f} MB -> {nbytes / us / 1e6:.2f} TB/s = {nbytes / us / 8e6:.2f} of 8 TB/s')
     del vin, vout
+
+# ---- fused cost volume + first 3-D layer (st_costvolume_agg3d) at the full-resolution sizing of the product mode:
+# 8 pairs x 736 x 1280, 8 feature channels, D = 192; algorithmic traffic = features read once + volume written once
+n, h, w, c, d = 8, 736, 1280, 8, 192
+gl = torch.randn(n, h, w, c, device=dev)
+gr = torch.randn(n, h, w, c, device=dev)
+vout = torch.empty(n, h, w, d, device=dev)
+for _ in range(2):
+    check(lib.st_costvolume_agg3d(ptr(gl), ptr(gr), n, h, w, c, c, d, w27, 0.01, 0, ptr(vout), None))
+torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+for _ in range(max(2, reps // 4)):
+    check(lib.st_costvolume_agg3d(ptr(gl), ptr(gr), n, h, w, c, c, d, w27, 0.01, 0, ptr(vout), None))
+e1.record()
+torch.cuda.synchronize()
+us = e0.elapsed_time(e1) / max(2, reps // 4) * 1e3
+nbytes = vout.numel() * 4.0 + 2.0 * gl.numel() * 4
+print(f'fused cost volume + agg3d (8 x 736 x 1280 x 192, C = 8): {us:.1f} us, algorithmic {nbytes / 1e6:.1f} MB -> '
+      f'{nbytes / us / 1e6:.2f} TB/s = {nbytes / us / 8e6:.2f} of 8 TB/s; {n * h * w * d * (27 + c) * 2 / us / 1e6:.1f} TFLOP/s fp32 VALU')
+vol = torch.empty_like(vout)
+torch.cuda.synchronize()
+e0.record()
+for _ in range(2):
+    check(lib.st_costvolume_softargmin(ptr(gl), ptr(gr), n, h, w, c, c, d, 1.0, ptr(vol), None, None))
+    check(lib.st_volume_agg3d(ptr(vol), ptr(vout), n, h, w, d, w27, 0.01, 0, None))
+e1.record()
+torch.cuda.synchronize()
+print(f'two-call form (volume through memory): {e0.elapsed_time(e1) / 2 * 1e3:.1f} us')
