@@ -20,6 +20,7 @@
 namespace st {
 namespace {
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
@@ -164,8 +165,12 @@ __global__ __launch_bounds__(192) __attribute__((amdgpu_waves_per_eu(3))) void c
   extern __shared__ float4 a3_smem4[];
   float* lds = reinterpret_cast<float*>(a3_smem4);
   const int D = DFIX ? DMAX : a.D, DQ = D >> 2, FRW = D + TW + 4;
-  float* costrow = lds;                          // [TW + 2][D]
-  float* frs = costrow + (TW + 2) * D;           // [C][FRW]: right-image pixels x0 - D .. x0 + TW + 3
+  // cost row: [TW + 2][DS], level d of a column at float d + 1, floats 0 and D + 1 stay zero (levels -1 and D of the zero
+  // padded volume): the six levels 4q-1 .. 4q+4 a thread needs are one aligned 16-byte + one aligned 8-byte read, and
+  // land in registers as the pairs (4q-1, 4q), (4q+1, 4q+2), (4q+3, 4q+4) the packed FMAs below take as they are
+  const int DS = D + 4;
+  float* costrow = lds;
+  float* frs = costrow + (TW + 2) * DS;          // [C][FRW]: right-image pixels x0 - D .. x0 + TW + 3
   float* fls = frs + C * FRW;                    // [C][FLW]: left-image pixels x0 - 4 .. x0 + TW + 3
   const int x0 = blockIdx.x * TW, y0 = blockIdx.y * a.RY, n = blockIdx.z;
   const int y1 = min(y0 + a.RY, a.H);
@@ -227,21 +232,30 @@ __global__ __launch_bounds__(192) __attribute__((amdgpu_waves_per_eu(3))) void c
       for (int pi = 0; pi < 4; ++pi)
 #pragma unroll
         for (int dj = 0; dj < 4; ++dj) acc[pi][dj] = 0.0f;
+      // operands of channel c+1 are read while channel c's FMAs run (last iteration re-reads channel C-1: no branch)
+      const float* lp = fls + 4 * g + 4;
+      const float* rp = frs + (D + 4 * g - 4 * q - 4);
+      f32x4 L = *reinterpret_cast<const f32x4*>(lp);
+      f32x4 ra = *reinterpret_cast<const f32x4*>(rp), rb = *reinterpret_cast<const f32x4*>(rp + 4);
 #pragma unroll 1
       for (int c = 0; c < ((MODE & 2) ? 0 : C); ++c) {
-        const f32x4 L = *reinterpret_cast<const f32x4*>(fls + c * FLW + 4 * g + 4);
-        const float* rp = frs + c * FRW + (D + 4 * g - 4 * q - 4);
-        const f32x4 ra = *reinterpret_cast<const f32x4*>(rp), rb = *reinterpret_cast<const f32x4*>(rp + 4);
+        const int cn = min(c + 1, C - 1);
+        const f32x4 Ln = *reinterpret_cast<const f32x4*>(lp + cn * FLW);
+        const f32x4 ran = *reinterpret_cast<const f32x4*>(rp + cn * FRW), rbn = *reinterpret_cast<const f32x4*>(rp + cn * FRW + 4);
         const float R[8] = {ra[0], ra[1], ra[2], ra[3], rb[0], rb[1], rb[2], rb[3]};
 #pragma unroll
         for (int pi = 0; pi < 4; ++pi)
 #pragma unroll
           for (int dj = 0; dj < 4; ++dj) acc[pi][dj] = fmaf(L[pi], R[4 + pi - dj], acc[pi][dj]);
+        L = Ln; ra = ran; rb = rbn;
       }
 #pragma unroll
-      for (int pi = 0; pi < 4; ++pi)
-        *reinterpret_cast<f32x4*>(costrow + (1 + 4 * g + pi) * D + 4 * q) =
-            f32x4{acc[pi][0] * invC, acc[pi][1] * invC, acc[pi][2] * invC, acc[pi][3] * invC};
+      for (int pi = 0; pi < 4; ++pi) {
+        float* dst = costrow + (1 + 4 * g + pi) * DS + 4 * q + 1;
+        dst[0] = acc[pi][0] * invC;
+        *reinterpret_cast<f32x2*>(dst + 1) = f32x2{acc[pi][1] * invC, acc[pi][2] * invC};
+        dst[3] = acc[pi][3] * invC;
+      }
     }
     if (tid < 2 * DQ) {                          // halo columns x0 - 1 (side 0) and x0 + TW (side 1)
       const int side = tid / DQ, hq = tid % DQ;
@@ -254,57 +268,101 @@ __global__ __launch_bounds__(192) __attribute__((amdgpu_waves_per_eu(3))) void c
         const float l = fls[c * FLW + pxo];
         const float* rp = frs + c * FRW + roff;
         const f32x4 ra = *reinterpret_cast<const f32x4*>(rp), rb = *reinterpret_cast<const f32x4*>(rp + 4);
-        const float R[8] = {ra[0], ra[1], ra[2], ra[3], rb[0], rb[1], rb[2], rb[3]};
+        const float R[4] = {sh ? ra[1] : ra[0], sh ? ra[2] : ra[1], sh ? ra[3] : ra[2], sh ? rb[0] : ra[3]};
 #pragma unroll
-        for (int dj = 0; dj < 4; ++dj) acc[dj] = fmaf(l, sh ? R[4 - dj] : R[3 - dj], acc[dj]);
+        for (int dj = 0; dj < 4; ++dj) acc[dj] = fmaf(l, R[3 - dj], acc[dj]);
       }
-      *reinterpret_cast<f32x4*>(costrow + (side ? TW + 1 : 0) * D + 4 * hq) =
-          f32x4{acc[0] * invC, acc[1] * invC, acc[2] * invC, acc[3] * invC};
+      float* dst = costrow + (side ? TW + 1 : 0) * DS + 4 * hq + 1;
+      dst[0] = acc[0] * invC;
+      *reinterpret_cast<f32x2*>(dst + 1) = f32x2{acc[1] * invC, acc[2] * invC};
+      dst[3] = acc[3] * invC;
     }
   };
-  // one iteration; (ra, rb) hold cost rows r-2, r-1, rc receives row r
-  auto step = [&](auto out_tag, int r, float (&ra)[6][6], float (&rb)[6][6], float (&rc)[6][6]) {
+  // Weight pairs (w, w) of the taps i = 0 and i = 2 as SCALAR register pairs of their own: the empty asm makes each an
+  // opaque 64-bit value, so the broadcast cannot be folded into an op_sel modifier of the packed FMA
+  f32x2 wp[2][3][3];
+#pragma unroll
+  for (int j = 0; j < 3; ++j)
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      wp[0][j][k] = f32x2{a.w[(0 * 3 + j) * 3 + k], a.w[(0 * 3 + j) * 3 + k]};
+      wp[1][j][k] = f32x2{a.w[(2 * 3 + j) * 3 + k], a.w[(2 * 3 + j) * 3 + k]};
+      asm volatile("" : "+s"(wp[0][j][k]));
+      asm volatile("" : "+s"(wp[1][j][k]));
+    }
+  // one iteration; (ra, rb) hold cost rows r-2, r-1, rc receives row r.  A register row: 6 columns x 3 level pairs
+  auto step = [&](auto out_tag, int r, f32x2 (&ra)[6][3], f32x2 (&rb)[6][3], f32x2 (&rc)[6][3]) {
     constexpr bool OUT = decltype(out_tag)::value;
+    // feature row r+1 is requested first thing (into registers; the stage keeps row r for `produce`), travels during the
+    // whole iteration and is written to the stage at its end: the wait in front of that write allows the four output
+    // stores issued after the loads to be still in flight (vmcnt counts loads and stores together)
+    if (r + 1 <= y1 && !((MODE & 8) && OUT)) load_feat(r + 1);
     produce();
     __syncthreads();
     if (active) {
 #pragma unroll
       for (int col = 0; col < 6; ++col) {
-        const float* p = costrow + (4 * g + col) * D + 4 * q;
+        const float* p = costrow + (4 * g + col) * DS + 4 * q;
         const f32x4 v = *reinterpret_cast<const f32x4*>(p);
-        rc[col][0] = q > 0 ? p[-1] : 0.0f;
-        rc[col][1] = v[0]; rc[col][2] = v[1]; rc[col][3] = v[2]; rc[col][4] = v[3];
-        rc[col][5] = q < DQ - 1 ? p[4] : 0.0f;
+        rc[col][0] = f32x2{v[0], v[1]};
+        rc[col][1] = f32x2{v[2], v[3]};
+        rc[col][2] = *reinterpret_cast<const f32x2*>(p + 4);
       }
     }
-    // feature row r+1 is requested now (the stage still holds row r, which `produce` is done with), travels during the
-    // stencil and is written to the stage behind it: the wait in front of that write allows the four output stores
-    // issued after the loads to be still in flight (vmcnt counts both)
-    if (r + 1 <= y1 && !((MODE & 8) && OUT)) load_feat(r + 1);
     const int y = r - 1;
     if (OUT && active) {
       // the strip's output row as a buffer: pixels beyond the image fall outside the descriptor and are dropped
       const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(
           a.out + (((size_t)n * a.H + y) * a.W + x0) * D, 0, min(TW, a.W - x0) * D * 4, 0x00020000);
+      // outputs (4q, 4q+1) and (4q+2, 4q+3) of a pixel as two accumulator pairs; per (row j, column k): tap i = 0 and tap
+      // i = 2 as packed FMAs on the aligned level pairs, tap i = 1 (odd pairs) as four scalar FMAs - per output the
+      // oracle's order j, k, i.  The four pixels advance together: eight independent chains for the issue slots
+      f32x2 p0[4], p1[4];
+#pragma unroll
+      for (int pi = 0; pi < 4; ++pi) p0[pi] = p1[pi] = f32x2{a.bias, a.bias};
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          const float w1 = a.w[(1 * 3 + j) * 3 + k];
+#pragma unroll
+          for (int pi = 0; pi < 4; ++pi) {
+            const f32x2 (&v)[3] = j == 0 ? ra[pi + k] : (j == 1 ? rb[pi + k] : rc[pi + k]);
+            p0[pi] = __builtin_elementwise_fma(wp[0][j][k], v[0], p0[pi]);
+            p1[pi] = __builtin_elementwise_fma(wp[0][j][k], v[1], p1[pi]);
+          }
+          __builtin_amdgcn_sched_barrier(0);     // keep the eight chains side by side (the scheduler would run them one by one)
+#pragma unroll
+          for (int pi = 0; pi < 4; ++pi) {
+            const f32x2 (&v)[3] = j == 0 ? ra[pi + k] : (j == 1 ? rb[pi + k] : rc[pi + k]);
+            p0[pi][0] = fmaf(w1, v[0][1], p0[pi][0]);
+            p0[pi][1] = fmaf(w1, v[1][0], p0[pi][1]);
+            p1[pi][0] = fmaf(w1, v[1][1], p1[pi][0]);
+            p1[pi][1] = fmaf(w1, v[2][0], p1[pi][1]);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int pi = 0; pi < 4; ++pi) {
+            const f32x2 (&v)[3] = j == 0 ? ra[pi + k] : (j == 1 ? rb[pi + k] : rc[pi + k]);
+            p0[pi] = __builtin_elementwise_fma(wp[1][j][k], v[1], p0[pi]);
+            p1[pi] = __builtin_elementwise_fma(wp[1][j][k], v[2], p1[pi]);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      // all eight chains end HERE: without this use the optimiser sinks the chains of pixels 1..3 behind the branches of
+      // pixel 0's activation / store code and they run one after the other again
+#pragma unroll
+      for (int pi = 0; pi < 4; ++pi) asm volatile("" : "+v"(p0[pi]), "+v"(p1[pi]));
 #pragma unroll
       for (int pi = 0; pi < 4; ++pi) {
-        float acc[4] = {a.bias, a.bias, a.bias, a.bias};
-#pragma unroll
-        for (int j = 0; j < 3; ++j) {
-#pragma unroll
-          for (int k = 0; k < 3; ++k) {
-            const float* vals = j == 0 ? ra[pi + k] : (j == 1 ? rb[pi + k] : rc[pi + k]);
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-#pragma unroll
-              for (int i = 0; i < ((MODE & 4) ? 1 : 3); ++i) acc[e] = fmaf(a.w[(i * 3 + j) * 3 + k], vals[e + i], acc[e]);
-          }
-        }
+        const float acc[4] = {p0[pi][0], p0[pi][1], p1[pi][0], p1[pi][1]};
         {
           f32x4 o;
 #pragma unroll
           for (int e = 0; e < 4; ++e) o[e] = a.act ? acc[e] / (1.0f + a3_expf(-acc[e])) : acc[e];
-          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), orsrc, ((4 * g + pi) * D + 4 * q) * 4, 0, 0);
+          if (MODE & 1) asm volatile("" ::"v"(o));    // tools: the result stays alive, nothing is stored
+          else __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), orsrc, ((4 * g + pi) * D + 4 * q) * 4, 0, 0);
         }
       }
     }
@@ -312,11 +370,15 @@ __global__ __launch_bounds__(192) __attribute__((amdgpu_waves_per_eu(3))) void c
     __syncthreads();
   };
 
-  float r0[6][6], r1[6][6], r2[6][6];
+  f32x2 r0[6][3], r1[6][3], r2[6][3];
 #pragma unroll
   for (int c = 0; c < 6; ++c)
 #pragma unroll
-    for (int e = 0; e < 6; ++e) r0[c][e] = r1[c][e] = r2[c][e] = 0.0f;
+    for (int e = 0; e < 3; ++e) r0[c][e] = r1[c][e] = r2[c][e] = f32x2{0.f, 0.f};
+  for (int e = tid; e < TW + 2; e += NT) {       // the two pad levels of every column
+    costrow[e * DS] = 0.0f;
+    costrow[e * DS + D + 1] = 0.0f;
+  }
   load_feat(y0 - 1);
   store_feat();
   __syncthreads();
@@ -417,7 +479,7 @@ extern "C" int st_costvolume_agg3d(const float* featL_dev, const float* featR_de
   // strip width: TW x D / 16 threads (<= 192) each own a 4 pixel x 4 level tile
   const int TW = D <= 48 ? 64 : (D <= 96 ? 32 : 16);
   const int strips = ceil_div(W, TW);
-  const int lds = ((TW + 2) * D + C * (D + TW + 4) + C * (TW + 8)) * (int)sizeof(float);
+  const int lds = ((TW + 2) * (D + 4) + C * (D + TW + 4) + C * (TW + 8)) * (int)sizeof(float);
   // band count: whole launch rounds over 256 CUs x 4 workgroups (register-bound), two produce-only rows per band
   const long long slots = 256ll * 4;
   int best_b = 1;
@@ -457,9 +519,9 @@ extern "C" int st_costvolume_agg3d(const float* featL_dev, const float* featR_de
         return ST_OK;
       };
       switch (mode) {
+        case 1: return launch(cv_agg3d_kernel<16, 8, 192, true, 1>);
+        case 9: return launch(cv_agg3d_kernel<16, 8, 192, true, 9>);
         case 2: return launch(cv_agg3d_kernel<16, 8, 192, true, 2>);
-        case 4: return launch(cv_agg3d_kernel<16, 8, 192, true, 4>);
-        case 6: return launch(cv_agg3d_kernel<16, 8, 192, true, 6>);
         case 8: return launch(cv_agg3d_kernel<16, 8, 192, true, 8>);
         default: break;
       }

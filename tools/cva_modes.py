@@ -1,7 +1,6 @@
 #!/usr/bin/env python
 """Timing-only ablations of the fused cost-volume + 3-D layer kernel (tools build: ST_LIBRARY=..._ablation.so).
-ST_CVA_MODE bits: 2 no cost FMAs, 4 one stencil tap of three, 8 no feature loads in the output steps.  (A 'no output stores'
-mode is not offered: guarding the store lets the compiler sink most of the stencil into the never-taken branch.)"""
+ST_CVA_MODE bits: 1 no output stores (results kept alive by an empty asm), 2 no cost FMAs, 4 one stencil tap of three, 8 no feature loads in the output steps."""
 import ctypes as C
 import os
 import sys
@@ -21,7 +20,7 @@ gl = torch.randn(n, h, w, c, device=dev)
 gr = torch.randn(n, h, w, c, device=dev)
 vout = torch.empty(n, h, w, d, device=dev)
 w27 = (C.c_float * 27)(*[0.03 * ((i * 7) % 11 - 5) for i in range(27)])
-for mode in (sys.argv[1:] or ['0', '2', '4', '6', '8']):
+for mode in (sys.argv[1:] or ['0', '1', '2', '8', '9']):
     os.environ['ST_CVA_MODE'] = mode
     for _ in range(2):
         check(lib.st_costvolume_agg3d(ptr(gl), ptr(gr), n, h, w, c, c, d, w27, 0.01, 0, ptr(vout), None))
@@ -33,3 +32,13 @@ for mode in (sys.argv[1:] or ['0', '2', '4', '6', '8']):
     e1.record()
     torch.cuda.synchronize()
     print(f'mode {mode}: {e0.elapsed_time(e1) / 4 * 1e3:.1f} us')
+
+vol = torch.empty_like(vout)
+torch.cuda.synchronize()
+e0.record()
+for _ in range(2):
+    check(lib.st_costvolume_softargmin(ptr(gl), ptr(gr), n, h, w, c, c, d, 1.0, ptr(vol), None, None))
+    check(lib.st_volume_agg3d(ptr(vol), ptr(vout), n, h, w, d, w27, 0.01, 0, None))
+e1.record()
+torch.cuda.synchronize()
+print(f'yardstick of this box, two-call form: {e0.elapsed_time(e1) / 2 * 1e3:.1f} us')
