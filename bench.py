@@ -61,6 +61,7 @@ def parse():
                     help='also time the workload with the stereo module in its FULL-RESOLUTION mode (a D=192 x 720 x 1280 volume '
                          'per pair, one 3-D aggregation layer, soft-argmin at image resolution; secondary line, pair 0 checked '
                          'against the CPU oracle: ~1 min of host time)')
+    ap.add_argument('--fullres-contexts', type=int, default=2, help='in-flight contexts of the --fullres-leg')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-test-step', action='store_true',
                     help='skip the second leg through Config.fromfile -> MODELS.build -> model.test_step')
@@ -525,7 +526,8 @@ def fullres_leg(args, inputs, batch_cpu, headline, plan, dev):
     from stereotracking_amd.synthetic import synthetic_state_dict
     try:
         B, D = args.batch, args.max_disp
-        runner = InflightPipelines(2, B, (720, 1280), 0.5, 0.33, 1, stereo=True, max_disp=D, max_det=args.max_det,
+        nctx = max(1, args.fullres_contexts)
+        runner = InflightPipelines(nctx, B, (720, 1280), 0.5, 0.33, 1, stereo=True, max_disp=D, max_det=args.max_det,
                                    agg_layers=0, agg3d_layers=1, full_res=True)
         sd = synthetic_state_dict(runner.param_table(), seed=0)
         g = torch.Generator().manual_seed(3)
@@ -536,7 +538,7 @@ def fullres_leg(args, inputs, batch_cpu, headline, plan, dev):
         for p in runner.pipes:                     # the detector graph is the headline's: reuse its committed plan
             p.det.set_tuning(plan)
         nb = len(inputs)
-        steps, warm = max(4, args.steps // 5), 2
+        steps, warm = max(4 * nctx, args.steps // 5), 2 * nctx
         for i in range(warm):
             runner.submit(*inputs[i % nb])
         runner.synchronize()
@@ -579,7 +581,7 @@ def fullres_leg(args, inputs, batch_cpu, headline, plan, dev):
         ref = torch.from_numpy(ostereo.disparity_fullres(fl, fr, fl.shape[-1], D, 32.0, sd, 1, valid_hw=(720, 1280))[2])[0, 0]
         ad = (disp0 - ref).abs()
         return dict(value=round(v, 3), unit='stereo frame-pairs/s', ms_per_step=round(dt / steps * 1e3, 3), steps=steps,
-                    vs_headline=round(v / headline, 4), inflight_contexts=2,
+                    vs_headline=round(v / headline, 4), inflight_contexts=nctx,
                     volume=dict(levels=D, height=H, width=W, cells_per_pair=D * H * W, bytes_per_pair=int(vol_bytes / B)),
                     stage_ms_per_step_serialized=kern,
                     disparity_vs_oracle_pair0=dict(l1_px=float(ad.mean()), max_abs_px=float(ad.max()),

@@ -302,7 +302,10 @@ class StereoCostVolume(nn.Module):
             f32 = dict(dtype=torch.float32, device=dev)
             self._fr = dict(red=torch.empty(2 * N, Hf, Wf, Cr, **f32), up=torch.empty(2 * N, H, W, Cr, **f32),
                             va=torch.empty(N, H, W, D, **f32), disp=torch.empty(N, H, W, **f32))
-            self._fr['vb'] = torch.empty(N, H, W, D, **f32) if self.agg3d_layers else None
+            # second volume: only where a layer runs volume -> volume (the first layer fused with the cost volume writes
+            # straight into `va`)
+            fused = self.fuse_first_layer and self.lib.st_costvolume_agg3d_supported(Cr, D) == 1
+            self._fr['vb'] = torch.empty(N, H, W, D, **f32) if self.agg3d_layers > (1 if fused else 0) else None
         return self._fr
 
     def _compute_full_res(self, feat, N, Hf, Wf, Cf, ld, valid_hw, disp_postp, cost_out, stream, dev, H, W):
