@@ -413,6 +413,30 @@ def test_costvolume_agg3d_fused_bit_exact(N, H, W, Cc, ld, D, act, cuda):
     assert lib.st_costvolume_agg3d(ptr(gl), ptr(gr), N, H, W, 5, ld, D, w27, bias, act, ptr(out), current_stream()) != 0
 
 
+def test_costvolume_agg3d_fused_equals_two_call_form_at_full_resolution(cuda):
+    """The benched size of the full-resolution mode (736 x 1280 pixels, D = 192, 8 feature channels; 2 pairs here): the fused
+    kernel's volume equals the two-call form's bit for bit over all 362 M cells (80 strips x 8 bands of 92 rows per pair: every
+    band seam, the ragged d > x corner and the image borders at full size), with and without the activation."""
+    lib = _lib.load()
+    N, H, W, Cc, D = 2, 736, 1280, 8, 192
+    g = torch.Generator(device='cpu').manual_seed(5)
+    gl = torch.randn(N, H, W, Cc, generator=g).to(cuda)
+    gr = torch.randn(N, H, W, Cc, generator=g).to(cuda)
+    w = (torch.randn(27, generator=g) * 0.3).tolist()
+    w27 = (C.c_float * 27)(*w)
+    vol = torch.empty(N, H, W, D, device=cuda)
+    ref = torch.empty_like(vol)
+    out = torch.empty_like(vol)
+    check(lib.st_costvolume_softargmin(ptr(gl), ptr(gr), N, H, W, Cc, Cc, D, 1.0, ptr(vol), None, current_stream()))
+    for act in (0, 1):
+        check(lib.st_volume_agg3d(ptr(vol), ptr(ref), N, H, W, D, w27, 0.03125, act, current_stream()))
+        out.fill_(float('nan'))
+        check(lib.st_costvolume_agg3d(ptr(gl), ptr(gr), N, H, W, Cc, Cc, D, w27, 0.03125, act, ptr(out), current_stream()))
+        torch.cuda.synchronize()
+        assert torch.equal(out, ref), act
+    del vol, ref, out
+
+
 @pytest.mark.parametrize('N,Hf,Wf,D', [(1, 3, 37, 192), (2, 2, 45, 128), (1, 5, 13, 112), (1, 1, 70, 144), (1, 2, 33, 176)])
 def test_softargmin_wide_volumes_bit_exact(N, Hf, Wf, D, cuda):
     """st_softargmin on volumes of 112 .. 192 levels (the full-resolution mode): rows held in registers, split over two
