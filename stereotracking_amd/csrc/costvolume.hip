@@ -45,6 +45,54 @@ __device__ __forceinline__ float cv_expf(float x) {  // same polynomial as decod
   return ldexpf(p, (int)n);
 }
 
+// cv_expf on TWO values per instruction (packed fp32, default operand selection only - every constant is an explicit
+// (c, c) scalar register pair): element for element the operations of cv_expf above, in its order, so the
+// results are bit-identical.  For arguments <= 0 (soft-argmin: x = T c - max): the > 88.7 branch cannot be taken.
+struct CvExpPk {
+  f32x2 log2e, nln2hi, ln2lo, c0, c1, c2, c3, c4, c5, one;
+};
+__device__ __forceinline__ f32x2 cv_dup_s(float c) {
+  f32x2 p = {c, c};
+  asm volatile("" : "+s"(p));     // opaque: the broadcast cannot be folded into op_sel
+  return p;
+}
+__device__ __forceinline__ CvExpPk cv_exp_pk_consts() {
+  CvExpPk k;
+  k.log2e = cv_dup_s(1.44269504088896341f); k.nln2hi = cv_dup_s(-0.693359375f); k.ln2lo = cv_dup_s(2.12194440e-4f);
+  k.c0 = cv_dup_s(1.9875691500e-4f); k.c1 = cv_dup_s(1.3981999507e-3f); k.c2 = cv_dup_s(8.3334519073e-3f);
+  k.c3 = cv_dup_s(4.1665795894e-2f); k.c4 = cv_dup_s(1.6666665459e-1f); k.c5 = cv_dup_s(5.0000001201e-1f);
+  k.one = cv_dup_s(1.0f);
+  return k;
+}
+// NB pairs advance stage by stage (a dependent packed FMA pays a wait state; NB independent chains fill it): the
+// scheduling barriers keep the stages apart, the arithmetic per element is cv_expf's.
+template <int NB>
+__device__ __forceinline__ void cv_expf_pk_nonpos(f32x2 (&x)[NB], const CvExpPk& k) {
+  f32x2 n[NB], r[NB], p[NB];
+#define CV_STAGE(body)                       \
+  _Pragma("unroll") for (int b = 0; b < NB; ++b) { body; } \
+  __builtin_amdgcn_sched_barrier(0);
+  CV_STAGE(r[b] = x[b] * k.log2e)
+  CV_STAGE((n[b] = f32x2{rintf(r[b][0]), rintf(r[b][1])}))
+  CV_STAGE(r[b] = __builtin_elementwise_fma(n[b], k.nln2hi, x[b]))
+  CV_STAGE(r[b] = __builtin_elementwise_fma(n[b], k.ln2lo, r[b]))
+  CV_STAGE(p[b] = __builtin_elementwise_fma(k.c0, r[b], k.c1))
+  CV_STAGE(p[b] = __builtin_elementwise_fma(p[b], r[b], k.c2))
+  CV_STAGE(p[b] = __builtin_elementwise_fma(p[b], r[b], k.c3))
+  CV_STAGE(p[b] = __builtin_elementwise_fma(p[b], r[b], k.c4))
+  CV_STAGE(p[b] = __builtin_elementwise_fma(p[b], r[b], k.c5))
+  CV_STAGE((p[b] = __builtin_elementwise_fma(p[b], r[b] * r[b], r[b])))
+  CV_STAGE(p[b] = p[b] + k.one)
+#undef CV_STAGE
+#pragma unroll
+  for (int b = 0; b < NB; ++b) {
+    f32x2 e = {ldexpf(p[b][0], (int)n[b][0]), ldexpf(p[b][1], (int)n[b][1])};
+    if (x[b][0] < -103.0f) e[0] = 0.0f;
+    if (x[b][1] < -103.0f) e[1] = 0.0f;
+    x[b] = e;
+  }
+}
+
 constexpr int CV_TX = 64;     // pixels per workgroup
 constexpr int CV_MAXDG = 64;  // accumulators per lane (D <= 256)
 
@@ -490,13 +538,35 @@ __global__ __launch_bounds__(256) void softargmin_lds_kernel(const float* __rest
     m = fmaxf(m, temperature * v.x); m = fmaxf(m, temperature * v.y);
     m = fmaxf(m, temperature * v.z); m = fmaxf(m, temperature * v.w);
   }
+  // exponentials two per instruction (cv_expf_pk_nonpos: element for element cv_expf), sums in the oracle's order
+  const CvExpPk ek = cv_exp_pk_consts();
+  const f32x2 t2 = cv_dup_s(temperature);
+  f32x2 negm = {-m, -m};
+  asm volatile("" : "+v"(negm));
   float s = 0.f, t = 0.f;
-  for (int k = 0; k < D4; ++k) {
-    const float4 v = *reinterpret_cast<const float4*>(c + 4 * k);
-    const float vv[4] = {v.x, v.y, v.z, v.w};
+  int k = 0;
+  for (; k + 2 <= D4; k += 2) {
+    const f32x4 va = *reinterpret_cast<const f32x4*>(c + 4 * k), vb = *reinterpret_cast<const f32x4*>(c + 4 * k + 4);
+    f32x2 x[4] = {f32x2{va[0], va[1]}, f32x2{va[2], va[3]}, f32x2{vb[0], vb[1]}, f32x2{vb[2], vb[3]}};
+#pragma unroll
+    for (int b = 0; b < 4; ++b) x[b] = t2 * x[b] + negm;
+    cv_expf_pk_nonpos<4>(x, ek);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float e = x[j >> 1][j & 1];
+      s += e;
+      t = fmaf((float)(4 * k + j), e, t);
+    }
+  }
+  if (k < D4) {
+    const f32x4 va = *reinterpret_cast<const f32x4*>(c + 4 * k);
+    f32x2 x[2] = {f32x2{va[0], va[1]}, f32x2{va[2], va[3]}};
+#pragma unroll
+    for (int b = 0; b < 2; ++b) x[b] = t2 * x[b] + negm;
+    cv_expf_pk_nonpos<2>(x, ek);
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const float e = cv_expf(temperature * vv[j] - m);
+      const float e = x[j >> 1][j & 1];
       s += e;
       t = fmaf((float)(4 * k + j), e, t);
     }
@@ -523,9 +593,11 @@ __global__ __launch_bounds__(256) void softargmin_reg_kernel(const float* __rest
   const int sub = lane % K;
   float* tw = tile[wave];
   const long long nwave = (npix + PPW - 1) / PPW;
+  const CvExpPk ek = cv_exp_pk_consts();
+  const f32x2 t2 = cv_dup_s(temperature);
   for (long long wv = (long long)blockIdx.x * 4 + wave; wv < nwave; wv += (long long)gridDim.x * 4) {
     const long long p0 = wv * PPW;
-    float v[DL];
+    f32x2 v2[DL / 2];   // the lane's values as register PAIRS: the scaling and the exponentials run two per instruction
     // chunk ch + 1 is requested from memory BEFORE chunk ch goes through the tile: one round trip in flight behind the
     // LDS transposition of the previous one (a wave has few neighbours here: two waves per SIMD)
     f32x4 xa[4];
@@ -556,8 +628,8 @@ __global__ __launch_bounds__(256) void softargmin_reg_kernel(const float* __rest
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const f32x4 r = *reinterpret_cast<const f32x4*>(tw + lane * 20 + 4 * j);
-        v[ch * 16 + 4 * j + 0] = r[0]; v[ch * 16 + 4 * j + 1] = r[1];
-        v[ch * 16 + 4 * j + 2] = r[2]; v[ch * 16 + 4 * j + 3] = r[3];
+        v2[ch * 8 + 2 * j] = f32x2{r[0], r[1]};
+        v2[ch * 8 + 2 * j + 1] = f32x2{r[2], r[3]};
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();     // the next chunk overwrites the tile: every lane has read its row
@@ -567,12 +639,25 @@ __global__ __launch_bounds__(256) void softargmin_reg_kernel(const float* __rest
         for (int i = 0; i < 4; ++i) xa[i] = xb[i];
       }
     }
+    // T c once (the oracle forms the same product for the maximum and for the exponent), maximum, exp(T c - max)
+#pragma unroll
+    for (int i = 0; i < DL / 2; ++i) v2[i] = t2 * v2[i];
     float m = -__builtin_inff();
 #pragma unroll
-    for (int i = 0; i < DL; ++i) m = fmaxf(m, temperature * v[i]);
+    for (int i = 0; i < DL / 2; ++i) m = fmaxf(fmaxf(m, v2[i][0]), v2[i][1]);
     if (K == 2) m = fmaxf(m, __shfl_xor(m, 1));
+    f32x2 negm = {-m, -m};
+    asm volatile("" : "+v"(negm));
+    constexpr int EB = 4;                    // pairs per batch of the packed exponential (DL / 2 is a multiple of 8)
 #pragma unroll
-    for (int i = 0; i < DL; ++i) v[i] = cv_expf(temperature * v[i] - m);    // this lane's exponentials
+    for (int i = 0; i < DL / 2; i += EB) {   // this lane's exponentials
+      f32x2 xb[EB];
+#pragma unroll
+      for (int b = 0; b < EB; ++b) xb[b] = v2[i + b] + negm;
+      cv_expf_pk_nonpos<EB>(xb, ek);
+#pragma unroll
+      for (int b = 0; b < EB; ++b) v2[i + b] = xb[b];
+    }
     float s = 0.f, t = 0.f;
 #pragma unroll
     for (int k = 0; k < K; ++k) {
@@ -583,8 +668,8 @@ __global__ __launch_bounds__(256) void softargmin_reg_kernel(const float* __rest
       if (sub == k) {
 #pragma unroll
         for (int i = 0; i < DL; ++i) {
-          s += v[i];
-          t = fmaf((float)(k * DL + i), v[i], t);
+          s += v2[i >> 1][i & 1];
+          t = fmaf((float)(k * DL + i), v2[i >> 1][i & 1], t);
         }
       }
     }

@@ -78,3 +78,16 @@ for _ in range(2):
 e1.record()
 torch.cuda.synchronize()
 print(f'two-call form (volume through memory): {e0.elapsed_time(e1) / 2 * 1e3:.1f} us')
+
+# ---- wide soft-argmin (st_softargmin on the D = 192 volume of 8 pairs: 5.8 GB read once)
+disp = torch.empty(n, h, w, device=dev)
+for _ in range(2):
+    check(lib.st_softargmin(ptr(vout), n, h, w, d, 32.0, ptr(disp), None))
+torch.cuda.synchronize()
+e0.record()
+for _ in range(5):
+    check(lib.st_softargmin(ptr(vout), n, h, w, d, 32.0, ptr(disp), None))
+e1.record()
+torch.cuda.synchronize()
+us = e0.elapsed_time(e1) / 5 * 1e3
+print(f'soft-argmin (8 x 736 x 1280 x 192): {us:.1f} us, {vout.numel() * 4 / us / 1e6:.2f} TB/s = {vout.numel() * 4 / us / 8e6:.2f} of 8 TB/s')
