@@ -413,6 +413,31 @@ def test_costvolume_agg3d_fused_bit_exact(N, H, W, Cc, ld, D, act, cuda):
     assert lib.st_costvolume_agg3d(ptr(gl), ptr(gr), N, H, W, 5, ld, D, w27, bias, act, ptr(out), current_stream()) != 0
 
 
+def test_costvolume_agg3d_fused_equals_two_call_form_on_random_shapes(cuda):
+    """Seeded sweep over 40 shapes (every D multiple of 4 up to 192, widths below / across / beyond a strip, heights from 1 row,
+    C in {4, 8, 16} with and without padding channels, both activations): the fused kernel equals the two-call form bit for
+    bit (which the tests above pin to the oracle)."""
+    lib = _lib.load()
+    rng = np.random.RandomState(20260)
+    for it in range(40):
+        D = 4 * int(rng.randint(1, 49))
+        Cc = int(rng.choice([4, 8, 16]))
+        ld = Cc + 4 * int(rng.randint(0, 3))
+        N, H, W = int(rng.randint(1, 4)), int(rng.randint(1, 30)), int(rng.randint(1, 210))
+        act = int(rng.randint(0, 2))
+        fl = torch.from_numpy(rng.normal(0, 1.0, (N, H, W, ld)).astype(np.float32)).to(cuda)
+        fr = torch.from_numpy(rng.normal(0, 1.0, (N, H, W, ld)).astype(np.float32)).to(cuda)
+        w27 = (C.c_float * 27)(*rng.normal(0, 0.4, 27).astype(np.float32).tolist())
+        vol = torch.empty(N, H, W, D, device=cuda)
+        ref = torch.empty_like(vol)
+        out = torch.full_like(vol, float('nan'))
+        check(lib.st_costvolume_softargmin(ptr(fl), ptr(fr), N, H, W, Cc, ld, D, 1.0, ptr(vol), None, current_stream()))
+        check(lib.st_volume_agg3d(ptr(vol), ptr(ref), N, H, W, D, w27, 0.25, act, current_stream()))
+        check(lib.st_costvolume_agg3d(ptr(fl), ptr(fr), N, H, W, Cc, ld, D, w27, 0.25, act, ptr(out), current_stream()))
+        torch.cuda.synchronize()
+        assert torch.equal(out, ref), (it, N, H, W, Cc, ld, D, act)
+
+
 def test_costvolume_agg3d_fused_equals_two_call_form_at_full_resolution(cuda):
     """The benched size of the full-resolution mode (736 x 1280 pixels, D = 192, 8 feature channels; 2 pairs here): the fused
     kernel's volume equals the two-call form's bit for bit over all 362 M cells (80 strips x 8 bands of 92 rows per pair: every
