@@ -138,16 +138,22 @@ __global__ __launch_bounds__(256) void agg3d_kernel(const Agg3dArgs a) {
 // full-resolution sizing the materialised form writes 6.3 GB and reads them back, per 8 pairs).  Arithmetic per cell
 // is that of costvolume.hip followed by the kernel above, fmaf for fmaf (oracle_costvolume, then oracle_agg3d).
 //
-// A workgroup owns a strip of TW pixel columns x all D levels and walks down a band of rows.  Per row r:
-//   produce   cost row r for columns x0-1 .. x0+TW from the staged feature rows (LDS, channel-major so that four
+// A workgroup (192 threads) owns a strip of TW pixel columns x all D levels and walks down a band of rows.  Per row r:
+//   loads     feature row r+1 is requested from memory first thing (buffer loads with a per-ROW descriptor: uniform base,
+//             one 32-bit offset per thread, pixels outside the image by the range check);
+//   produce   cost row r for columns x0-1 .. x0+TW from the staged feature row r (LDS, channel-major so that four
 //             neighbouring pixels of one channel are one 16-byte read): a thread computes a 4 pixel x 4 level tile (7
-//             right-image pixels feed its 16 cells), 2 * D/4 threads add the two halo columns;
-//   (barrier) every thread takes the 6 columns x 6 levels it needs of the new cost row into registers;
+//             right-image pixels feed its 16 cells; channel c+1's operands are read while channel c's FMAs run), 2 * D/4
+//             threads add the two halo columns; the row goes to ONE LDS row, stored shifted by a level with zero pads;
+//   (barrier) every thread takes the 6 columns x 6 levels it needs of the new cost row into registers, as level PAIRS;
 //   stencil   output row r-1 from rows r-2, r-1 (kept in registers from the two iterations before) and r: 4 pixels x 4
-//             levels per thread, 16-byte stores; the feature row r+1 (requested from memory before `produce`) goes
-//             into the stage;
+//             levels per thread = eight accumulator pairs side by side; disparity taps 0 and 2 as packed FMAs on aligned
+//             pairs (default operand selection, (w, w) in scalar register pairs), tap 1 scalar; 16-byte stores;
+//   stage     feature row r+1 goes from registers into the stage (the wait in front allows the four stores to be in
+//             flight: `vmcnt` counts loads and stores together);
 //   (barrier)
-// The three register rows rotate by name (the loop body is instantiated three times), not by copies.
+// The three register rows rotate by name (the loop body is instantiated three times), not by copies; the first two
+// iterations of a band (rows y0-1, y0) are instantiated without the output part.
 struct CvAggArgs {
   const float* fl;
   const float* fr;
