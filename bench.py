@@ -503,7 +503,7 @@ def agg3d_leg(args, inputs, batch_cpu, headline, dev):
         ad = (disp0 - ref).abs()
         return dict(value=round(v, 3), unit='stereo frame-pairs/s', ms_per_step=round(dt / args.steps * 1e3, 4),
                     vs_headline=round(v / headline, 4), agg3d_layers=1, agg_layers=args.agg_layers,
-                    agg3d_kernel=dict(kernel='st::agg3d_kernel', volume=[args.batch, Hf, Wf, D], avg_launch_us=round(us, 2),
+                    agg3d_kernel=dict(kernel='st::vol_agg3d_kernel', volume=[args.batch, Hf, Wf, D], avg_launch_us=round(us, 2),
                                       bytes_per_launch=int(nbytes), bound='hbm', peak=8000.0, unit='GB/s',
                                       achieved=round(nbytes / (us * 1e-6) / 1e9, 1), frac=round(nbytes / (us * 1e-6) / 8e12, 4)),
                     disparity_vs_oracle_pair0=dict(l1_px=float(ad.mean()), max_abs_px=float(ad.max()),

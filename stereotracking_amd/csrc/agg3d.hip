@@ -4,13 +4,17 @@
 // oracle/st_oracle.c::oracle_agg3d and this kernel is BIT-EXACT against it (same fmaf order: rows j, columns k,
 // disparity taps i; padded taps contribute fmaf(w, 0, acc); SiLU through the oracle's exp polynomial).
 //
-// HBM-bound stencil (27 FMAs per cell against 8 bytes of traffic), written as a STREAMING stencil: one workgroup owns a
-// column strip of TW pixels x all D disparities and walks down a band of RY rows, keeping a ring of four pixel rows
-// ((TW + 2) x D floats each) in LDS - rows y-1, y, y+1 feed output row y while row y+2 travels from memory through
-// registers into the fourth slot (one barrier per row).  A volume element is fetched (TW + 2) / TW x (RY + 2) / RY
-// times per layer (1.2x at the bench volume; the round-4 kernel staged three rows per output row: 3.1x).  A thread
-// produces 4 consecutive disparities of one pixel from 9 aligned 16-byte LDS reads + the two neighbours across the quad
-// borders, and stores 16 bytes.
+// Three kernels, one arithmetic:
+//   vol_agg3d_kernel   volume -> volume layer (st_volume_agg3d): a workgroup owns a column strip of TW pixels x all D
+//                      disparities and walks down a band of rows; the two rows above the current one live in REGISTERS
+//                      (as level pairs), the current one passes through a single LDS row; the stencil's outer taps run on
+//                      packed-fp32 FMAs with default operand selection.  A volume element is fetched (TW + 2) / TW x
+//                      (RY + 2) / RY times per layer.
+//   cv_agg3d_kernel    the same with the row computed from the feature maps instead of read (st_costvolume_agg3d: cost
+//                      volume + first layer, the volume between them never reaches memory).
+//   agg3d_kernel       the first streaming form (a ring of four rows in LDS, every tap an LDS read): tools build only
+//                      (ST_A3_RING), the yardstick the register form was measured against (0.34 -> 0.47 of 8 TB/s at
+//                      D = 192).
 #include <algorithm>
 #include <cstdlib>
 #include <type_traits>
@@ -52,7 +56,10 @@ struct Agg3dArgs {
   int act;
 };
 
-// TW: pixels per strip; NST: float4 staging registers per thread = ceil((TW + 2) * (D / 4) / 256)
+// (tools build) streaming stencil with a ring of four pixel rows ((TW + 2) x D floats each) in LDS - rows y-1, y, y+1 feed
+// output row y while row y+2 travels from memory through registers into the fourth slot (one barrier per row); a thread
+// produces 4 consecutive disparities of one pixel from 9 aligned 16-byte LDS reads + the two neighbours across the quad
+// borders.  TW: pixels per strip; NST: float4 staging registers per thread = ceil((TW + 2) * (D / 4) / 256)
 template <int TW, int NST>
 __global__ __launch_bounds__(256) void agg3d_kernel(const Agg3dArgs a) {
   extern __shared__ float4 a3_smem4[];
@@ -163,6 +170,79 @@ struct CvAggArgs {
   float bias;
   int act;
 };
+
+
+// One output row of the 3x3x3 stencil from three register rows (6 columns x 3 level pairs each: levels 4q-1 .. 4q+4 of the
+// columns px-1 .. px+4 of a thread's four pixels): outputs (4q, 4q+1) and (4q+2, 4q+3) of a pixel as two accumulator pairs;
+// per (row j, column k): tap i = 0 and tap i = 2 as packed FMAs on the aligned level pairs (default operand selection; wp =
+// the (w, w) pairs of those taps), tap i = 1 (odd pairs) as four scalar FMAs - per output the oracle's order j, k, i.  The
+// four pixels advance together: eight independent chains for the issue slots.  16-byte stores through `orsrc` (pixels
+// beyond the descriptor are dropped).  NOSTORE: tools only (the results stay alive, nothing is stored).
+template <bool NOSTORE>
+__device__ __forceinline__ void a3_stencil_row(const f32x2 (&ra)[6][3], const f32x2 (&rb)[6][3], const f32x2 (&rc)[6][3],
+                                               const f32x2 (&wp)[2][3][3], const float (&w)[27], float bias, int act,
+                                               __amdgpu_buffer_rsrc_t orsrc, int voff0, int pxbytes) {
+  f32x2 p0[4], p1[4];
+#pragma unroll
+  for (int pi = 0; pi < 4; ++pi) p0[pi] = p1[pi] = f32x2{bias, bias};
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const float w1 = w[(1 * 3 + j) * 3 + k];
+#pragma unroll
+      for (int pi = 0; pi < 4; ++pi) {
+        const f32x2 (&v)[3] = j == 0 ? ra[pi + k] : (j == 1 ? rb[pi + k] : rc[pi + k]);
+        p0[pi] = __builtin_elementwise_fma(wp[0][j][k], v[0], p0[pi]);
+        p1[pi] = __builtin_elementwise_fma(wp[0][j][k], v[1], p1[pi]);
+      }
+      __builtin_amdgcn_sched_barrier(0);     // keep the eight chains side by side (the scheduler would run them one by one)
+#pragma unroll
+      for (int pi = 0; pi < 4; ++pi) {
+        const f32x2 (&v)[3] = j == 0 ? ra[pi + k] : (j == 1 ? rb[pi + k] : rc[pi + k]);
+        p0[pi][0] = fmaf(w1, v[0][1], p0[pi][0]);
+        p0[pi][1] = fmaf(w1, v[1][0], p0[pi][1]);
+        p1[pi][0] = fmaf(w1, v[1][1], p1[pi][0]);
+        p1[pi][1] = fmaf(w1, v[2][0], p1[pi][1]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int pi = 0; pi < 4; ++pi) {
+        const f32x2 (&v)[3] = j == 0 ? ra[pi + k] : (j == 1 ? rb[pi + k] : rc[pi + k]);
+        p0[pi] = __builtin_elementwise_fma(wp[1][j][k], v[1], p0[pi]);
+        p1[pi] = __builtin_elementwise_fma(wp[1][j][k], v[2], p1[pi]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  // all eight chains end HERE: without this use the optimiser sinks the chains of pixels 1..3 behind the branches of
+  // pixel 0's activation / store code and they run one after the other again
+#pragma unroll
+  for (int pi = 0; pi < 4; ++pi) asm volatile("" : "+v"(p0[pi]), "+v"(p1[pi]));
+#pragma unroll
+  for (int pi = 0; pi < 4; ++pi) {
+    const float acc[4] = {p0[pi][0], p0[pi][1], p1[pi][0], p1[pi][1]};
+    f32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = act ? acc[e] / (1.0f + a3_expf(-acc[e])) : acc[e];
+    if (NOSTORE) asm volatile("" ::"v"(o));
+    else __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), orsrc, voff0 + pi * pxbytes, 0, 0);
+  }
+}
+
+// the (w, w) pairs of the taps i = 0 and i = 2 as SCALAR register pairs of their own: the empty asm makes each an opaque
+// 64-bit value, so the broadcast cannot be folded into an op_sel modifier of the packed FMA
+__device__ __forceinline__ void a3_weight_pairs(const float (&w)[27], f32x2 (&wp)[2][3][3]) {
+#pragma unroll
+  for (int j = 0; j < 3; ++j)
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      wp[0][j][k] = f32x2{w[(0 * 3 + j) * 3 + k], w[(0 * 3 + j) * 3 + k]};
+      wp[1][j][k] = f32x2{w[(2 * 3 + j) * 3 + k], w[(2 * 3 + j) * 3 + k]};
+      asm volatile("" : "+s"(wp[0][j][k]));
+      asm volatile("" : "+s"(wp[1][j][k]));
+    }
+}
 
 // DFIX: D == DMAX, known at compile time (every offset an immediate)
 template <int TW, int C, int DMAX, bool DFIX, int MODE = 0>   // MODE: timing-only ablations of the tools build (0 in the product)
@@ -284,18 +364,8 @@ __global__ __launch_bounds__(192) __attribute__((amdgpu_waves_per_eu(3))) void c
       dst[3] = acc[3] * invC;
     }
   };
-  // Weight pairs (w, w) of the taps i = 0 and i = 2 as SCALAR register pairs of their own: the empty asm makes each an
-  // opaque 64-bit value, so the broadcast cannot be folded into an op_sel modifier of the packed FMA
   f32x2 wp[2][3][3];
-#pragma unroll
-  for (int j = 0; j < 3; ++j)
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-      wp[0][j][k] = f32x2{a.w[(0 * 3 + j) * 3 + k], a.w[(0 * 3 + j) * 3 + k]};
-      wp[1][j][k] = f32x2{a.w[(2 * 3 + j) * 3 + k], a.w[(2 * 3 + j) * 3 + k]};
-      asm volatile("" : "+s"(wp[0][j][k]));
-      asm volatile("" : "+s"(wp[1][j][k]));
-    }
+  a3_weight_pairs(a.w, wp);
   // one iteration; (ra, rb) hold cost rows r-2, r-1, rc receives row r.  A register row: 6 columns x 3 level pairs
   auto step = [&](auto out_tag, int r, f32x2 (&ra)[6][3], f32x2 (&rb)[6][3], f32x2 (&rc)[6][3]) {
     constexpr bool OUT = decltype(out_tag)::value;
@@ -320,57 +390,7 @@ __global__ __launch_bounds__(192) __attribute__((amdgpu_waves_per_eu(3))) void c
       // the strip's output row as a buffer: pixels beyond the image fall outside the descriptor and are dropped
       const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(
           a.out + (((size_t)n * a.H + y) * a.W + x0) * D, 0, min(TW, a.W - x0) * D * 4, 0x00020000);
-      // outputs (4q, 4q+1) and (4q+2, 4q+3) of a pixel as two accumulator pairs; per (row j, column k): tap i = 0 and tap
-      // i = 2 as packed FMAs on the aligned level pairs, tap i = 1 (odd pairs) as four scalar FMAs - per output the
-      // oracle's order j, k, i.  The four pixels advance together: eight independent chains for the issue slots
-      f32x2 p0[4], p1[4];
-#pragma unroll
-      for (int pi = 0; pi < 4; ++pi) p0[pi] = p1[pi] = f32x2{a.bias, a.bias};
-#pragma unroll
-      for (int j = 0; j < 3; ++j) {
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-          const float w1 = a.w[(1 * 3 + j) * 3 + k];
-#pragma unroll
-          for (int pi = 0; pi < 4; ++pi) {
-            const f32x2 (&v)[3] = j == 0 ? ra[pi + k] : (j == 1 ? rb[pi + k] : rc[pi + k]);
-            p0[pi] = __builtin_elementwise_fma(wp[0][j][k], v[0], p0[pi]);
-            p1[pi] = __builtin_elementwise_fma(wp[0][j][k], v[1], p1[pi]);
-          }
-          __builtin_amdgcn_sched_barrier(0);     // keep the eight chains side by side (the scheduler would run them one by one)
-#pragma unroll
-          for (int pi = 0; pi < 4; ++pi) {
-            const f32x2 (&v)[3] = j == 0 ? ra[pi + k] : (j == 1 ? rb[pi + k] : rc[pi + k]);
-            p0[pi][0] = fmaf(w1, v[0][1], p0[pi][0]);
-            p0[pi][1] = fmaf(w1, v[1][0], p0[pi][1]);
-            p1[pi][0] = fmaf(w1, v[1][1], p1[pi][0]);
-            p1[pi][1] = fmaf(w1, v[2][0], p1[pi][1]);
-          }
-          __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-          for (int pi = 0; pi < 4; ++pi) {
-            const f32x2 (&v)[3] = j == 0 ? ra[pi + k] : (j == 1 ? rb[pi + k] : rc[pi + k]);
-            p0[pi] = __builtin_elementwise_fma(wp[1][j][k], v[1], p0[pi]);
-            p1[pi] = __builtin_elementwise_fma(wp[1][j][k], v[2], p1[pi]);
-          }
-          __builtin_amdgcn_sched_barrier(0);
-        }
-      }
-      // all eight chains end HERE: without this use the optimiser sinks the chains of pixels 1..3 behind the branches of
-      // pixel 0's activation / store code and they run one after the other again
-#pragma unroll
-      for (int pi = 0; pi < 4; ++pi) asm volatile("" : "+v"(p0[pi]), "+v"(p1[pi]));
-#pragma unroll
-      for (int pi = 0; pi < 4; ++pi) {
-        const float acc[4] = {p0[pi][0], p0[pi][1], p1[pi][0], p1[pi][1]};
-        {
-          f32x4 o;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) o[e] = a.act ? acc[e] / (1.0f + a3_expf(-acc[e])) : acc[e];
-          if (MODE & 1) asm volatile("" ::"v"(o));    // tools: the result stays alive, nothing is stored
-          else __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), orsrc, ((4 * g + pi) * D + 4 * q) * 4, 0, 0);
-        }
-      }
+      a3_stencil_row<(MODE & 1) != 0>(ra, rb, rc, wp, a.w, a.bias, a.act, orsrc, ((4 * g) * D + 4 * q) * 4, D * 4);
     }
     if (r + 1 <= y1) store_feat();
     __syncthreads();
@@ -401,6 +421,123 @@ __global__ __launch_bounds__(192) __attribute__((amdgpu_waves_per_eu(3))) void c
   }
 }
 
+
+// ---- volume -> volume layer on the same structure (st_volume_agg3d) --------------------------------------------------------
+// The kernel above with the cost row read from the input volume instead of computed: 18 / 34 / 66 columns x D levels of
+// row r+1 are requested (buffer loads, per-row descriptor: columns left / right of the image read as zero) right after the
+// registers took row r, in front of the output stores, and go into the LDS row at the top of the next iteration.  One LDS
+// row (14 KB) instead of the streaming kernel's ring of four (55 KB): three waves per SIMD instead of two; a volume element
+// is fetched (TW + 2) / TW x (RY + 2) / RY times.
+template <int TW, int DMAX, bool DFIX>
+__global__ __launch_bounds__(192) __attribute__((amdgpu_waves_per_eu(3))) void vol_agg3d_kernel(const Agg3dArgs a) {
+  constexpr int NT = 192, NG = TW / 4;
+  constexpr int NV = ((TW + 2) * (DMAX / 4) + NT - 1) / NT;
+  extern __shared__ float4 a3_smem4[];
+  float* costrow = reinterpret_cast<float*>(a3_smem4);      // [TW + 2][DS], shifted by one level, zero pads (see above)
+  const int D = DFIX ? DMAX : a.D, DQ = D >> 2, DS = D + 4;
+  const int x0 = blockIdx.x * TW, y0 = blockIdx.y * a.RY, n = blockIdx.z;
+  const int y1 = min(y0 + a.RY, a.Hf);
+  const int tid = threadIdx.x;
+  const int q = tid % DQ, g = tid / DQ;
+  const bool active = (DFIX && TW * DMAX / 16 == NT) ? true : g < NG;
+  const int nitem = (TW + 2) * DQ;
+  // float4 i of a thread: quad e % DQ of column e / DQ (e = tid + NT i); byte offset in the image row: a column left of the
+  // image is negative (= huge unsigned), one right of it beyond the row - outside the descriptor either way
+  // (D fixed at compile time: NT is a multiple of D / 4, so float4 i sits NT / DQ columns right of float4 0 - one offset
+  // register instead of NV)
+  constexpr bool STEP = DFIX && NT % (DMAX / 4) == 0;
+  constexpr int CSTEP = STEP ? NT / (DMAX / 4) : 0;
+  int voff[STEP ? 1 : NV], ldst[STEP ? 1 : NV];
+#pragma unroll
+  for (int i = 0; i < (STEP ? 1 : NV); ++i) {
+    const int e = tid + NT * i, col = e / DQ, qq = e - col * DQ;
+    voff[i] = (STEP || e < nitem) ? ((x0 - 1 + col) * D + 4 * qq) * 4 : 0x7fffffff;
+    ldst[i] = (STEP || e < nitem) ? col * DS + 4 * qq + 1 : -1;
+  }
+  auto voff_of = [&](int i) { return STEP ? (tid + NT * i < nitem ? voff[0] + i * CSTEP * D * 4 : 0x7fffffff) : voff[i]; };
+  auto ldst_of = [&](int i) { return STEP ? (tid + NT * i < nitem ? ldst[0] + i * CSTEP * DS : -1) : ldst[i]; };
+  f32x4 vst[NV];
+  const int rowbytes = a.Wf * D * 4;
+  auto load_vol = [&](int gy) {                  // row gy of the input volume -> registers (zero outside the image)
+    if (gy < 0 || gy >= a.Hf) {                  // uniform
+#pragma unroll
+      for (int i = 0; i < NV; ++i) vst[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+      return;
+    }
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(a.in + ((size_t)n * a.Hf + gy) * a.Wf * D), 0, rowbytes, 0x00020000);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) vst[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff_of(i), 0, 0));
+  };
+  auto store_vol = [&]() {                       // registers -> the LDS row (level d at float d + 1)
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+      if (ldst_of(i) >= 0) {
+        float* dst = costrow + ldst_of(i);
+        dst[0] = vst[i][0];
+        *reinterpret_cast<f32x2*>(dst + 1) = f32x2{vst[i][1], vst[i][2]};
+        dst[3] = vst[i][3];
+      }
+  };
+  f32x2 wp[2][3][3];
+  a3_weight_pairs(a.w, wp);
+  const __amdgpu_buffer_rsrc_t nul = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, 0, 0x00020000);
+  auto step = [&](auto out_tag, int r, f32x2 (&ra)[6][3], f32x2 (&rb)[6][3], f32x2 (&rc)[6][3]) {
+    constexpr bool OUT = decltype(out_tag)::value;
+    store_vol();                                 // row r: requested one iteration ago, in front of that iteration's stores
+    __syncthreads();
+    if (active) {
+#pragma unroll
+      for (int col = 0; col < 6; ++col) {
+        const float* p = costrow + (4 * g + col) * DS + 4 * q;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(p);
+        rc[col][0] = f32x2{v[0], v[1]};
+        rc[col][1] = f32x2{v[2], v[3]};
+        rc[col][2] = *reinterpret_cast<const f32x2*>(p + 4);
+      }
+    }
+    if (r + 1 <= y1) load_vol(r + 1);
+    if (OUT) {
+      if (active) {
+        const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(
+            a.out + (((size_t)n * a.Hf + (r - 1)) * a.Wf + x0) * D, 0, min(TW, a.Wf - x0) * D * 4, 0x00020000);
+        a3_stencil_row<false>(ra, rb, rc, wp, a.w, a.bias, a.act, orsrc, ((4 * g) * D + 4 * q) * 4, D * 4);
+      }
+    } else {
+      // the two fill iterations issue four stores as well (empty descriptor: dropped by the range check), so that every
+      // path into the loop has the same loads-then-four-stores history and the wait for the loads stays vmcnt(4)
+#pragma unroll
+      for (int pi = 0; pi < 4; ++pi)
+        __builtin_amdgcn_raw_buffer_store_b128(u32x4{0u, 0u, 0u, 0u}, nul, ((4 * g + pi) * D + 4 * q) * 4, 0, 0);
+    }
+    __syncthreads();
+  };
+  f32x2 r0[6][3], r1[6][3], r2[6][3];
+#pragma unroll
+  for (int c = 0; c < 6; ++c)
+#pragma unroll
+    for (int e = 0; e < 3; ++e) r0[c][e] = r1[c][e] = r2[c][e] = f32x2{0.f, 0.f};
+  for (int e = tid; e < TW + 2; e += NT) {       // the two pad levels of every column
+    costrow[e * DS] = 0.0f;
+    costrow[e * DS + D + 1] = 0.0f;
+  }
+  load_vol(y0 - 1);
+#pragma unroll
+  for (int pi = 0; pi < 4; ++pi)
+    __builtin_amdgcn_raw_buffer_store_b128(u32x4{0u, 0u, 0u, 0u}, nul, ((4 * g + pi) * D + 4 * q) * 4, 0, 0);
+  const std::false_type fill{};
+  const std::true_type emit{};
+  step(fill, y0 - 1, r0, r1, r2);
+  step(fill, y0, r1, r2, r0);
+  for (int r = y0 + 1; r <= y1; r += 3) {
+    step(emit, r, r2, r0, r1);
+    if (r + 1 > y1) break;
+    step(emit, r + 1, r0, r1, r2);
+    if (r + 2 > y1) break;
+    step(emit, r + 2, r1, r2, r0);
+  }
+}
+
 }  // namespace
 }  // namespace st
 
@@ -417,10 +554,48 @@ extern "C" int st_volume_agg3d(const float* vol_in_dev, float* vol_out_dev, int 
   a.in = vol_in_dev; a.out = vol_out_dev; a.N = N; a.Hf = Hf; a.Wf = Wf; a.D = D;
   for (int i = 0; i < 27; ++i) a.w[i] = weight27_host[i];
   a.bias = bias; a.act = act;
-  // strip width by LDS budget (4 rows x (TW + 2) x D floats): 64 pixels up to 48 levels (51 KB), 32 up to 96 (52 KB),
-  // 16 beyond (55 KB at D = 192) - two to three workgroups per CU in every case
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
   const int TW = D <= 48 ? 64 : (D <= 96 ? 32 : 16);
   const int strips = ceil_div(Wf, TW);
+#ifdef ST_ABLATION
+  const bool ring = getenv("ST_A3_RING") != nullptr;   // tools: the streaming kernel with the LDS ring of four rows
+#else
+  const bool ring = false;
+#endif
+  if (!ring) {
+    // register-carried rows, one LDS row: TW x D / 16 threads (<= 192) own 4 pixel x 4 level tiles
+    const int lds = (TW + 2) * (D + 4) * (int)sizeof(float);
+    const long long slots = 256ll * 4;
+    int best_b = 1;
+    double best_e = -1.0;
+    for (int b = 1; b <= 64 && ceil_div(Hf, b) >= 4; ++b) {
+      const int ry = ceil_div(Hf, b), nb = ceil_div(Hf, ry);
+      const long long wgs = (long long)N * strips * nb;
+      const double fill = (double)wgs / (double)(ceil_div((int)std::min<long long>(wgs, 1 << 30), (int)slots) * slots);
+      const double e = fill * ry / (ry + 2.0);
+      if (e > best_e + 1e-9) { best_e = e; best_b = b; }
+    }
+    a.RY = std::min(Hf, ceil_div(Hf, best_b));
+    const int bands = ceil_div(Hf, a.RY);
+    ST_REQUIRE(bands < 65536, "st_volume_agg3d: grid too large");
+    const dim3 grid((unsigned)strips, (unsigned)bands, (unsigned)N);
+#define ST_VA3_LAUNCH(TWV, DMAXV)                                                                    \
+  do {                                                                                               \
+    auto kern = D == DMAXV ? vol_agg3d_kernel<TWV, DMAXV, true> : vol_agg3d_kernel<TWV, DMAXV, false>; \
+    static int lds_set = 0;                                                                          \
+    ST_ENSURE_DYNAMIC_LDS(kern, lds, lds_set);                                                       \
+    hipLaunchKernelGGL(kern, grid, dim3(192), lds, stream, a);                                       \
+  } while (0)
+    if (TW == 64) ST_VA3_LAUNCH(64, 48);
+    else if (TW == 32) ST_VA3_LAUNCH(32, 96);
+    else ST_VA3_LAUNCH(16, 192);
+#undef ST_VA3_LAUNCH
+    ST_CHECK_HIP(hipGetLastError());
+    return ST_OK;
+  }
+#ifdef ST_ABLATION
+  // strip width by LDS budget (4 rows x (TW + 2) x D floats): 64 pixels up to 48 levels (51 KB), 32 up to 96 (52 KB),
+  // 16 beyond (55 KB at D = 192) - two to three workgroups per CU in every case
   // Band height.  A workgroup's prologue (three rows) and its halo rows are overhead per band, a half-empty last launch
   // round is overhead per launch: pick the band count b (rows RY = ceil(Hf / b) >= 4) that maximises
   // (workgroups / slots rounded up to whole rounds) x RY / (RY + 3), slots = 256 CUs x workgroups per CU by LDS.
@@ -440,7 +615,6 @@ extern "C" int st_volume_agg3d(const float* vol_in_dev, float* vol_out_dev, int 
   const int bands = ceil_div(Hf, RY);
   ST_REQUIRE(bands < 65536, "st_volume_agg3d: grid too large");
   const dim3 grid((unsigned)strips, (unsigned)bands, (unsigned)N);
-  hipStream_t stream = static_cast<hipStream_t>(stream_);
 #define ST_A3_LAUNCH(TWV, NSTV)                                                                      \
   do {                                                                                               \
     auto kern = agg3d_kernel<TWV, NSTV>;                                                             \
@@ -458,6 +632,7 @@ extern "C" int st_volume_agg3d(const float* vol_in_dev, float* vol_out_dev, int 
   }
 #undef ST_A3_LAUNCH
   ST_CHECK_HIP(hipGetLastError());
+#endif
   return ST_OK;
 }
 
