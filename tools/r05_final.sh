@@ -14,3 +14,11 @@ print('headline', d['value'], d['ms_per_step'], 'sustained', d['sustained'], 'fr
 print('test_step', d['test_step']['value'], d['test_step']['primed_loop']['value'], 'cpu', d['cpu_baseline']['value'], d['cpu_baseline']['value_1_thread'])
 print('agg3d', d['secondary_agg3d'].get('value'), 'fullres', d['secondary_full_resolution'].get('value'))
 PY
+# stereo kernels on their own (product library), and the LDS-ring 3-D kernel of the tools build as yardstick when it is there
+python tools/cv_bench.py 20 > gpurun_out/r05/cv_bench_final.txt 2>&1
+L=$PWD/stereotracking_amd/lib/libstereotrack_hip_ablation.so
+if [ -f $L ]; then
+  echo "--- tools build, ST_A3_RING=1: the first streaming 3-D kernel (ring of four rows in LDS)" >> gpurun_out/r05/cv_bench_final.txt
+  ST_A3_RING=1 ST_LIBRARY=$L python tools/cv_bench.py 20 2>&1 | grep "^agg3d\|two-call" >> gpurun_out/r05/cv_bench_final.txt
+fi
+grep -v amdgpu.ids gpurun_out/r05/cv_bench_final.txt
