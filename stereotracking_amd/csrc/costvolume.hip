@@ -574,7 +574,8 @@ __global__ __launch_bounds__(256) void softargmin_lds_kernel(const float* __rest
   out_disp[p0 + threadIdx.x] = t / s;
 }
 
-// WIDE volumes (D >= 112: the full-resolution mode's 192 levels).  The LDS kernel above keeps a pixel's whole row in
+// Volumes of 16 .. 192 levels in steps of 16 (the benched 48, the full-resolution mode's 192).  The LDS kernel above (other
+// level counts) keeps a pixel's whole row in
 // LDS (784 B at D = 192: 64 pixels = one wave per 50 KB, three waves per CU - measured 5.8 ms for the 5.8 GB volume of 8
 // pairs, 0.12 of 8 TB/s).  Here the row lives in REGISTERS, split over K = 2 neighbouring lanes when D / 16 is even (96
 // registers per lane at D = 192): a wave owns 64 / K pixels and brings their rows in through a private 5 KB LDS tile, 16
@@ -873,15 +874,21 @@ extern "C" int st_softargmin(const float* cost_dev, int N, int Hf, int Wf, int D
   ST_REQUIRE(cost_dev && out_disp_dev && N > 0 && Hf > 0 && Wf > 0 && D > 0, "st_softargmin: bad argument");
   const long long npix = (long long)N * Hf * Wf;
   hipStream_t stream = static_cast<hipStream_t>(stream_);
-  if (D % 16 == 0 && D >= 112 && D <= 192 && (reinterpret_cast<uintptr_t>(cost_dev) & 15) == 0) {
-    // wide volumes: rows in registers (softargmin_reg_kernel)
-    const int ppw = (D / 16) % 2 == 0 ? 32 : 64;                     // pixels per wave (K = 2 lanes per pixel, or 1)
+  if (D % 16 == 0 && D <= 192 && (reinterpret_cast<uintptr_t>(cost_dev) & 15) == 0) {
+    // rows in registers (softargmin_reg_kernel): one lane per pixel up to 96 levels and for odd D / 16, two lanes beyond
+    const int ppw = (D > 96 && (D / 16) % 2 == 0) ? 32 : 64;         // pixels per wave (K = 2 lanes per pixel, or 1)
     const long long nwave = (npix + ppw - 1) / ppw;
     const unsigned blocks = (unsigned)std::min<long long>((nwave + 3) / 4, 256 * 16);
 #define ST_SA_LAUNCH(NCHV, KV)                                                                              \
   hipLaunchKernelGGL((softargmin_reg_kernel<NCHV, KV>), dim3(blocks), dim3(256), 0, stream, cost_dev, npix,  \
                      temperature, out_disp_dev)
     switch (D / 16) {
+      case 1: ST_SA_LAUNCH(1, 1); break;
+      case 2: ST_SA_LAUNCH(2, 1); break;
+      case 3: ST_SA_LAUNCH(3, 1); break;
+      case 4: ST_SA_LAUNCH(4, 1); break;
+      case 5: ST_SA_LAUNCH(5, 1); break;
+      case 6: ST_SA_LAUNCH(6, 1); break;
       case 7: ST_SA_LAUNCH(7, 1); break;
       case 8: ST_SA_LAUNCH(8, 2); break;
       case 9: ST_SA_LAUNCH(9, 1); break;

@@ -462,10 +462,11 @@ def test_costvolume_agg3d_fused_equals_two_call_form_at_full_resolution(cuda):
     del vol, ref, out
 
 
-@pytest.mark.parametrize('N,Hf,Wf,D', [(1, 3, 37, 192), (2, 2, 45, 128), (1, 5, 13, 112), (1, 1, 70, 144), (1, 2, 33, 176)])
+@pytest.mark.parametrize('N,Hf,Wf,D', [(1, 3, 37, 192), (2, 2, 45, 128), (1, 5, 13, 112), (1, 1, 70, 144), (1, 2, 33, 176),
+                                      (1, 3, 37, 48), (2, 2, 45, 16), (1, 5, 13, 96), (1, 1, 70, 80), (1, 2, 33, 32), (1, 3, 20, 64)])
 def test_softargmin_wide_volumes_bit_exact(N, Hf, Wf, D, cuda):
-    """st_softargmin on volumes of 112 .. 192 levels (the full-resolution mode): rows held in registers, split over two
-    lanes when D / 16 is even, the two running sums chained through the lanes in the oracle's order - BIT-EXACT against
+    """st_softargmin on volumes of 16 .. 192 levels in steps of 16 (the register kernel: the 48 levels of the benched
+    default, the 192 of the full-resolution mode): rows held in registers, split over two lanes when D > 96 and D / 16 is even, the two running sums chained through the lanes in the oracle's order - BIT-EXACT against
     oracle_softargmin; pixel counts that are no multiple of the 32 / 64 pixels of a wave included."""
     lib = _lib.load()
     rng = np.random.RandomState(D + Wf)
