@@ -149,11 +149,15 @@ def test_costvolume_recovers_known_shift(cuda):
     assert np.abs(disp[:, :, D:] - d_true).max() < 1e-2
 
 
-def test_upsample_pack_bit_exact_and_matches_torch(cuda):
+@pytest.mark.parametrize('Hf,Wf,s,cut_h,cut_w', [(24, 40, 4, 16, 0),      # four pixels per thread
+                                                 (24, 40, 4, 5, 7),       # valid region ends inside a group of four
+                                                 (30, 37, 1, 3, 2),       # scale 1 (the full-resolution mode), odd width
+                                                 (16, 33, 2, 0, 1)])      # width 66: the one-pixel kernel
+def test_upsample_pack_bit_exact_and_matches_torch(Hf, Wf, s, cut_h, cut_w, cuda):
     rng = np.random.RandomState(4)
-    N, Hf, Wf, s = 2, 24, 40, 4
+    N = 2
     lr = rng.uniform(0, 48, (N, Hf, Wf)).astype(np.float32)
-    H, W, vh, vw = Hf * s, Wf * s, Hf * s - 16, Wf * s
+    H, W, vh, vw = Hf * s, Wf * s, Hf * s - cut_h, Wf * s - cut_w
     ref = c_oracle.disp_upsample(lr, s, vh, vw)
     lib = _lib.load()
     out = torch.full((N, 3, H, W), float('nan'), device=cuda)
@@ -166,8 +170,8 @@ def test_upsample_pack_bit_exact_and_matches_torch(cuda):
     # the oracle itself agrees with torch's bilinear interpolation (align_corners=False)
     t = torch.nn.functional.interpolate(torch.from_numpy(lr)[:, None], scale_factor=s, mode='bilinear',
                                         align_corners=False)[:, 0].numpy() * s
-    assert np.abs(ref[:, 0, :vh] - t[:, :vh]).max() <= 1e-4 * 48 * s
-    assert np.all(ref[:, :, vh:] == 0)
+    assert np.abs(ref[:, 0, :vh, :vw] - t[:, :vh, :vw]).max() <= 1e-4 * 48 * s
+    assert np.all(ref[:, :, vh:] == 0) and np.all(ref[:, :, :, vw:] == 0)
 
 
 def make_disp(rng, H, W):
