@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Timing-only ablations of the fused cost-volume + 3-D layer kernel (tools build: ST_LIBRARY=..._ablation.so).
-ST_CVA_MODE bits: 1 no output stores (results kept alive by an empty asm), 2 no cost FMAs, 4 one stencil tap of three, 8 no feature loads in the output steps."""
+ST_CVA_MODE bits: 1 no output stores (results kept alive by an empty asm), 2 no cost FMAs, 8 no feature loads in the output steps (modes 0, 1, 2, 8, 9 are instantiated)."""
 import ctypes as C
 import os
 import sys
