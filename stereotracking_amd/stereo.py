@@ -25,11 +25,12 @@ aggregation and soft-argmin" with D = max_disp levels at IMAGE resolution (192 x
   cost       cost[d,Y,X] = (1/8) sum_c G_L[c,Y,X] * G_R[c,Y,X-d], d in [0, max_disp) pixels; 0 where X-d < 0
              (st_costvolume_softargmin, materialised in slabs of <= 128 levels)
   aggregate  `agg3d_layers` 3x3x3 layers over (d, Y, X) (st_volume_agg3d); no 2-D stage (a 3x3 convolution over 192
-             levels-as-channels at image resolution is 625 GFLOP per pair)
+             levels-as-channels at image resolution is 625 GFLOP per pair).  With at least one layer, cost volume and
+             first layer run as ONE kernel (st_costvolume_agg3d: the volume between them never reaches memory; same bits)
   disparity  disp = sum_d d * softmax_d(temperature * cost) in pixels, no upsampling step (st_softargmin), 0 outside the
              original image, three identical channels (st_disp_upsample_pack with scale 1)
 A raw-pixel correlation at full resolution was withdrawn in round 3 (not a matcher); this mode correlates learned stage-1
-FEATURES brought to image resolution.  It is ~3 x slower than the default module (bench.py --fullres-leg) and exists so
+FEATURES brought to image resolution.  It runs at ~0.53 of the default module's rate (bench.py --fullres-leg) and exists so
 that the literal sizing is a tested, benched product path, not only a kernel measurement.
 """
 import ctypes as C
@@ -302,10 +303,12 @@ class StereoCostVolume(nn.Module):
             f32 = dict(dtype=torch.float32, device=dev)
             self._fr = dict(red=torch.empty(2 * N, Hf, Wf, Cr, **f32), up=torch.empty(2 * N, H, W, Cr, **f32),
                             va=torch.empty(N, H, W, D, **f32), disp=torch.empty(N, H, W, **f32))
-            # second volume: only where a layer runs volume -> volume (the first layer fused with the cost volume writes
-            # straight into `va`)
-            fused = self.fuse_first_layer and self.lib.st_costvolume_agg3d_supported(Cr, D) == 1
-            self._fr['vb'] = torch.empty(N, H, W, D, **f32) if self.agg3d_layers > (1 if fused else 0) else None
+            self._fr['vb'] = None
+        # second volume: only where a layer runs volume -> volume (the first layer fused with the cost volume writes straight
+        # into `va`); allocated on first need (a tool may switch `fuse_first_layer` off on a live module)
+        fused = self.fuse_first_layer and self.lib.st_costvolume_agg3d_supported(Cr, D) == 1
+        if self._fr['vb'] is None and self.agg3d_layers > (1 if fused else 0):
+            self._fr['vb'] = torch.empty(N, H, W, D, dtype=torch.float32, device=dev)
         return self._fr
 
     def _compute_full_res(self, feat, N, Hf, Wf, Cf, ld, valid_hw, disp_postp, cost_out, stream, dev, H, W):

@@ -650,3 +650,17 @@ def test_stereo_full_resolution_mode_matches_oracle(agg3d_layers, cuda):
     res = pipe.run(img, right)
     torch.cuda.synchronize()
     assert torch.equal(res['disp_postp'].cpu(), torch.from_numpy(got)) and torch.isfinite(res['head']).all()
+    # (6) which kernels ran: with a 3-D layer the cost volume and the first layer are ONE launch (st_costvolume_agg3d);
+    # switched off, the two-call form gives the same bits
+    sm.timing = True
+    out2 = torch.full_like(out, float('nan'))
+    sm.compute(pipe.det, img, right, (H, W), None, out2)
+    torch.cuda.synchronize()
+    stages = sm.pop_full_res_times()
+    assert ('cost_volume_agg3d_first' in stages) == (agg3d_layers > 0) and torch.equal(out2, out)
+    sm.fuse_first_layer = False
+    out3 = torch.full_like(out, float('nan'))
+    sm.compute(pipe.det, img, right, (H, W), None, out3)
+    torch.cuda.synchronize()
+    assert 'cost_volume' in sm.pop_full_res_times() and torch.equal(out3, out)
+    sm.timing, sm.fuse_first_layer = False, True
