@@ -166,6 +166,7 @@ struct CvAggArgs {
   const float* fr;
   float* out;
   int N, H, W, ld, D, RY;
+  int strips, bands, order;   // 1-D grid of N * bands * strips workgroups; order 1: XCD-contiguous (below)
   float w[27];
   float bias;
   int act;
@@ -258,7 +259,16 @@ __global__ __launch_bounds__(192) __attribute__((amdgpu_waves_per_eu(3))) void c
   float* costrow = lds;
   float* frs = costrow + (TW + 2) * DS;          // [C][FRW]: right-image pixels x0 - D .. x0 + TW + 3
   float* fls = frs + C * FRW;                    // [C][FLW]: left-image pixels x0 - 4 .. x0 + TW + 3
-  const int x0 = blockIdx.x * TW, y0 = blockIdx.y * a.RY, n = blockIdx.z;
+  // Workgroup -> (pair, band, strip).  Neighbouring strips share 196 of the 212 right-image pixels they stage per row;
+  // workgroups are dealt to the 8 XCDs (own L2 each) round-robin, so in launch order every XCD ends up fetching the whole
+  // feature row.  Order 1 gives each XCD a CONTIGUOUS range of the (pair, band, strip) sequence: neighbours share an L2.
+  int wg = blockIdx.x;
+  if (a.order == 1) {
+    const int total = gridDim.x, per = total >> 3;
+    if (wg < (per << 3)) wg = (wg & 7) * per + (wg >> 3);
+  }
+  const int strip = wg % a.strips, band = (wg / a.strips) % a.bands, n = wg / (a.strips * a.bands);
+  const int x0 = strip * TW, y0 = band * a.RY;
   const int y1 = min(y0 + a.RY, a.H);
   const int tid = threadIdx.x;
   const int q = tid % DQ, g = tid / DQ;
@@ -675,7 +685,13 @@ extern "C" int st_costvolume_agg3d(const float* featL_dev, const float* featR_de
   a.RY = std::min(H, ceil_div(H, best_b));
   const int bands = ceil_div(H, a.RY);
   ST_REQUIRE(bands < 65536, "st_costvolume_agg3d: grid too large");
-  const dim3 grid((unsigned)strips, (unsigned)bands, (unsigned)N);
+  a.strips = strips; a.bands = bands;
+  a.order = 1;
+#ifdef ST_ABLATION
+  if (const char* o = getenv("ST_CVA_ORDER")) a.order = atoi(o);     // tools: 0 = launch order
+#endif
+  ST_REQUIRE((long long)N * strips * bands < (1ll << 31), "st_costvolume_agg3d: grid too large");
+  const dim3 grid((unsigned)(N * strips * bands));
   hipStream_t stream = static_cast<hipStream_t>(stream_);
 #define ST_CVA_LAUNCH(TWV, CV, DMAXV)                                                                \
   do {                                                                                               \
