@@ -759,6 +759,46 @@ def batched_association_line(dev, B=1024, T=32, M=16):
         return dict(error=repr(e))
 
 
+def launch_ranks(args, argv, json_fd):
+    """`bench.py --gpus N` started WITHOUT torch.distributed.run: start the N ranks from here.  The parent makes no GPU
+    call (counting devices does not initialise one), runs `python -m torch.distributed.run --nnodes=1 --nproc-per-node N
+    --master-addr 127.0.0.1 --master-port <free> bench.py <the same arguments>` as a child, relays rank 0's single JSON
+    line to its own stdout and returns the child's exit status (non-zero if ANY rank failed; a run whose ranks printed
+    no line, or more than one, is a failure too).  Fewer than N visible devices is an error before anything starts -
+    except under ST_BENCH_BACKEND=gloo, the one-card rehearsal of the N-rank code path.
+    (reference: launcher handling tools/test.py:33-41, one process per GPU.)"""
+    import socket
+    import subprocess
+    backend = os.environ.get('ST_BENCH_BACKEND', 'nccl')
+    ndev = torch.cuda.device_count()
+    if backend == 'nccl' and ndev < args.gpus:
+        sys.stderr.write(f'bench.py: --gpus {args.gpus} but only {ndev} device(s) visible; refusing to measure fewer '
+                         'ranks than asked for\n')
+        return 2
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={args.gpus}',
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + list(argv)
+    sys.stderr.write('bench.py: no launcher in the environment, starting %d ranks: %s\n' % (args.gpus, ' '.join(cmd)))
+    sys.stderr.flush()
+    p = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=2, env=env, cwd=os.getcwd())
+    out, _ = p.communicate()
+    lines = [l for l in out.decode(errors='replace').splitlines() if l.startswith('{') and l.rstrip().endswith('}')]
+    if p.returncode != 0:
+        sys.stderr.write(f'bench.py: the {args.gpus}-rank run failed with status {p.returncode}\n')
+        return p.returncode
+    if len(lines) != 1:
+        sys.stderr.write(f'bench.py: expected ONE JSON line from rank 0, got {len(lines)}\n')
+        return 3
+    if json.loads(lines[0]).get('n_gpus') != args.gpus:
+        sys.stderr.write('bench.py: the line does not report n_gpus = %d\n' % args.gpus)
+        return 4
+    os.write(json_fd, (lines[0] + '\n').encode())
+    return 0
+
+
 def main():
     args = parse()
     # stdout carries exactly ONE line, the JSON of rank 0: libraries that print to file descriptor 1 (RCCL writes a
@@ -769,13 +809,23 @@ def main():
     rank = int(os.environ.get('RANK', 0))
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}')
+    launched = 'RANK' in os.environ and 'WORLD_SIZE' in os.environ
+    if args.gpus > 1 and not launched:
+        # `python bench.py --gpus N` without a launcher (the form the driver uses for N = 1): this process has made no
+        # GPU call yet and never will - it starts the N ranks itself, relays their ONE JSON line and their exit status.
+        # A --gpus N run can therefore never come back as a silent 1-rank measurement.
+        raise SystemExit(launch_ranks(args, sys.argv[1:], json_fd))
+    if world != args.gpus:
+        raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}: start one rank per GPU (or drop the launcher: '
+                         'bench.py --gpus N starts its own ranks)')
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a GPU (the HIP path is the only product path)')
     # one rank per GPU; ST_BENCH_BACKEND=gloo is a single-GPU REHEARSAL of the multi-rank code path (ranks share
     # cuda:0, the detection buffers are gathered through host memory) - never used for reported numbers
     backend = os.environ.get('ST_BENCH_BACKEND', 'nccl')
+    if backend == 'nccl' and torch.cuda.device_count() < world:
+        raise SystemExit(f'--gpus {world} but only {torch.cuda.device_count()} device(s) visible: one rank per GPU, '
+                         'never two ranks on one card (ST_BENCH_BACKEND=gloo is the one-card rehearsal)')
     dev_index = local_rank if backend == 'nccl' else local_rank % torch.cuda.device_count()
     torch.cuda.set_device(dev_index)
     dev = torch.device('cuda', dev_index)

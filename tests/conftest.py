@@ -19,7 +19,7 @@ def pytest_configure(config):
 # GPUTEST_r02 stopped at test_multirank_gpu and 27 parity tests did not run).
 _ORDER = ['test_decode_nms_gpu', 'test_stereo_depth_gpu', 'test_conv_gpu', 'test_detector_gpu', 'test_batched_assoc_gpu',
           'test_bench_config_parity_gpu', 'test_shell_gpu', 'test_sequence_gpu']
-_LAST = ['test_multirank_gpu']
+_LAST = ['test_multirank_gpu', 'test_config3_gpu']
 
 
 def pytest_collection_modifyitems(session, config, items):

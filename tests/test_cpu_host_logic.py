@@ -520,3 +520,50 @@ def test_detection_gatherer_single_rank_collective_gloo():
         assert g2.gather(rec)[0] is rec
     finally:
         dist.destroy_process_group()
+
+
+# ---- bench.py --gpus N without a launcher (a --gpus N run may never come back as ONE rank) -------------
+def _bench(args, env_extra=None, drop=('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT')):
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, **(env_extra or {}))
+    for k in drop:
+        if k not in (env_extra or {}):
+            env.pop(k, None)
+    return subprocess.run([sys.executable, os.path.join(root, 'bench.py')] + args, cwd=root, env=env, capture_output=True,
+                          text=True, timeout=300)
+
+
+def test_bench_gpus_n_without_launcher_refuses_fewer_devices():
+    """`python bench.py --gpus 2` with fewer than 2 visible devices on the RCCL backend is an ERROR before any rank
+    starts - never a 1-rank measurement printed as if it were the N-rank one."""
+    import torch
+    if torch.cuda.device_count() >= 2:
+        pytest.skip('two devices visible: the refusal cannot be provoked')
+    p = _bench(['--gpus', '2', '--steps', '1', '--warmup', '0'])
+    assert p.returncode == 2 and p.stdout.strip() == ''
+    assert 'device(s) visible' in p.stderr and 'refusing' in p.stderr
+
+
+def test_bench_gpus_n_without_launcher_starts_n_ranks_and_relays_their_failure():
+    """Without RANK / WORLD_SIZE in the environment the parent starts the N ranks itself (torch.distributed.run, one
+    process per rank).  Here (no GPU) the ranks die with 'bench.py needs a GPU': the 2-rank launch must have happened, the
+    parent must exit non-zero and print no JSON line.  (The successful form - n_gpus: 2 on one card over gloo - is
+    tests/test_multirank_gpu.py::test_bench_gpus2_without_launcher_starts_two_ranks.)"""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip('a GPU is present: covered by the -m gpu form of this test')
+    p = _bench(['--gpus', '2', '--steps', '1', '--warmup', '0'], dict(ST_BENCH_BACKEND='gloo'))
+    assert p.returncode != 0 and p.stdout.strip() == ''
+    assert 'starting 2 ranks' in p.stderr and '--nproc-per-node=2' in p.stderr
+    # (torch.distributed.run may end the second rank as soon as the first has failed: one or two such messages)
+    assert 1 <= p.stderr.count('bench.py needs a GPU') <= 2, p.stderr[-3000:]
+    assert 'the 2-rank run failed' in p.stderr
+
+
+def test_bench_under_a_launcher_with_the_wrong_world_size_is_an_error():
+    p = _bench(['--gpus', '2', '--steps', '1', '--warmup', '0'], dict(RANK='0', LOCAL_RANK='0', WORLD_SIZE='1'))
+    assert p.returncode != 0 and p.stdout.strip() == '' and 'WORLD_SIZE=1' in p.stderr
+    p = _bench(['--gpus', '1', '--steps', '1', '--warmup', '0'], dict(RANK='0', LOCAL_RANK='0', WORLD_SIZE='2'))
+    assert p.returncode != 0 and p.stdout.strip() == '' and 'WORLD_SIZE=2' in p.stderr
