@@ -551,6 +551,21 @@ __global__ __launch_bounds__(192) __attribute__((amdgpu_waves_per_eu(3))) void v
 }  // namespace
 }  // namespace st
 
+// Compute units of the current device (cached): the band-count searches below fill whole launch rounds of
+// CUs x resident workgroups.  (Both kernels pin 3 waves per SIMD = 4 workgroups of 192 threads per CU; the count is a
+// performance heuristic only - results are bit-exact for any band height.)
+static int a3_cu_count(int* out) {
+  static int cus = 0;
+  if (cus == 0) {
+    int dev = 0, n = 0;
+    ST_CHECK_HIP(hipGetDevice(&dev));
+    ST_CHECK_HIP(hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev));
+    cus = std::max(1, n);
+  }
+  *out = cus;
+  return ST_OK;
+}
+
 extern "C" int st_volume_agg3d(const float* vol_in_dev, float* vol_out_dev, int N, int Hf, int Wf, int D,
                                const float* weight27_host, float bias, int act, st_stream_t stream_) {
   using namespace st;
@@ -560,6 +575,10 @@ extern "C" int st_volume_agg3d(const float* vol_in_dev, float* vol_out_dev, int 
   ST_REQUIRE(((reinterpret_cast<uintptr_t>(vol_in_dev) | reinterpret_cast<uintptr_t>(vol_out_dev)) & 15) == 0,
              "st_volume_agg3d: volumes must be 16-byte aligned");
   ST_REQUIRE(Hf < 65536 && N < 65536, "st_volume_agg3d: grid too large");
+  // a volume row travels through 32-bit buffer offsets (per-row descriptors): Wf x D floats must stay below 2 GiB
+  ST_REQUIRE((long long)Wf * D * 4 < (1ll << 31), "st_volume_agg3d: a volume row of Wf x D floats must be < 2 GiB");
+  int cus = 0;
+  ST_CHECK(a3_cu_count(&cus));
   Agg3dArgs a;
   a.in = vol_in_dev; a.out = vol_out_dev; a.N = N; a.Hf = Hf; a.Wf = Wf; a.D = D;
   for (int i = 0; i < 27; ++i) a.w[i] = weight27_host[i];
@@ -575,7 +594,7 @@ extern "C" int st_volume_agg3d(const float* vol_in_dev, float* vol_out_dev, int 
   if (!ring) {
     // register-carried rows, one LDS row: TW x D / 16 threads (<= 192) own 4 pixel x 4 level tiles
     const int lds = (TW + 2) * (D + 4) * (int)sizeof(float);
-    const long long slots = 256ll * 4;
+    const long long slots = (long long)cus * 4;
     int best_b = 1;
     double best_e = -1.0;
     for (int b = 1; b <= 64 && ceil_div(Hf, b) >= 4; ++b) {
@@ -610,7 +629,7 @@ extern "C" int st_volume_agg3d(const float* vol_in_dev, float* vol_out_dev, int 
   // round is overhead per launch: pick the band count b (rows RY = ceil(Hf / b) >= 4) that maximises
   // (workgroups / slots rounded up to whole rounds) x RY / (RY + 3), slots = 256 CUs x workgroups per CU by LDS.
   const int lds = 4 * (TW + 2) * D * (int)sizeof(float);
-  const long long slots = 256ll * std::max(1, (160 * 1024) / lds);
+  const long long slots = (long long)cus * std::max(1, (160 * 1024) / lds);
   int best_b = 1;
   double best_e = -1.0;
   for (int b = 1; b <= 64 && ceil_div(Hf, b) >= 4; ++b) {
@@ -662,6 +681,11 @@ extern "C" int st_costvolume_agg3d(const float* featL_dev, const float* featR_de
   ST_REQUIRE(((reinterpret_cast<uintptr_t>(featL_dev) | reinterpret_cast<uintptr_t>(featR_dev) |
                reinterpret_cast<uintptr_t>(vol_out_dev)) & 15) == 0, "st_costvolume_agg3d: buffers must be 16-byte aligned");
   ST_REQUIRE(H < 65536 && N < 65536, "st_costvolume_agg3d: grid too large");
+  // 32-bit buffer offsets inside one image row: feature rows (W x ld floats) and volume rows (W x D floats) below 2 GiB
+  ST_REQUIRE((long long)W * ld * 4 < (1ll << 31) && (long long)W * D * 4 < (1ll << 31),
+             "st_costvolume_agg3d: an image row of W x ld (features) / W x D (volume) floats must be < 2 GiB");
+  int cus = 0;
+  ST_CHECK(a3_cu_count(&cus));
   CvAggArgs a;
   a.fl = featL_dev; a.fr = featR_dev; a.out = vol_out_dev;
   a.N = N; a.H = H; a.W = W; a.ld = ld; a.D = D;
@@ -671,8 +695,8 @@ extern "C" int st_costvolume_agg3d(const float* featL_dev, const float* featR_de
   const int TW = D <= 48 ? 64 : (D <= 96 ? 32 : 16);
   const int strips = ceil_div(W, TW);
   const int lds = ((TW + 2) * (D + 4) + C * (D + TW + 4) + C * (TW + 8)) * (int)sizeof(float);
-  // band count: whole launch rounds over 256 CUs x 4 workgroups (register-bound), two produce-only rows per band
-  const long long slots = 256ll * 4;
+  // band count: whole launch rounds over the device's CUs x 4 workgroups (register-bound), two produce-only rows per band
+  const long long slots = (long long)cus * 4;
   int best_b = 1;
   double best_e = -1.0;
   for (int b = 1; b <= 64 && ceil_div(H, b) >= 4; ++b) {

@@ -160,6 +160,7 @@ class StereoDensePipeline:
         key = (f'v{self.det.lib.st_version()}_b{self.batch}_{self.height}x{self.width}_w{self.det.widen_factor:g}'
                f'_d{self.det.deepen_factor:g}_s{int(self.stereo)}{"r" if self.rgb_only else ""}_a{self.agg_layers}'
                f'_D{self.max_disp // self.feat_stride if self.full_res else self.D}'
+               f'{"_F%d" % self.stereo_module.reduce.out_channels if self.full_res else ""}'
                f'_ops{self.det.lib.st_detector_num_ops(self.det.handle)}_{_device_tag()}'
                + ('_split' + os.environ.get('ST_SPLIT_MASK', '') if self.split_bf16 else ''))
         # (the 3-D aggregation layers run on a kernel of their own: no tile choice, not part of the key)
@@ -168,14 +169,23 @@ class StereoDensePipeline:
             explicit = tuning_cache or os.environ.get('ST_TUNE_CACHE')
             store = explicit or default_tuning_cache()
             sources = [store, committed_tuning_plans()] if explicit else [committed_tuning_plans(), store]
-            for path in sources:
-                cache, _ = _read_plans(path)
-                if key in cache and (not self.agg_layers or key + '_agg' in cache):
-                    self.det.set_tuning(cache[key])
-                    if self.agg_layers:
-                        self.stereo_module.variant = int(cache[key + '_agg'])
-                    self.tuning_source = path
-                    return
+            # full_res: the key carries `_F<channels>`, so a plan tuned for this mode is never served to the default module
+            # or back.  Where no such plan exists yet, the DEFAULT module's plan of the same detector graph (agg_layers = 0
+            # needs no `_agg` entry) is taken on purpose: the detector launch plan is identical - the key pins the op
+            # count, set_tuning() rejects a plan of another length - and the full-resolution stereo kernels have no tile
+            # choice.  Anything tuned per mode later lands under the `_F` key and wins.
+            keys = [key] + ([key.replace(f'_F{self.stereo_module.reduce.out_channels}', '', 1)] if self.full_res else [])
+            for k in keys:
+                for path in sources:
+                    cache, _ = _read_plans(path)
+                    if k in cache and (not self.agg_layers or k + '_agg' in cache):
+                        if len(cache[k]) != self.det.lib.st_detector_num_ops(self.det.handle):
+                            continue
+                        self.det.set_tuning(cache[k])
+                        if self.agg_layers:
+                            self.stereo_module.variant = int(cache[k + '_agg'])
+                        self.tuning_source = path
+                        return
         self.det.set_split(self.split_bf16)
         self.det.autotune()
         if self.agg_layers:

@@ -67,6 +67,11 @@ class StereoCostVolume(nn.Module):
                 raise ValueError('full_res needs max_disp to be a multiple of 16 in [16, 192]')
             if full_res_channels % 4 or feat_channels % 4:
                 raise ValueError('full_res_channels / feat_channels must be multiples of 4')
+            if not 4 <= full_res_channels <= feat_channels:
+                raise ValueError(f'full_res needs 4 <= full_res_channels <= feat_channels (got {full_res_channels} of '
+                                 f'{feat_channels}): the reduce conv starts as a pass-through of the first channels.  '
+                                 'The fused cost-volume + 3-D kernel takes 4, 8 or 16 channels; any other count runs '
+                                 'the two-call form (st_costvolume_softargmin -> st_volume_agg3d), same results')
             self.reduce = nn.Conv2d(int(feat_channels), int(full_res_channels), 1)
             with torch.no_grad():   # until a checkpoint is loaded: the first channels pass through
                 self.reduce.weight.zero_()
@@ -157,12 +162,23 @@ class StereoCostVolume(nn.Module):
         d.wgt_wino_dev = wn.data_ptr() if wn is not None else None
         return d
 
+    @staticmethod
+    def _scratch_key(dev):
+        """Scratch buffers (volumes, full-resolution stages) are owned by the STREAM that launches on them: a module shared
+        by several engines / streams (the non-dense MOT shell path calls `detector.stereo.compute(eng, ...)` from every
+        context) gets one set per (device, stream), so two batches in flight never write the same volume."""
+        return (str(dev), int(torch.cuda.current_stream(dev).cuda_stream))
+
     def _volumes(self, dev, N, Hf, Wf):
         D = self.levels
-        if self._vol is None or self._vol[0].device != dev or self._vol[0].shape != (N, Hf, Wf, D):
-            self._vol = (torch.zeros(N, Hf, Wf, D, dtype=torch.float32, device=dev),
-                         torch.zeros(N, Hf, Wf, D, dtype=torch.float32, device=dev))
-        return self._vol
+        if self._vol is None:
+            self._vol = {}
+        k = self._scratch_key(dev)
+        v = self._vol.get(k)
+        if v is None or v[0].shape != (N, Hf, Wf, D):
+            v = self._vol[k] = (torch.zeros(N, Hf, Wf, D, dtype=torch.float32, device=dev),
+                                torch.zeros(N, Hf, Wf, D, dtype=torch.float32, device=dev))
+        return v
 
     def autotune(self, dev, N, Hf, Wf, reps=5, candidates=tuple(range(22)) + (42, 43)):
         """Pick the aggregation convs' tile variant by measurement (same policy as st_detector_autotune:
@@ -299,17 +315,21 @@ class StereoCostVolume(nn.Module):
         (2N,H,W,Cr), two volumes (N,H,W,D) (cost / aggregation ping-pong) and the disparity (N,H,W)."""
         Cr, D, s = self.reduce.out_channels, self.levels, self.feat_stride
         H, W = Hf * s, Wf * s
-        if self._fr is None or self._fr['red'].device != dev or self._fr['red'].shape != (2 * N, Hf, Wf, Cr):
+        if self._fr is None:
+            self._fr = {}
+        k = self._scratch_key(dev)          # one set per (device, launching stream): see _scratch_key
+        fr = self._fr.get(k)
+        if fr is None or fr['red'].shape != (2 * N, Hf, Wf, Cr):
             f32 = dict(dtype=torch.float32, device=dev)
-            self._fr = dict(red=torch.empty(2 * N, Hf, Wf, Cr, **f32), up=torch.empty(2 * N, H, W, Cr, **f32),
-                            va=torch.empty(N, H, W, D, **f32), disp=torch.empty(N, H, W, **f32))
-            self._fr['vb'] = None
+            fr = self._fr[k] = dict(red=torch.empty(2 * N, Hf, Wf, Cr, **f32), up=torch.empty(2 * N, H, W, Cr, **f32),
+                                    va=torch.empty(N, H, W, D, **f32), disp=torch.empty(N, H, W, **f32))
+            fr['vb'] = None
         # second volume: only where a layer runs volume -> volume (the first layer fused with the cost volume writes straight
         # into `va`); allocated on first need (a tool may switch `fuse_first_layer` off on a live module)
         fused = self.fuse_first_layer and self.lib.st_costvolume_agg3d_supported(Cr, D) == 1
-        if self._fr['vb'] is None and self.agg3d_layers > (1 if fused else 0):
-            self._fr['vb'] = torch.empty(N, H, W, D, dtype=torch.float32, device=dev)
-        return self._fr
+        if fr['vb'] is None and self.agg3d_layers > (1 if fused else 0):
+            fr['vb'] = torch.empty(N, H, W, D, dtype=torch.float32, device=dev)
+        return fr
 
     def _compute_full_res(self, feat, N, Hf, Wf, Cf, ld, valid_hw, disp_postp, cost_out, stream, dev, H, W):
         if Cf != self.reduce.in_channels:

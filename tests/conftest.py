@@ -10,6 +10,8 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu)')
+    config.addinivalue_line('markers', 'split: parked split-operand (bf16 x 3) conv instances; need a GPU AND the tools build '
+                                       '(ST_LIBRARY=...ablation.so); deselected unless -m names the marker')
     config.addinivalue_line('markers', 'yardstick: timing comparisons (record-only under -m gpu; ST_YARDSTICK_ASSERT=1 '
                                        'turns their speed claims into assertions)')
 
@@ -23,6 +25,13 @@ _LAST = ['test_multirank_gpu', 'test_config3_gpu']
 
 
 def pytest_collection_modifyitems(session, config, items):
+    # `split` tests (parked bf16 x 3 instances, tools build only) run only when the -m expression names them
+    if 'split' not in (config.getoption('-m') or ''):
+        parked = [it for it in items if it.get_closest_marker('split')]
+        if parked:
+            config.hook.pytest_deselected(items=parked)
+            items[:] = [it for it in items if not it.get_closest_marker('split')]
+
     def key(item):
         name = os.path.splitext(os.path.basename(str(item.fspath)))[0]
         if name in _LAST:

@@ -31,7 +31,9 @@ The float criterion is measured against float64, per quantity (boxes, scores, di
 amplifies fp32 feature noise on texture-less matches, for every fp32 evaluation.)  The score noise that legitimises an
 order swap is no longer hand-set: two detections may swap only if their FLOAT64 scores are closer than the sum of the
 two measured score errors (gpu-vs-fp64 + cpu32-vs-fp64) of that sequence.
-The record goes to gpurun_out/r05_config2_oracle_<sequence>_<thresholds>.json (copied to profiles/)."""
+Round 6: the GPU's tracks are also SCORED against the oracle's tracks as ground truth (CLEAR MOTA / Identity IDF1,
+stereotracking_amd/metrics.py): 1.0 / 1.0 with the shipped thresholds on both sequences, >= 0.99 under the stress thresholds.
+The record goes to gpurun_out/r06_config2_oracle_<sequence>_<thresholds>.json (copied to profiles/)."""
 import os
 
 import numpy as np
@@ -230,7 +232,25 @@ def test_config2_sequence_against_oracle_pipeline_and_oracle_tracker(seq, name, 
     rec['ids_relabeled'] = len(relabeled)
     rec['ids_relabeled_across_birth_frames'] = len(cross_frame)
     rec['relabeled_examples'] = {str(a): b for a, b in list(relabeled.items())[:16]}
-    write_record(f'r05_config2_oracle_{seq}_{name}.json', rec)
+    # --- the consequence in the metric the reference REPORTS (mot_drone_metrics.py:83-88: CLEAR + Identity): the GPU's tracks
+    # scored against the ORACLE's tracks as ground truth (both unscaled, x y w h).  MOTA / IDF1 are invariant under a
+    # relabeling of ids, so "one id bijection" reads as 1.0 / 1.0 here; every row outside the bijection costs an FP / FN /
+    # IDSW.  (the white-noise miss of the 1e-3 float bar, bounded where it matters - the tracks.)
+    from stereotracking_amd.metrics import clear_identity
+
+    def mot_rows(t, ids, boxes):
+        b = np.asarray(boxes, np.float64).reshape(-1, 4)
+        return np.concatenate([np.full((len(b), 1), float(t)), np.asarray(ids, np.float64).reshape(-1, 1), b[:, 0:2],
+                               b[:, 2:4] - b[:, 0:2]], axis=1)
+    gt_rows = np.concatenate([mot_rows(t, ref_tracks[ref_tracks[:, 0] == t][:, 1],
+                                       unscale_boxes_np(ref_tracks[ref_tracks[:, 0] == t][:, 2:6],
+                                                        ref_tracks[ref_tracks[:, 0] == t][:, 8])) for t in range(T)])
+    pr_rows = np.concatenate([mot_rows(t, outs[t].pred_track_instances.instances_id.cpu().numpy(),
+                                       outs[t].pred_track_instances.bboxes.cpu().double().numpy()) for t in range(T)])
+    mot = clear_identity(gt_rows, pr_rows, iou_thr=0.5)
+    rec['mot_vs_oracle_tracks'] = {k: float(mot[k]) for k in ('MOTA', 'IDF1', 'MOTP', 'IDSW', 'FP', 'FN', 'TP', 'IDP', 'IDR')}
+    rec['within_1e3_of_cpu_path'] = bool(worst['box'] <= 1e-3 and worst['score'] <= 1e-3)
+    write_record(f'r06_config2_oracle_{seq}_{name}.json', rec)
     print({k: v for k, v in rec.items() if k != 'frames'})
 
     rows = max(tot['track_rows'], 1)
@@ -257,6 +277,13 @@ def test_config2_sequence_against_oracle_pipeline_and_oracle_tracker(seq, name, 
     assert worst['gap64_at_swaps'] <= noise, (worst, noise)
     assert tot['det_sym_diff'] <= max(2, sum(f['det_oracle'] for f in rec['frames']) // 100), tot
     assert tot.get('depth_over_tol', 0) + tot.get('depth_class_mismatch', 0) <= max(2, tot.get('depth_rows', 0) // 100), tot
+    if name == 'shipped':
+        # the SHIPPED configuration, in the reference's own metric: GPU tracks against the oracle's tracks are a perfect
+        # score on BOTH sequences - the white-noise one included, where the float bar of 1e-3 is missed (1.5e-3)
+        assert mot['MOTA'] == 1.0 and mot['IDF1'] == 1.0 and mot['IDSW'] == 0 and mot['FP'] == 0 and mot['FN'] == 0, mot
+    else:
+        # stress thresholds (~230-440 tracks per frame): the rows outside the bijection cost at most 1 % of either score
+        assert mot['MOTA'] >= 0.99 and mot['IDF1'] >= 0.99, mot
     if name == 'shipped':
         # the SHIPPED configuration: every track row inside the bijection, relabels only inside one frame's new ids
         assert tot['inconsistent'] == 0 and tot['only_gpu'] == 0 and tot['only_oracle'] == 0, tot

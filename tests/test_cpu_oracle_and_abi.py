@@ -428,8 +428,19 @@ def test_shipped_code_has_no_packed_fp32_operand_select():
     MFMAs of ANY kernel run on the chip (tools/micro/pkfma_corun.hip).  The product library must not contain that
     operand form at all - checked on the built gfx950 code objects, so a compiler that folds a broadcast into op_sel
     again fails here, on CPU, before anything runs."""
+    import glob
     import isa_utils
     from stereotracking_amd import _lib
+    if not os.path.exists(isa_utils.OBJDUMP):
+        pytest.skip(f'{isa_utils.OBJDUMP} not present: the code objects cannot be disassembled here')
+    if not os.path.exists(_lib.LIB_PATH):
+        pytest.skip('product library not built (run __graft_entry__.build())')
+    # the fence must look at the code that SHIPS: a library older than any kernel source is stale
+    csrc = os.path.join(os.path.dirname(os.path.abspath(_lib.__file__)), 'csrc')
+    srcs = [f for pat in ('*.hip', '*.cpp', '*.h', 'experiments/*') for f in glob.glob(os.path.join(csrc, pat))]
+    newest = max(srcs, key=os.path.getmtime)
+    assert os.path.getmtime(_lib.LIB_PATH) >= os.path.getmtime(newest), \
+        f'{_lib.LIB_PATH} is older than {newest}: rebuild (make -C stereotracking_amd/csrc) before trusting this fence'
     code = isa_utils.disassemble_library(_lib.LIB_PATH)
     assert len(code) > 100, 'disassembly found too few kernels'
     n_packed = sum(1 for lines in code.values() for ins in lines if ins.startswith('v_pk_') and '_f32' in ins)
