@@ -163,3 +163,110 @@ def test_prediction_results_csv_side_effect(tmp_path):
     import pytest
     with pytest.raises(ValueError):
         append_prediction_results(str(tmp_path / 'x.txt'), [])
+
+
+# ---- HOTA / DetA / AssA (reference mot_drone_metrics.py:83-88, 291-295: the default metric list starts with HOTA) and
+# ---- the CLEAR extras Frag / MT / ML (:306-308), on cases whose answers follow from the definitions by hand ----------
+def test_hota_perfect_tracking_is_one_at_every_threshold():
+    from stereotracking_amd.metrics import HOTA_ALPHAS, hota
+    gt = rows({t: [(1, 10 + t, 10), (2, 100, 50 + t)] for t in range(1, 11)})
+    pred = rows({t: [(7, 10 + t, 10), (9, 100, 50 + t)] for t in range(1, 11)})
+    h = hota(gt, pred)
+    assert len(HOTA_ALPHAS) == 19 and abs(HOTA_ALPHAS[0] - 0.05) < 1e-12 and abs(HOTA_ALPHAS[-1] - 0.95) < 1e-12
+    for k in ('HOTA', 'DetA', 'AssA', 'LocA', 'DetRe', 'DetPr', 'AssRe', 'AssPr'):
+        assert np.allclose(h[k], 1.0), k
+    assert np.all(h['HOTA_TP'] == 20) and not h['HOTA_FN'].any() and not h['HOTA_FP'].any()
+
+
+def test_hota_identity_switch_halves_the_association_score():
+    """One gt track of 10 frames, exact boxes, predicted as id 1 (frames 1-5) then id 2 (6-10): every detection is found
+    (DetA = 1); a TP of id pair (g, 1) has TPA = 5, FNA = 5 (g's detections carried by the other id), FPA = 0, so
+    A(c) = 5 / 10 for all ten TPs: AssA = 0.5, HOTA = sqrt(0.5) at every threshold; AssPr = 1, AssRe = 0.5."""
+    from stereotracking_amd.metrics import hota
+    gt = rows({t: [(1, 10 + 2 * t, 10)] for t in range(1, 11)})
+    pred = rows({t: [(1 if t <= 5 else 2, 10 + 2 * t, 10)] for t in range(1, 11)})
+    h = hota(gt, pred)
+    assert np.allclose(h['DetA'], 1.0) and np.allclose(h['AssA'], 0.5) and np.allclose(h['HOTA'], np.sqrt(0.5))
+    assert np.allclose(h['AssPr'], 1.0) and np.allclose(h['AssRe'], 0.5)
+
+
+def test_hota_missed_half_and_localisation_threshold():
+    from stereotracking_amd.metrics import HOTA_ALPHAS, hota
+    # found in 5 of 10 frames with the right id: DetA = 5 / 10; A(c) = 5 / (5 + 5 FNA) = 0.5; HOTA = 0.5
+    gt = rows({t: [(1, 10 + 2 * t, 10)] for t in range(1, 11)})
+    h = hota(gt, rows({t: [(4, 10 + 2 * t, 10)] for t in range(1, 6)}))
+    assert np.allclose(h['DetA'], 0.5) and np.allclose(h['AssA'], 0.5) and np.allclose(h['HOTA'], 0.5)
+    assert np.allclose(h['DetPr'], 1.0) and np.allclose(h['DetRe'], 0.5)
+    # boxes of 20 x 20 shifted by 5 px: IoU = 15 * 20 / (2 * 400 - 300) = 0.6 -> matched for alpha <= 0.6 (12 of the 19
+    # thresholds), unmatched (FP + FN, score 0) beyond: mean HOTA = 12 / 19, LocA = 0.6 where anything matched
+    pred = rows({t: [(4, 15 + 2 * t, 10)] for t in range(1, 11)})
+    h = hota(gt, pred)
+    exp = (HOTA_ALPHAS <= 0.6 + 1e-9).astype(float)
+    assert exp.sum() == 12 and np.allclose(h['HOTA'], exp) and np.allclose(h['DetA'], exp) and np.allclose(h['AssA'], exp)
+    assert np.allclose(h['LocA'][:12], 0.6) and abs(h['HOTA'].mean() - 12 / 19) < 1e-12
+    # empty sides
+    h = hota(gt, [])
+    assert np.all(h['HOTA_FN'] == 10) and not h['HOTA'].any()
+    h = hota([], pred)
+    assert np.all(h['HOTA_FP'] == 10) and not h['HOTA'].any()
+
+
+def test_hota_two_objects_swapped_ids_midway():
+    """Two gt tracks far apart, 8 frames; the tracker exchanges its two ids after frame 4.  Detection is perfect.  Every
+    TP has TPA = 4, FNA = 4, FPA = 4: A(c) = 4 / 12, AssA = 1 / 3, HOTA = sqrt(1 / 3); CLEAR counts 2 id switches."""
+    from stereotracking_amd.metrics import hota
+    gt = rows({t: [(1, 10 + t, 10), (2, 300, 50 + t)] for t in range(1, 9)})
+    pred = rows({t: [(1 if t <= 4 else 2, 10 + t, 10), (2 if t <= 4 else 1, 300, 50 + t)] for t in range(1, 9)})
+    h = hota(gt, pred)
+    assert np.allclose(h['DetA'], 1.0) and np.allclose(h['AssA'], 1 / 3) and np.allclose(h['HOTA'], np.sqrt(1 / 3))
+    r = clear_identity(gt, pred)
+    assert r['IDSW'] == 2 and r['MOTA'] == (16 - 0 - 2) / 16 and r['IDF1'] == 0.5
+
+
+def test_clear_frag_mt_pt_ml():
+    """gt 1: 10 frames, tracked in frames 1-4 and 7-10 (two segments: Frag 1, ratio 0.8 -> PT, not MT: MT needs > 0.8);
+    gt 2: 10 frames, tracked in 9 (ratio 0.9 -> MT), one gap in the middle (Frag 1); gt 3: 10 frames, tracked once (ML);
+    gt 4: always tracked (MT) - so that no frame is without predictions (TrackEval skips such a frame entirely, it does not
+    end a tracked segment; restated the same way here)."""
+    gt = rows({t: [(1, 10 + t, 10), (2, 200, 50 + t), (3, 400 + t, 300), (4, 600, 400)] for t in range(1, 11)})
+    pred = {}
+    for t in range(1, 11):
+        objs = [(14, 600, 400)]
+        if t not in (5, 6):
+            objs.append((11, 10 + t, 10))
+        if t != 5:
+            objs.append((12, 200, 50 + t))
+        if t == 3:
+            objs.append((13, 400 + t, 300))
+        pred[t] = objs
+    r = clear_identity(gt, rows(pred))
+    assert (r['MT'], r['PT'], r['ML'], r['Frag']) == (2, 1, 1, 2)
+    assert (r['TP'], r['FN'], r['FP'], r['IDSW']) == (8 + 9 + 1 + 10, 2 + 1 + 9, 0, 0)
+
+
+def test_drone_metrics_report_the_reference_key_set():
+    """MOTDroneMetrics(metric=...) mirrors the reference constructor (mot_drone_metrics.py:83-103): default
+    ['HOTA', 'CLEAR', 'Identity'], an unknown name raises KeyError; the combined result carries the keys the reference
+    logs (:291-320); two videos combine by count (HOTA: TP-weighted association, summed detection counts)."""
+    import pytest
+    with pytest.raises(KeyError):
+        MOTDroneMetrics(metric=['HOTA', 'VACE'])
+    m = MOTDroneMetrics(ignore_depth=True)
+    assert m.metrics == ['HOTA', 'CLEAR', 'Identity']
+    # video a: perfect, 10 detections; video b: the id-switch case above (10 detections, AssA 0.5)
+    m.gt['a'] = rows({t: [(1, 10 + t, 10)] for t in range(1, 11)})
+    m.pred['a'] = rows({t: [(3, 10 + t, 10)] for t in range(1, 11)})
+    m.gt['b'] = rows({t: [(1, 10 + 2 * t, 10)] for t in range(1, 11)})
+    m.pred['b'] = rows({t: [(1 if t <= 5 else 2, 10 + 2 * t, 10)] for t in range(1, 11)})
+    out = m.evaluate(distributed=False)
+    c = out['combined']
+    for k in ('HOTA', 'AssA', 'DetA', 'MOTA', 'MOTP', 'IDSW', 'TP', 'FP', 'FN', 'Frag', 'MT', 'ML', 'IDF1', 'IDTP', 'IDFN',
+              'IDFP', 'IDP', 'IDR'):
+        assert k in c, k
+    assert abs(out['per_video']['a']['HOTA'] - 1.0) < 1e-12 and abs(out['per_video']['b']['HOTA'] - np.sqrt(0.5)) < 1e-12
+    # combined: DetA = 1 (20 TP, nothing else); AssA = (10 * 1 + 10 * 0.5) / 20 = 0.75
+    assert abs(c['DetA'] - 1.0) < 1e-12 and abs(c['AssA'] - 0.75) < 1e-12 and abs(c['HOTA'] - np.sqrt(0.75)) < 1e-12
+    assert c['IDSW'] == 1 and c['MT'] == 2 and c['ML'] == 0 and c['Frag'] == 0
+    m2 = MOTDroneMetrics(ignore_depth=True, metric='CLEAR')
+    m2.gt, m2.pred = m.gt, m.pred
+    assert 'HOTA' not in m2.evaluate(distributed=False)['combined']
