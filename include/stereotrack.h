@@ -175,6 +175,14 @@ int st_pack_raw_inputs(const unsigned char* img_u8_dev, const unsigned short* di
  * multiples of 4.  No concatenated staging copy. */
 int st_pack_raw_frames(const unsigned char* const* frames_u8_dev_ptrs_host, int N, int h, int w, int H, int W,
                        float img_pad, float* img_out_dev, st_stream_t stream);
+/* Resize_Disparity with a non-identity scale (reference datasets/transforms/transforms_disparity.py:23-137: the image
+ * through mmcv.imrescale / imresize = cv2.resize INTER_LINEAR, disp_postp / disp_mask / depth_postp through
+ * INTER_NEAREST, :52-112).  P planes of h x w elements -> h2 x w2; interleaved = 0: planar [P][h][w], 1: [h][w][P].
+ * bilinear = 1 (elem_bytes 1 only): OpenCV's 8-bit INTER_LINEAR restated (11-bit fixed-point taps, the exact 2 x 2
+ * decimation as a box mean; cv2 is un-vendored: published algorithm, parity unpinned); bilinear = 0: INTER_NEAREST for
+ * 1- / 2- / 4-byte elements (uint8 masks, uint16 PNG codes, fp32 maps: the sampling commutes with code / 16). */
+int st_resize_planes(const void* in_dev, int P, int h, int w, int interleaved, void* out_dev, int h2, int w2,
+                     int elem_bytes, int bilinear, st_stream_t stream);
 
 /* SPP: out[..., 0:C]=x, [C:2C]=maxpool5, [2C:3C]=maxpool9, [3C:4C]=maxpool13
  * (stride 1, same pad, -inf padding).  x may alias out channels [0,C).

@@ -74,6 +74,7 @@ _PROTOS = {
     'st_detector_forward_raw': (_i, [_vp, _vp, _i, _i, _f, _vp, _vp, _sz, _vp, _vp]),
     'st_detector_forward_phase0_raw': (_i, [_vp, _vp, _vp, _i, _i, _f, _vp, _sz, _vp]),
     'st_pack_raw_frames': (_i, [_vp, _i, _i, _i, _i, _i, _f, _vp, _vp]),
+    'st_resize_planes': (_i, [_vp, _i, _i, _i, _i, _vp, _i, _i, _i, _i, _vp]),
     'st_detector_set_split': (_i, [_vp, _i]),
     'st_split_instances_available': (_i, []),
     'st_volume_agg3d': (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _f, _i, _vp]),

@@ -329,6 +329,85 @@ __global__ __launch_bounds__(256) void pack_raw_frames_vec4_kernel(const FramePt
   }
 }
 
+
+// ---- Resize_Disparity with a non-identity scale (reference mmtrack/datasets/transforms/transforms_disparity.py:23-137:
+// image through mmcv.imrescale / imresize = cv2.resize INTER_LINEAR, disparity / mask / depth through INTER_NEAREST).
+// cv2 is an un-vendored dependency; its 8-bit bilinear path is restated here from the published OpenCV source
+// (imgproc/resize.cpp, [upstream-memory]): coordinates fx = (float)((dx + 0.5) * scale - 0.5), sx = floor(fx), the two
+// tap weights rounded to 11-bit fixed point (cvRound: half to even), a horizontal pass in int32 and the vertical pass
+// ((b0 * (S0 >> 4)) >> 16) + ((b1 * (S1 >> 4)) >> 16) + 2) >> 2; an exact 2 x 2 decimation runs as the 2 x 2 box mean
+// (a + b + c + d + 2) >> 2, which is what cv2 substitutes for INTER_LINEAR there.  Nearest: sx = min(floor(dx * scale), w - 1).
+// One thread per output element; `ps` / `rs` / `pls` = pixel / row / plane strides in elements (planar CHW or interleaved HWC).
+struct ResizeArgs {
+  const void* in;
+  void* out;
+  int P, h, w, h2, w2;
+  long long ips, irs, ipls, ops, ors, opls;
+  double sx, sy;     // src / dst
+};
+
+__device__ __forceinline__ void rs_tap(int d, double scale, int n, int& s, int& a0, int& a1) {
+  float f = (float)(((double)d + 0.5) * scale - 0.5);
+  int i = (int)floorf(f);
+  f -= (float)i;
+  if (i < 0) { f = 0.f; i = 0; }
+  if (i >= n - 1) { f = 0.f; i = n - 1; }
+  s = i;
+  a0 = __float2int_rn((1.f - f) * 2048.f);
+  a1 = __float2int_rn(f * 2048.f);
+}
+
+__global__ __launch_bounds__(256) void resize_bilinear_u8_kernel(const ResizeArgs a) {
+  const unsigned char* __restrict__ in = static_cast<const unsigned char*>(a.in);
+  unsigned char* __restrict__ out = static_cast<unsigned char*>(a.out);
+  const long long total = (long long)a.P * a.h2 * a.w2;
+  const bool box = a.h == 2 * a.h2 && a.w == 2 * a.w2;
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+    const int dx = (int)(idx % a.w2);
+    const int dy = (int)((idx / a.w2) % a.h2);
+    const int p = (int)(idx / ((long long)a.w2 * a.h2));
+    const unsigned char* src = in + p * a.ipls;
+    int v;
+    if (box) {
+      const unsigned char* r0 = src + (2 * dy) * a.irs + (2 * dx) * a.ips;
+      const unsigned char* r1 = r0 + a.irs;
+      v = ((int)r0[0] + (int)r0[a.ips] + (int)r1[0] + (int)r1[a.ips] + 2) >> 2;
+    } else {
+      int sx, ax0, ax1;
+      rs_tap(dx, a.sx, a.w, sx, ax0, ax1);
+      // rows: the fraction is NOT zeroed at the border, the row index is clamped (both taps then read the same row)
+      float fy = (float)(((double)dy + 0.5) * a.sy - 0.5);
+      const int sy = (int)floorf(fy);
+      fy -= (float)sy;
+      const int b0 = __float2int_rn((1.f - fy) * 2048.f), b1 = __float2int_rn(fy * 2048.f);
+      const int y0 = min(max(sy, 0), a.h - 1), y1 = min(max(sy + 1, 0), a.h - 1);
+      const int x1 = min(sx + 1, a.w - 1);
+      const unsigned char* r0 = src + y0 * a.irs;
+      const unsigned char* r1 = src + y1 * a.irs;
+      const int S0 = (int)r0[sx * a.ips] * ax0 + (int)r0[x1 * a.ips] * ax1;
+      const int S1 = (int)r1[sx * a.ips] * ax0 + (int)r1[x1 * a.ips] * ax1;
+      v = (((b0 * (S0 >> 4)) >> 16) + ((b1 * (S1 >> 4)) >> 16) + 2) >> 2;
+      v = min(max(v, 0), 255);
+    }
+    out[p * a.opls + dy * a.ors + dx * a.ops] = (unsigned char)v;
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void resize_nearest_kernel(const ResizeArgs a) {
+  const T* __restrict__ in = static_cast<const T*>(a.in);
+  T* __restrict__ out = static_cast<T*>(a.out);
+  const long long total = (long long)a.P * a.h2 * a.w2;
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+    const int dx = (int)(idx % a.w2);
+    const int dy = (int)((idx / a.w2) % a.h2);
+    const int p = (int)(idx / ((long long)a.w2 * a.h2));
+    const int sx = min((int)floor((double)dx * a.sx), a.w - 1);
+    const int sy = min((int)floor((double)dy * a.sy), a.h - 1);
+    out[p * a.opls + dy * a.ors + dx * a.ops] = in[p * a.ipls + sy * a.irs + sx * a.ips];
+  }
+}
+
 }  // namespace st
 
 extern "C" int st_pack_raw_frames(const unsigned char* const* frames_u8_dev_ptrs_host, int N, int h, int w, int H, int W,
@@ -372,6 +451,33 @@ extern "C" int st_pack_raw_inputs(const unsigned char* img_u8_dev, const unsigne
   const int blocks = (int)std::min<long long>((total + 255) / 256, 256 * 16);
   hipLaunchKernelGGL(pack_raw_inputs_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), img_u8_dev,
                      disp_u16_dev, N, h, w, H, W, img_pad, img_out_dev, disp_postp_out_dev, disp_mask_out_dev);
+  ST_CHECK_HIP(hipGetLastError());
+  return ST_OK;
+}
+
+extern "C" int st_resize_planes(const void* in_dev, int P, int h, int w, int interleaved, void* out_dev, int h2, int w2,
+                                int elem_bytes, int bilinear, st_stream_t stream) {
+  using namespace st;
+  ST_REQUIRE(in_dev && out_dev && P > 0 && P <= 16 && h > 0 && w > 0 && h2 > 0 && w2 > 0, "st_resize_planes: bad argument");
+  ST_REQUIRE(elem_bytes == 1 || elem_bytes == 2 || elem_bytes == 4, "st_resize_planes: elem_bytes must be 1, 2 or 4");
+  ST_REQUIRE(!bilinear || elem_bytes == 1, "st_resize_planes: bilinear is the 8-bit image path (cv2 INTER_LINEAR, uint8)");
+  ST_REQUIRE((long long)P * h * w < (1ll << 31) && (long long)P * h2 * w2 < (1ll << 31), "st_resize_planes: image too large");
+  ResizeArgs a;
+  a.in = in_dev; a.out = out_dev; a.P = P; a.h = h; a.w = w; a.h2 = h2; a.w2 = w2;
+  if (interleaved) {   // [h][w][P]
+    a.ips = P; a.irs = (long long)w * P; a.ipls = 1; a.ops = P; a.ors = (long long)w2 * P; a.opls = 1;
+  } else {             // [P][h][w]
+    a.ips = 1; a.irs = w; a.ipls = (long long)h * w; a.ops = 1; a.ors = w2; a.opls = (long long)h2 * w2;
+  }
+  a.sx = (double)w / (double)w2;
+  a.sy = (double)h / (double)h2;
+  const long long total = (long long)P * h2 * w2;
+  const int blocks = (int)std::min<long long>((total + 255) / 256, 256 * 32);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (bilinear) hipLaunchKernelGGL(resize_bilinear_u8_kernel, dim3(blocks), dim3(256), 0, s, a);
+  else if (elem_bytes == 1) hipLaunchKernelGGL(resize_nearest_kernel<unsigned char>, dim3(blocks), dim3(256), 0, s, a);
+  else if (elem_bytes == 2) hipLaunchKernelGGL(resize_nearest_kernel<unsigned short>, dim3(blocks), dim3(256), 0, s, a);
+  else hipLaunchKernelGGL(resize_nearest_kernel<unsigned int>, dim3(blocks), dim3(256), 0, s, a);
   ST_CHECK_HIP(hipGetLastError());
   return ST_OK;
 }

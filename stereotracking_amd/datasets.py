@@ -334,20 +334,75 @@ class LoadDepthFromFile:
         return results
 
 
+def resize_on_device(a, h2, w2, bilinear):
+    """One array of a dataset sample -> (h2, w2) through the HIP resampler (st_resize_planes, csrc/pack_pool.hip): uint8
+    images by OpenCV's 8-bit INTER_LINEAR, everything else (uint16 PNG codes, fp32 maps, uint8 masks) by INTER_NEAREST.
+    `a`: numpy (h, w) / (h, w, c) or a CUDA tensor of that layout; the result comes back in the same container.  There is
+    no CPU implementation in the product: without the HIP library and a GPU this raises."""
+    import torch
+    from ._lib import check, current_stream, load, ptr
+    if not torch.cuda.is_available():
+        raise RuntimeError('Resize_Disparity with a non-identity scale resamples on the GPU (st_resize_planes); no GPU here')
+    if isinstance(a, torch.Tensor):
+        t = a
+    elif a.dtype == np.uint16:         # PNG codes: moved as their int16 bit pattern (nearest sampling copies elements)
+        t = torch.from_numpy(np.ascontiguousarray(a).view(np.int16))
+    else:
+        t = torch.from_numpy(np.ascontiguousarray(a))
+    if bilinear and t.dtype != torch.uint8:
+        raise TypeError('the bilinear path is the 8-bit image path (decoded frames are uint8)')
+    h, w = t.shape[:2]
+    P = 1 if t.dim() == 2 else int(t.shape[2])
+    dev = t.device if t.is_cuda else torch.device('cuda', torch.cuda.current_device())
+    src = t.to(dev).contiguous()
+    dst = torch.empty((h2, w2) + tuple(t.shape[2:]), dtype=t.dtype, device=dev)
+    check(load().st_resize_planes(ptr(src), P, h, w, 1, ptr(dst), h2, w2, t.element_size(), 1 if bilinear else 0,
+                                  current_stream()), 'st_resize_planes')
+    if isinstance(a, torch.Tensor):
+        return dst
+    out = dst.cpu().numpy()
+    return out.view(a.dtype) if out.dtype != a.dtype else out
+
+
 @TRANSFORMS.register_module(name=['Resize_Disparity', 'mmtrack.Resize_Disparity'])
 class Resize_Disparity:
-    """transforms_disparity.py:23-137 at test time: keep_ratio rescale to `scale` (w, h).  The shipped pipeline rescales
-    1280x720 frames to (1280, 720) - the identity; any other factor needs an image resampler (cv2) and is refused."""
+    """transforms_disparity.py:23-137 at test time: rescale to `scale` (w, h) - keep_ratio: mmcv.rescale_size, else exactly
+    `scale`.  The shipped pipeline rescales 1280x720 frames to (1280, 720): the identity, nothing is touched.  Any other
+    size resamples ON THE DEVICE (st_resize_planes): img / right by cv2's 8-bit INTER_LINEAR, disp_postp / disp_codes /
+    disp_mask / depth_postp by INTER_NEAREST (:52-112), and records img_shape / scale_factor = (new_w / w, new_h / h) the
+    way mmdet's Resize does - predict() divides the boxes by it again (rescale=True)."""
+
+    BILINEAR = ('img', 'right')
+    NEAREST = ('disp_postp', 'disp_codes', 'disp_mask', 'depth_postp', 'depth')
 
     def __init__(self, scale, keep_ratio=True, **kwargs):
-        self.scale = tuple(scale)
+        self.scale, self.keep_ratio = tuple(scale), bool(keep_ratio)
+
+    def new_size(self, h, w):
+        if self.keep_ratio:
+            f = min(max(self.scale) / max(h, w), min(self.scale) / min(h, w))      # mmcv.rescale_size
+            return int(w * f + 0.5), int(h * f + 0.5)
+        return int(self.scale[0]), int(self.scale[1])
 
     def __call__(self, results):
         h, w = results['img_shape'][:2]
-        f = min(max(self.scale) / max(h, w), min(self.scale) / min(h, w))      # mmcv.rescale_size
-        if int(w * f + 0.5) != w or int(h * f + 0.5) != h:
-            raise NotImplementedError(f'Resize_Disparity: {w}x{h} -> scale {self.scale} is not the identity')
-        results['scale_factor'] = (1.0, 1.0)
+        nw, nh = self.new_size(h, w)
+        results['scale'] = self.scale
+        results['keep_ratio'] = self.keep_ratio
+        if (nw, nh) == (w, h):
+            results['scale_factor'] = (1.0, 1.0)
+            return results
+        done = {}
+        for keys, bil in ((self.BILINEAR, True), (self.NEAREST, False)):
+            for k in keys:
+                a = results.get(k)
+                if a is None:
+                    continue
+                if id(a) not in done:      # 'depth' and 'depth_postp' may be one array
+                    done[id(a)] = resize_on_device(a, nh, nw, bil)
+                results[k] = done[id(a)]
+        results['img_shape'] = (nh, nw) + tuple(results['img_shape'][2:])
+        results['scale_factor'] = (nw / w, nh / h)
         return results
 
 

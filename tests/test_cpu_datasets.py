@@ -114,8 +114,44 @@ def test_pipeline_from_reference_shaped_config(tiny):
     m = sample.metainfo
     assert m['frame_id'] == 2 and m['video_length'] == 6 and m['ori_shape'] == (48, 96) and m['scale_factor'] == (1.0, 1.0)
     assert len(m['instances']) == len(d.data_list[2]['instances'])
-    with pytest.raises(NotImplementedError):
-        ds.Resize_Disparity(scale=(640, 360))(dict(img_shape=(48, 96)))
+    # a non-identity scale: sizes / scale_factor as mmcv.rescale_size + mmdet Resize record them; the resampling itself is a
+    # device pass (st_resize_planes; tests/test_resize_gpu.py) - without a GPU an array to resample is an error, never a
+    # silent CPU path
+    rz = ds.Resize_Disparity(scale=(640, 360))
+    assert rz.new_size(48, 96) == (640, 320) and ds.Resize_Disparity(scale=(640, 360), keep_ratio=False).new_size(48, 96) == (640, 360)
+    r = rz(dict(img_shape=(48, 96)))
+    assert r['img_shape'] == (320, 640) and r['scale_factor'] == (640 / 96, 320 / 48)
+    if not torch.cuda.is_available():
+        with pytest.raises(RuntimeError, match='GPU'):
+            rz(dict(img_shape=(48, 96), img=np.zeros((48, 96, 3), np.uint8)))
     # depth: AirSim encoding value / 100 (loading_disparity.py:233)
     r = ds.LoadDepthFromFile()(dict(d.get_data_info(2)))
     assert r['depth'].shape == (48, 96, 1) and abs(float(r['depth'].max()) - 80.0) < 1e-3
+
+
+def test_resize_oracle_restatement_properties():
+    """oracle/resize.py (the numpy restatement the GPU test checks st_resize_planes against) on cases whose answers follow
+    from the algorithm: constant images stay constant, the exact 2 x 2 decimation is the rounded box mean, an upscale by an
+    integer factor reproduces the source at the sample centres' nearest pixels, a horizontal ramp stays monotone and inside
+    the source range, nearest picks floor(dx * src / dst)."""
+    from oracle import resize as orz
+    assert orz.rescale_size(720, 1280, (640, 360)) == (640, 360) and orz.rescale_size(48, 96, (640, 360)) == (640, 320)
+    const = np.full((37, 53, 3), 201, np.uint8)
+    assert (orz.resize_bilinear_u8(const, 19, 71) == 201).all()
+    rng = np.random.RandomState(0)
+    img = rng.randint(0, 256, (48, 96, 3)).astype(np.uint8)
+    half = orz.resize_bilinear_u8(img, 24, 48)
+    x = img.astype(np.int64)
+    assert np.array_equal(half, ((x[0::2, 0::2] + x[0::2, 1::2] + x[1::2, 0::2] + x[1::2, 1::2] + 2) >> 2).astype(np.uint8))
+    ramp = np.tile(np.arange(96, dtype=np.uint8)[None, :] * 2, (48, 1))
+    up = orz.resize_bilinear_u8(ramp, 100, 250)
+    assert up.shape == (100, 250) and (np.diff(up.astype(int), axis=1) >= 0).all() and up.min() == 0 and up.max() == 190
+    # rows of a horizontal ramp agree to one code (the two truncating shifts of the vertical pass split b0 + b1 = 2048)
+    assert np.abs(up.astype(int) - up[0].astype(int)).max() <= 1
+    same = orz.resize_bilinear_u8(img, 48, 96)                    # identity size: fx = 0 everywhere
+    assert np.array_equal(same, img)
+    codes = rng.randint(0, 65536, (48, 96)).astype(np.uint16)
+    nn = orz.resize_nearest(codes, 31, 200)
+    for dy, dx in ((0, 0), (30, 199), (7, 101), (15, 3)):
+        assert nn[dy, dx] == codes[min(int(np.floor(dy * 48 / 31)), 47), min(int(np.floor(dx * 96 / 200)), 95)]
+    assert np.array_equal(orz.resize_nearest(codes, 24, 48), codes[0::2, 0::2])
