@@ -165,6 +165,8 @@ def conv_roofline(pipe, img, right, steps):
             n_launch //= 3      # one launch computes three ops of the plan (3x3/s2 + main|short + conv1)
         if VARIANT_TILES[v] == 'wino2x2g+':
             n_launch = 0        # riders of a grouped Winograd launch: computed by the 'wino2x2g' op in front of them
+        if VARIANT_TILES[v] == 'wino32tail':
+            n_launch //= 2      # one launch computes two ops of the plan (bottleneck conv2 + CSP final_conv)
         name = ROW.get(VARIANT_TILES[v], VARIANT_TILES[v])
         e = per_variant.setdefault(name, dict(launches=0, ops=0, event_pairs=0, ms_per_step=0.0, gflop_per_step=0.0))
         e['launches'] += n_launch
@@ -188,6 +190,7 @@ def conv_roofline(pipe, img, right, steps):
               'wino2x2': 'st::wino_conv3x3_kernel', 'wino2x2n': 'st::wino_conv3x3_kernel', 'skipped': None,
               'wino2x2g': 'st::wino_conv3x3_kernel', 'wino2x2g+': 'st::wino_conv3x3_kernel',   # grouped launches
               'front3x3s2': 'st::front_s2_csp_kernel', 'pwres': 'st::pw_resident_kernel',
+              'wino32tail': 'st::wino_csp_tail_kernel',   # round 6: stage-1 bottleneck conv2 (Winograd) + final_conv in one launch
               'headpred': 'st::head_pred_kernel'}   # (a VALU reduction, listed with the conv ops it replaces)
     fam = {}
     for name, v in per_variant.items():
@@ -207,8 +210,11 @@ def conv_roofline(pipe, img, right, steps):
     # the Winograd family that is the direct-convolution count / 2.25 (F(2x2,3x3) issues 16 of every 36 multiplies),
     # which goes into `algorithmic_speedup`, never into `frac`.
     WINO = 'st::wino_conv3x3_kernel'
+    # the fused CSP tail executes its 3x3 conv (9 x 32 x 32 MACs per pixel) in Winograd form (/ 2.25 = 4096 MACs) and its 1x1
+    # conv (64 x 64 = 4096 MACs) directly: 13312 direct MACs per pixel, 8192 executed
+    SPEED = {WINO: 2.25, 'st::wino_csp_tail_kernel': 13312.0 / 8192.0}
     for f, e in fam.items():
-        speed = 2.25 if f == WINO else 1.0
+        speed = SPEED.get(f, 1.0)
         raw = e['ms_per_step']
         e['ms_per_step_raw_events'] = round(raw, 4)
         e['ms_per_step'] = max(raw - e['event_pairs'] * null_ms, 1e-6)

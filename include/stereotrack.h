@@ -115,6 +115,19 @@ size_t st_front_frag_floats(int Cout, int Cin);
 int st_front_pack_frags(const float* packed_wgt_host, int Cout, int Cin, float* out_host);
 int st_conv3x3s2_csp_front(const StConvDesc* a, const StConvDesc* ms, const StConvDesc* c1, const float* frag_ms_dev,
                            const float* frag_c1_dev, st_stream_t stream);
+/* Fused TAIL of a stage-1 CSP branch (round 6, tile variant 56): `conv2` = DarknetBottleneck conv2 (3x3 / stride 1 /
+ * pad 1, 32 -> 32, SiLU, with the identity in conv2->res) whose output tensor conv2->out1 (the first 32 channels of the
+ * CSP concat) is NEVER written, `fin` = CSPLayer final_conv (1x1, 64 -> 64, SiLU) reading that concat (fin->in_dev ==
+ * conv2->out1_dev, same ld / offset; its channels [32, 64) = the `short` half must already be in memory), with an
+ * optional residual on `fin` = the two-branch average (v + other) * post_scale of
+ * csp_darknet_disparity_v1.py:155-184.  One PERSISTENT launch instead of two: Winograd F(2x2,3x3) with the transformed
+ * 32 x 32 weights resident in registers, conv2's output handed to the 1x1 GEMM through LDS.  Replaces the module
+ * sequence mmdet CSPLayer builds behind its first bottleneck (reference csp_darknet_disparity_v1.py:145-153, run at
+ * :176-184).  conv2 needs wgt_wino_dev; frag_fin_dev = st_csp_tail_pack_frags of fin's packed weight matrix (device
+ * copy, st_csp_tail_frag_floats() floats).  ST_ERR_INVALID when the shapes differ. */
+size_t st_csp_tail_frag_floats(void);
+int st_csp_tail_pack_frags(const float* packed_wgt_host, float* out_host);
+int st_conv3x3_csp_tail(const StConvDesc* conv2, const StConvDesc* fin, const float* frag_fin_dev, st_stream_t stream);
 /* Pack one Conv2d weight [Cout][Cin][KH][KW] (+ optional BN, folded in fp64)
  * into the kernel layout above.  Host function; out buffers are host memory
  * of st_conv_packed_floats(...) / roundup(Cout,32) floats. */

@@ -85,6 +85,9 @@ _PROTOS = {
     'st_front_frag_floats': (_sz, [_i, _i]),
     'st_front_pack_frags': (_i, [_vp, _i, _i, _vp]),
     'st_conv3x3s2_csp_front': (_i, [C.POINTER(StConvDesc), C.POINTER(StConvDesc), C.POINTER(StConvDesc), _vp, _vp, _vp]),
+    'st_csp_tail_frag_floats': (_sz, []),
+    'st_csp_tail_pack_frags': (_i, [_vp, _vp]),
+    'st_conv3x3_csp_tail': (_i, [C.POINTER(StConvDesc), C.POINTER(StConvDesc), _vp, _vp]),
     'st_conv_packed_floats': (_sz, [_i, _i, _i, _i]),
     'st_wino_packed_floats': (_sz, [_i, _i]),
     'st_wino_pack_weights': (_i, [_vp, _i, _i, _vp]),

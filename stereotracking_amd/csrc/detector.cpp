@@ -50,6 +50,10 @@ int front_fused_launch(const StConvDesc& a, const StConvDesc& ms, const StConvDe
                        const float* frag_c1_dev, hipStream_t stream);
 size_t front_frag_floats(int Cout, int Cin);
 int front_pack_frags(const float* packed, int Cout, int Cin, float* out);
+bool csp_tail_applicable(const StConvDesc& c2, const StConvDesc& f);
+int csp_tail_launch(const StConvDesc& c2, const StConvDesc& f, const float* frag_fin_dev, hipStream_t stream);
+size_t csp_tail_frag_floats();
+int csp_tail_pack_frags(const float* packed, float* out);
 int conv_variant_count();
 bool conv_variant_valid(int id, int cout);
 const char* conv_variant_name(int id);
@@ -110,6 +114,8 @@ struct PackedConv {
   bool wino = false;
   size_t frag_off = 0;               // MFMA-fragment-ordered copy of a 1x1 weight matrix (fused front kernel), 0 = none
   bool frag = false;
+  size_t tail_off = 0;               // fragment-ordered copy of a 64 x 64 final_conv matrix (fused CSP tail, wino_csp_tail.hip)
+  bool tail = false;
   bool stem = false;                 // fused Focus+stem layout (st_stem_pack_weights), cin = 12, k = 3
   int stem_planes = 3;               // image planes the fused stem reads (1: identical planes, summed weights)
 };
@@ -157,6 +163,8 @@ struct Op {
   int pred_pcc[3] = {-1, -1, -1}, pred_pcr[3] = {-1, -1, -1};
   int wgroup = 0;           // > 0: consecutive ops with the same wgroup are INDEPENDENT 3x3 convs (head towers of the
                             // three levels) and run as ONE grouped Winograd launch when all of them are tuned to it
+  bool tail_next = false;   // this bottleneck conv2 (3x3, 32 -> 32, + identity) and the NEXT op (the CSP final_conv, 64 -> 64)
+                            // are one persistent launch of wino_csp_tail.hip (variant 56) whenever both descriptors qualify
   bool front_next2 = false; // this 3x3/s2 conv and the NEXT TWO ops (CSP main|short, blocks.0.conv1) are one launch
                             // of front_fused.hip (variant 45) whenever the three descriptors qualify
 };
@@ -194,6 +202,7 @@ struct StDetector {
   bool no_wino = false;            // keep the autotuner off the Winograd instance (exact-MFMA-order A/B runs)
   bool allow_chain = true;         // fuse CSP main_conv -> bottleneck conv1 when both run on the streaming kernel
   bool allow_front = true;         // fuse stage1.0 -> main|short -> conv1 (front_fused.hip)
+  bool allow_tail = true;          // fuse the last bottleneck conv2 -> final_conv of the stage-1 CSP layers (wino_csp_tail.hip)
   bool allow_wgroup = true;        // head tower convs of the three levels as grouped Winograd launches
   int allow_split = 0;             // bit i: autotune may pick the split-operand (bf16x3) instance 50 + i (st_detector_set_split)
 #ifdef ST_ABLATION
@@ -352,7 +361,16 @@ struct StDetector {
     }
     if (!out.valid()) out = new_tensor(x.N, x.H, x.W, cout);
     const int pcf = packed_convmodules({p + ".final_conv"}, 2 * mid, {cout}, 1);
+    // stage-1 shape (conv2 32 -> 32 + identity, final 64 -> 64, no upsampled store): the last bottleneck's conv2 and the
+    // final conv can run as one persistent launch (its epilogue takes the residual / post_scale of the final conv)
+    const bool tailable = nblocks > 0 && mid == 32 && cout == 64 && identity && !up.valid() && ops.back().type == Op::CONV &&
+                          convs[ops.back().pc].k == 3 && convs[ops.back().pc].wino;
+    const size_t conv2_idx = ops.size() - 1;
     op_conv(pcf, cat, 1, out, -1, TRef(), up, res, post_scale);
+    if (tailable && ops[conv2_idx].group == ops.back().group && ops[conv2_idx].phase == ops.back().phase) {
+      ops[conv2_idx].tail_next = true;
+      convs[pcf].tail = true;
+    }
     return out;
   }
 
@@ -385,6 +403,7 @@ int StDetector::build() {
 #ifdef ST_ABLATION   // tools-only build: ST_NO_FUSED_STEM=1 forces the two-kernel path (A/B measurements)
   if (getenv("ST_NO_FUSED_STEM")) fused_stem = false;
   if (getenv("ST_NO_FUSED_FRONT")) allow_front = false;
+  if (getenv("ST_NO_FUSED_TAIL")) allow_tail = false;
   if (getenv("ST_NO_WINO_GROUP")) allow_wgroup = false;
 #endif
   TRef packed_rgb, stem_rgb;
@@ -577,6 +596,11 @@ int StDetector::build() {
       wgt_floats += front_frag_floats(pc.cout, pc.cin);
       wgt_floats = (wgt_floats + 63) & ~(size_t)63;
     }
+    if (pc.tail) {
+      pc.tail_off = wgt_floats;
+      wgt_floats += csp_tail_frag_floats();
+      wgt_floats = (wgt_floats + 63) & ~(size_t)63;
+    }
   }
   return ST_OK;
 }
@@ -666,6 +690,7 @@ extern "C" int st_detector_finalize(StDetector* det) {
     }
     if (pc.wino) ST_CHECK(wino_pack_weights(host.data() + pc.wgt_off, pc.cout, pc.cin, host.data() + pc.wino_off));
     if (pc.frag) ST_CHECK(front_pack_frags(host.data() + pc.wgt_off, pc.cout, pc.cin, host.data() + pc.frag_off));
+    if (pc.tail) ST_CHECK(csp_tail_pack_frags(host.data() + pc.wgt_off, host.data() + pc.tail_off));
   }
   if (!det->wgt_dev) ST_CHECK_HIP(hipMalloc(reinterpret_cast<void**>(&det->wgt_dev), det->wgt_floats * sizeof(float)));
   ST_CHECK_HIP(hipMemcpy(det->wgt_dev, host.data(), det->wgt_floats * sizeof(float), hipMemcpyHostToDevice));
@@ -842,6 +867,17 @@ int run_ops(StDetector* det, int phase_lo, int phase_hi, const float* const inpu
                                         det->wgt_dev + det->convs[det->ops[k + 2].pc].frag_off, stream));
             o.variant = fused_variant = 45;
             fused_left = 2;
+            chained = true;
+          }
+        }
+        if (!chained && !skipped && o.type == Op::CONV && o.tail_next && k + 1 < oe && det->force_variant < 0 &&
+            det->allow_tail && det->convs[det->ops[k + 1].pc].tail) {
+          const StConvDesc d2 = conv_desc(det, o, sbi * g.sb, ws, head);
+          const StConvDesc df = conv_desc(det, det->ops[k + 1], sbi * g.sb, ws, head);
+          if (csp_tail_applicable(d2, df)) {
+            ST_CHECK(csp_tail_launch(d2, df, det->wgt_dev + det->convs[det->ops[k + 1].pc].tail_off, stream));
+            o.variant = fused_variant = 56;
+            fused_left = 1;
             chained = true;
           }
         }
@@ -1113,10 +1149,10 @@ extern "C" int st_detector_set_split(StDetector* det, int allow) {
 // id 40 = the fused Focus+stem kernel (stem_focus_conv.hip), reported with the conv ops
 // id 41 = the streaming 1x1 kernel for narrow layers (pointwise_conv.hip)
 extern "C" const char* st_conv_variant_name(int id) {
-  return id == 47 ? "headpred" : id == 46 ? "pwres" : id == 45 ? "front3x3s2" : id == 40 ? "stem6x6s2" : id == 41 ? "pw128" : id == 42 ? "dc4x32" : id == 43 ? "wino2x2" : id == 44 ? "wino2x2n" : id == 48 ? "wino2x2g" : id == 49 ? "wino2x2g+" : id == 50 ? "split128x128" : id == 51 ? "split64x64" : id == 52 ? "split128x64" : id == 53 ? "split128x128k16" : id == 54 ? "split64x64k16" : id == 55 ? "split128x64k16" : conv_variant_name(id);
+  return id == 56 ? "wino32tail" : id == 47 ? "headpred" : id == 46 ? "pwres" : id == 45 ? "front3x3s2" : id == 40 ? "stem6x6s2" : id == 41 ? "pw128" : id == 42 ? "dc4x32" : id == 43 ? "wino2x2" : id == 44 ? "wino2x2n" : id == 48 ? "wino2x2g" : id == 49 ? "wino2x2g+" : id == 50 ? "split128x128" : id == 51 ? "split64x64" : id == 52 ? "split128x64" : id == 53 ? "split128x128k16" : id == 54 ? "split64x64k16" : id == 55 ? "split128x64k16" : conv_variant_name(id);
 }
 extern "C" const char* st_conv_variant_signature(int id) {
-  return id == 47 ? "head_pred" : id == 46 ? "pw_resident" : id == 45 ? "front_s2_csp" : id == 40 ? "stem_focus_conv" : id == 41 ? "pw_conv" : id == 42 ? "direct_conv3x3" : id >= 50 && id <= 55 ? "conv_split (bf16x3 operands)" : id == 43 ? "wino_conv3x3" : id == 48 ? "wino_conv3x3 grouped launch" : id == 49 ? "wino_conv3x3 grouped launch (rider: computed by the preceding op's launch)" : id == 44 ? "wino_conv3x3 narrow"
+  return id == 56 ? "wino_csp_tail (bottleneck conv2 + final_conv, persistent)" : id == 47 ? "head_pred" : id == 46 ? "pw_resident" : id == 45 ? "front_s2_csp" : id == 40 ? "stem_focus_conv" : id == 41 ? "pw_conv" : id == 42 ? "direct_conv3x3" : id >= 50 && id <= 55 ? "conv_split (bf16x3 operands)" : id == 43 ? "wino_conv3x3" : id == 48 ? "wino_conv3x3 grouped launch" : id == 49 ? "wino_conv3x3 grouped launch (rider: computed by the preceding op's launch)" : id == 44 ? "wino_conv3x3 narrow"
                                                               : conv_variant_signature(id);
 }
 

@@ -711,3 +711,110 @@ def test_product_library_refuses_the_parked_split_instances(cuda):
     from stereotracking_amd.pipeline import StereoDensePipeline
     with pytest.raises(RuntimeError, match='tools build'):
         StereoDensePipeline(1, (64, 64), 0.375, 0.33, 1, stereo=False, split_bf16=True)
+
+
+# ---- fused tail of a stage-1 CSP branch: bottleneck conv2 (Winograd, + identity) -> final_conv (1x1 on the concat) ----
+def _csp_tail(dev, N, H, W, avg, seed, in_ld=32, in_off=0):
+    """-> (fused output, conv2 of the unfused Winograd launch, final of the unfused launches, fp64 reference), NCHW."""
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(seed)
+    tmp = torch.randn(N, 32, H, W, generator=g)                       # bottleneck conv1 output = conv2 input
+    main = torch.randn(N, 32, H, W, generator=g)                      # identity of the bottleneck
+    short = torch.randn(N, 32, H, W, generator=g)                     # short_conv output: concat channels [32, 64)
+    other = torch.randn(N, 64, H, W, generator=g) if avg else None    # the other branch's stage output
+    w2 = torch.randn(32, 32, 3, 3, generator=g) / (3.0 * 32 ** 0.5)
+    b2 = torch.randn(32, generator=g) * 0.1
+    wf = torch.randn(64, 64, 1, 1, generator=g) / 8.0
+    bf = torch.randn(64, generator=g) * 0.1
+    nhwc = lambda t: t.permute(0, 2, 3, 1).contiguous()
+    xin = torch.randn(N, H, W, in_ld, generator=g) * 3.0
+    xin[..., in_off:in_off + 32] = nhwc(tmp)
+    xin = xin.to(dev)
+    cat = torch.full((N, H, W, 72), -777.0)                            # concat buffer: ld 72, conv2 -> [4, 36), short -> [36, 68)
+    cat[..., 36:68] = nhwc(short)
+    cat = cat.to(dev)
+    mainb, otherb = nhwc(main).to(dev), (nhwc(other).to(dev) if avg else None)
+    wp2, bp2 = pack(w2, b2)
+    wino = torch.empty(lib.st_wino_packed_floats(32, 32), dtype=torch.float32)
+    check(lib.st_wino_pack_weights(ptr(wp2), 32, 32, ptr(wino)), 'st_wino_pack_weights')
+    wpf, bpf = pack(wf, bf)
+    frag = torch.empty(lib.st_csp_tail_frag_floats(), dtype=torch.float32)
+    check(lib.st_csp_tail_pack_frags(ptr(wpf), ptr(frag)), 'st_csp_tail_pack_frags')
+    wp2d, bp2d, winod, wpfd, bpfd, fragd = (t.to(dev) for t in (wp2, bp2, wino, wpf, bpf, frag))
+    out = torch.full((N, H, W, 68), -777.0, device=dev)               # ld 68, off 4
+
+    def descs(cat_t, out_t):
+        c2 = StConvDesc()
+        c2.in_dev = xin.data_ptr(); c2.N, c2.Hi, c2.Wi, c2.Cin, c2.in_ld, c2.in_off = N, H, W, 32, in_ld, in_off
+        c2.wgt_dev = wp2d.data_ptr(); c2.bias_dev = bp2d.data_ptr(); c2.wgt_wino_dev = winod.data_ptr()
+        c2.Cout, c2.KH, c2.KW, c2.stride, c2.pad = 32, 3, 3, 1, 1
+        c2.out1_dev = cat_t.data_ptr(); c2.out1_ld, c2.out1_off, c2.split = 72, 4, 32
+        c2.res_dev = mainb.data_ptr(); c2.res_ld, c2.res_off = 32, 0
+        c2.post_scale, c2.act = 1.0, 1
+        f = StConvDesc()
+        f.in_dev = cat_t.data_ptr(); f.N, f.Hi, f.Wi, f.Cin, f.in_ld, f.in_off = N, H, W, 64, 72, 4
+        f.wgt_dev = wpfd.data_ptr(); f.bias_dev = bpfd.data_ptr()
+        f.Cout, f.KH, f.KW, f.stride, f.pad = 64, 1, 1, 1, 0
+        f.out1_dev = out_t.data_ptr(); f.out1_ld, f.out1_off, f.split = 68, 4, 64
+        if avg:
+            f.res_dev = otherb.data_ptr(); f.res_ld, f.res_off = 64, 0
+        f.post_scale, f.act = (0.5 if avg else 1.0), 1
+        return c2, f
+
+    stream = _lib.current_stream()
+    c2, f = descs(cat, out)
+    check(lib.st_conv3x3_csp_tail(C.byref(c2), C.byref(f), ptr(fragd), stream), 'st_conv3x3_csp_tail')
+    torch.cuda.synchronize()
+    o = out.cpu()
+    assert torch.all(o[..., :4] == -777.0), 'kernel wrote outside its channel slice'
+    assert torch.all(cat.cpu()[..., :36] == -777.0), 'the fused launch must not write conv2\'s output tensor'
+    fused = o[..., 4:].permute(0, 3, 1, 2)
+    # the two launches it replaces, on buffers of their own
+    cat2, out2 = cat.clone(), torch.full_like(out, -777.0)
+    c2u, fu = descs(cat2, out2)
+    check(lib.st_conv2d_nhwc_variant(C.byref(c2u), stream, 43), 'conv2')
+    check(lib.st_conv2d_nhwc(C.byref(fu), stream), 'final')
+    torch.cuda.synchronize()
+    conv2_unfused = cat2.cpu()[..., 4:36].permute(0, 3, 1, 2)
+    final_unfused = out2.cpu()[..., 4:].permute(0, 3, 1, 2)
+    y = ref_conv(tmp, w2, b2, 1, 1, 1, main, 1.0)
+    ref = ref_conv(torch.cat([y, short.double()], 1), wf, bf, 1, 0, 1, other, 0.5) if avg else \
+        ref_conv(torch.cat([y, short.double()], 1), wf, bf, 1, 0, 1)
+    # the same 1x1 in float64 on the UNFUSED launch's conv2 values: what the fused kernel must equal up to the fp32 rounding
+    # of its 64-term dot products alone (its conv2 arithmetic is that of the Winograd launch, instruction for instruction)
+    cat64 = torch.cat([conv2_unfused.double(), short.double()], 1)
+    ref_u = ref_conv(cat64, wf, bf, 1, 0, 1, other, 0.5) if avg else ref_conv(cat64, wf, bf, 1, 0, 1)
+    return fused, ref_u, final_unfused, ref
+
+
+@pytest.mark.parametrize('N,H,W,avg,in_ld,in_off', [
+    (2, 24, 48, False, 32, 0),      # exact tile blocks (16 x 8 pixels)
+    (1, 23, 41, True, 32, 0),       # ragged in x and y, with the two-branch average
+    (3, 46, 80, True, 36, 4),       # conv2 input = a channel slice (the fused front kernel stores conv1 at ld 36, off 4)
+    (1, 5, 7, False, 32, 0),        # image smaller than one tile block
+    (2, 184, 320, False, 32, 0),    # the stage-1 map of the benched configuration: every persistent workgroup loops
+])
+def test_csp_tail_fused_kernel_matches_the_two_launches(N, H, W, avg, in_ld, in_off, cuda):
+    """st_conv3x3_csp_tail (csrc/wino_csp_tail.hip, tile variant 56): bottleneck conv2 + identity -> final_conv (+ average)
+    in one persistent launch == the Winograd launch followed by the 1x1 launch, and == the fp64 module composition
+    (reference csp_darknet_disparity_v1.py:145-153 / mmdet CSPLayer)."""
+    fused, ref_u, final_u, ref = _csp_tail(cuda, N, H, W, avg, seed=N * 1000 + H + W, in_ld=in_ld, in_off=in_off)
+    assert_close(fused, ref)
+    assert_close(fused, final_u.double(), tol=2e-5)
+    assert_close(fused, ref_u, tol=4e-6)      # only the 1x1's own fp32 rounding separates them
+
+
+def test_csp_tail_rejects_other_shapes(cuda):
+    lib = _lib.load()
+    x = torch.zeros(1, 8, 8, 64, device=cuda)
+    c2, f = StConvDesc(), StConvDesc()
+    c2.in_dev = x.data_ptr(); c2.N, c2.Hi, c2.Wi, c2.Cin, c2.in_ld, c2.in_off = 1, 8, 8, 64, 64, 0
+    c2.wgt_dev = x.data_ptr(); c2.bias_dev = x.data_ptr(); c2.wgt_wino_dev = x.data_ptr(); c2.res_dev = x.data_ptr()
+    c2.Cout, c2.KH, c2.KW, c2.stride, c2.pad, c2.act = 64, 3, 3, 1, 1, 1
+    c2.out1_dev = x.data_ptr(); c2.out1_ld, c2.out1_off, c2.split = 64, 0, 64
+    f.in_dev = x.data_ptr(); f.N, f.Hi, f.Wi, f.Cin, f.in_ld, f.in_off = 1, 8, 8, 64, 64, 0
+    f.wgt_dev = x.data_ptr(); f.bias_dev = x.data_ptr()
+    f.Cout, f.KH, f.KW, f.stride, f.pad, f.act = 64, 1, 1, 1, 0, 1
+    f.out1_dev = x.data_ptr(); f.out1_ld, f.out1_off, f.split = 64, 0, 64
+    assert lib.st_conv3x3_csp_tail(C.byref(c2), C.byref(f), ptr(x), None) != 0      # 64 -> 64 conv2 is not the tail shape
+    assert 'csp tail' in lib.st_last_error().decode()
