@@ -239,6 +239,17 @@ __global__ __launch_bounds__(256, 2) void wino_csp_tail_kernel(const TailArgs p)
     // dropped: TWO window buffers - the next window requested a whole block ahead - with the 1x1 weights streamed from L2
     // instead of LDS to stay at two workgroups per CU: 254 against 234 us at N = 16, tools/tail_bench.py.)
     if (blk + gridDim.x < p.nblocks) dma_window(blk + gridDim.x);
+    f32x4 r2v[2][4];
+    if (AVG) {   // the other branch's output for this lane's pixel, in accumulator layout
+#pragma unroll
+      for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const unsigned off = okp ? (unsigned)((mp * p.res2_ld + p.res2_off + 32 * mb + 8 * q + 4 * h) * 4) : 0x80000000u;
+          r2v[mb][q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(arsrc, off, 0, 0));
+        }
+    }
+
     // ---- output transform, columns + conv2 epilogue.  ALL reads of Rb first: the operand tile written below aliases them
     const int t = a * 8 + txo;
     f32x4 q4[2][4];
@@ -268,17 +279,6 @@ __global__ __launch_bounds__(256, 2) void wino_csp_tail_kernel(const TailArgs p)
     f32x4 yv[4];
 #pragma unroll
     for (int g = 0; g < 4; ++g) yv[g] = *reinterpret_cast<const f32x4*>(Rb + yoff(nn, 2 * g + h));
-    f32x4 r2v[2][4];
-    if (AVG) {   // the other branch's output for this lane's pixel, in accumulator layout
-#pragma unroll
-      for (int mb = 0; mb < 2; ++mb)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const unsigned off = okp ? (unsigned)((mp * p.res2_ld + p.res2_off + 32 * mb + 8 * q + 4 * h) * 4) : 0x80000000u;
-          r2v[mb][q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(arsrc, off, 0, 0));
-        }
-    }
-
     __builtin_amdgcn_s_setprio(0);
     f32x16 acc2[2];
 #pragma unroll
