@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define ST_VERSION 420
+#define ST_VERSION 430
 
 enum {
   ST_OK = 0,

@@ -16,11 +16,12 @@
 //     the concat is loaded from HBM directly in operand layout, the 64 x 64 weights sit in LDS in fragment order;
 //   * the 1x1 GEMM runs with SWAPPED operands (A = weights, B = pixels), so a lane ends with 4 consecutive couts of one
 //     pixel per accumulator quad: 16-byte NHWC stores, 16-byte loads of the other branch for the average.
-// Per tile block and wave: 64 + 64 MFMAs (32x32x2 fp32), two workgroup barriers; the next block's input window travels
+// Per tile block and wave: 64 MFMAs 32x32x2 + 128 MFMAs 16x16x4 (the same matrix cycles), two workgroup barriers; the next block's input window travels
 // by LDS-DMA while the current block's epilogue and 1x1 GEMM run.  LDS: window 23 KB + transform exchange 32 KB (the 1x1
 // operand tiles alias the part of it only their own wave reads) + final weights 16 KB = 71 KB -> two workgroups per CU.
-// conv2's arithmetic is instruction for instruction that of wino_conv3x3_kernel<1,1,true>: its values are bit-identical
-// to the unfused launch; the 1x1 GEMM sums in another order than pw_resident_kernel (fp32 rounding only).
+// Both halves repeat the arithmetic of the launches they replace instruction for instruction - conv2 that of
+// wino_conv3x3_kernel<1, 1, true>, the 1x1 GEMM that of pw_resident_kernel<4, 4, 0, RES> (16x16x4 MFMA, same K walk, bias
+// in the accumulator) - so the fused launch returns the unfused pair's values BIT FOR BIT (tests/test_conv_gpu.py).
 #include <algorithm>
 #include <cstdint>
 #include <cstdlib>
@@ -140,11 +141,11 @@ __global__ __launch_bounds__(256, 2) void wino_csp_tail_kernel(const TailArgs p)
   const int hs10 = (h ^ ((qb1 >> 1) & 7)) << 2, hs11 = (h ^ (((qb1 >> 1) + 1) & 7)) << 2;
   const float* wrow0 = win + qb0 * 32;
   const float* wrow1 = win + qb1 * 32;
-  // epilogue lane roles.  Column reduce: tile txo of tile row a, couts c4 .. c4 + 3.  1x1 GEMM: pixel nn of the wave's 32
-  // (tile nn >> 2, row (nn >> 1) & 1, column nn & 1), K half h.
+  // epilogue lane roles.  Column reduce: tile txo of tile row a, couts c4 .. c4 + 3.  1x1 GEMM (16x16x4 MFMA, two pixel
+  // tiles of 16): pixels n = 16 pt + i16 of the wave's 32 (tile n >> 2, row (n >> 1) & 1, column n & 1), K quarter kq.
   const int txo = lane >> 3, c4 = (lane & 7) * 4;
   const f32x4 bias4 = *reinterpret_cast<const f32x4*>(p.bias2 + c4);
-  const int nn = lane & 31;
+  const int i16 = lane & 15, kq = lane >> 4;
   // operand tile of wave a inside Rb: pixel n, 16-byte slot s -> float offset; rows = the planes k = n >> 3 (k < 4) of
   // tiles 8a .. 8a + 7, which only wave a reads in the column reduce
   auto yoff = [&](int n, int s) { return (((n >> 3) * 32 + 8 * a) * 32) + (n & 7) * 32 + ((s ^ (n & 7)) << 2); };
@@ -164,9 +165,15 @@ __global__ __launch_bounds__(256, 2) void wino_csp_tail_kernel(const TailArgs p)
     const int by = (int)(rr % (unsigned)p.tby), n = (int)(rr / (unsigned)p.tby);
 
     // ---- early load: the identity of conv2's epilogue (needed right behind the barrier below)
-    const int oyp = by * (2 * CT_TY) + 2 * a + ((nn >> 1) & 1), oxp = bx * (2 * CT_TX) + 2 * (nn >> 2) + (nn & 1);
-    const bool okp = oyp < p.H && oxp < p.W;
-    const int mp = (n * p.H + oyp) * p.W + oxp;
+    bool okp[2];
+    int mp[2];
+#pragma unroll
+    for (int pt = 0; pt < 2; ++pt) {
+      const int nn = 16 * pt + i16;
+      const int oyp = by * (2 * CT_TY) + 2 * a + ((nn >> 1) & 1), oxp = bx * (2 * CT_TX) + 2 * (nn >> 2) + (nn & 1);
+      okp[pt] = oyp < p.H && oxp < p.W;
+      mp[pt] = (n * p.H + oyp) * p.W + oxp;
+    }
     f32x4 rv[2][2];   // [j][ii]
 #pragma unroll
     for (int j = 0; j < 2; ++j)
@@ -208,12 +215,13 @@ __global__ __launch_bounds__(256, 2) void wino_csp_tail_kernel(const TailArgs p)
     }
 
     // `short` in operand layout for the 1x1 GEMM: requested here (the patch registers are free again), used last
-    f32x4 shv[4];
-    {
-      const unsigned off = okp ? (unsigned)((mp * p.sh_ld + p.sh_off + 4 * h) * 4) : 0x80000000u;
+    f32x4 shv[2][2];   // [pixel tile][channel group of 16]: channels 32 + 16 gg + 4 kq .. + 3 of the concat
 #pragma unroll
-      for (int g = 0; g < 4; ++g)
-        shv[g] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(srsrc, off, g * 32, 0));
+    for (int pt = 0; pt < 2; ++pt) {
+      const unsigned off = okp[pt] ? (unsigned)((mp[pt] * p.sh_ld + p.sh_off + 4 * kq) * 4) : 0x80000000u;
+#pragma unroll
+      for (int gg = 0; gg < 2; ++gg)
+        shv[pt][gg] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(srsrc, off, gg * 64, 0));
     }
     __builtin_amdgcn_s_setprio(2);
     // ---- output transform, rows: R[0] = M0 + M1 + M2, R[1] = M1 - M2 - M3 (registers -> Rb)
@@ -239,17 +247,16 @@ __global__ __launch_bounds__(256, 2) void wino_csp_tail_kernel(const TailArgs p)
     // dropped: TWO window buffers - the next window requested a whole block ahead - with the 1x1 weights streamed from L2
     // instead of LDS to stay at two workgroups per CU: 254 against 234 us at N = 16, tools/tail_bench.py.)
     if (blk + gridDim.x < p.nblocks) dma_window(blk + gridDim.x);
-    f32x4 r2v[2][4];
-    if (AVG) {   // the other branch's output for this lane's pixel, in accumulator layout
+    f32x4 r2v[2][4];   // [pixel tile][cout block of 16]
+    if (AVG) {   // the other branch's output for this lane's pixels, in accumulator layout
 #pragma unroll
-      for (int mb = 0; mb < 2; ++mb)
+      for (int pt = 0; pt < 2; ++pt)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const unsigned off = okp ? (unsigned)((mp * p.res2_ld + p.res2_off + 32 * mb + 8 * q + 4 * h) * 4) : 0x80000000u;
-          r2v[mb][q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(arsrc, off, 0, 0));
+        for (int cb = 0; cb < 4; ++cb) {
+          const unsigned off = okp[pt] ? (unsigned)((mp[pt] * p.res2_ld + p.res2_off + 16 * cb + 4 * kq) * 4) : 0x80000000u;
+          r2v[pt][cb] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(arsrc, off, 0, 0));
         }
     }
-
     // ---- output transform, columns + conv2 epilogue.  ALL reads of Rb first: the operand tile written below aliases them
     const int t = a * 8 + txo;
     f32x4 q4[2][4];
@@ -275,42 +282,52 @@ __global__ __launch_bounds__(256, 2) void wino_csp_tail_kernel(const TailArgs p)
         *reinterpret_cast<f32x4*>(Rb + yoff(txo * 4 + ii * 2 + j, lane & 7)) = v;
       }
     }
-    // ---- 1x1 GEMM, swapped operands: D[cout][pixel] = sum_ci Wf[cout][ci] * act[ci][pixel]
-    f32x4 yv[4];
+    // ---- 1x1 GEMM, swapped operands: D[cout][pixel] = sum_ci Wf[cout][ci] * act[ci][pixel].  Instruction for instruction
+    // the arithmetic of pw_resident_kernel<4, 4, 0, RES> (the launch this replaces): v_mfma_f32_16x16x4_f32, accumulators
+    // started from the bias, K walked as g = 0..3 (16 channels), s = 0..3, one MFMA = channels 16 g + s + {0, 4, 8, 12} -
+    // so the fused launch returns the unfused pair's values BIT FOR BIT.
+    f32x4 yv[2][2];
 #pragma unroll
-    for (int g = 0; g < 4; ++g) yv[g] = *reinterpret_cast<const f32x4*>(Rb + yoff(nn, 2 * g + h));
+    for (int pt = 0; pt < 2; ++pt)
+#pragma unroll
+      for (int gg = 0; gg < 2; ++gg) yv[pt][gg] = *reinterpret_cast<const f32x4*>(Rb + yoff(16 * pt + i16, 4 * gg + kq));
     __builtin_amdgcn_s_setprio(0);
-    f32x16 acc2[2];
+    f32x4 acc2[2][4];
 #pragma unroll
-    for (int mb = 0; mb < 2; ++mb)
+    for (int cb = 0; cb < 4; ++cb) {
+      const f32x4 bf = *reinterpret_cast<const f32x4*>(Bf + 16 * cb + 4 * kq);
+      acc2[0][cb] = bf;
+      acc2[1][cb] = bf;
+    }
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc2[mb][r] = 0.f;
+    for (int g = 0; g < 4; ++g) {
+      f32x4 wfr[4];
 #pragma unroll
-    for (int G = 0; G < 8; ++G) {
-      const f32x4 act = G < 4 ? yv[G & 3] : shv[G & 3];
+      for (int cb = 0; cb < 4; ++cb) wfr[cb] = *reinterpret_cast<const f32x4*>(Wf + ((cb * 4 + g) * 64 + lane) * 4);
 #pragma unroll
-      for (int mb = 0; mb < 2; ++mb) {
-        const f32x4 wfr = *reinterpret_cast<const f32x4*>(Wf + ((mb * 8 + G) * 64 + lane) * 4);
+      for (int s4 = 0; s4 < 4; ++s4)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) acc2[mb] = __builtin_amdgcn_mfma_f32_32x32x2f32(wfr[e], act[e], acc2[mb], 0, 0, 0);
-      }
+        for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+          for (int pt = 0; pt < 2; ++pt) {
+            const f32x4 xf = g < 2 ? yv[pt][g & 1] : shv[pt][g & 1];
+            acc2[pt][cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(wfr[cb][s4], xf[s4], acc2[pt][cb], 0, 0, 0);
+          }
     }
     __builtin_amdgcn_s_setprio(2);
-    // ---- final epilogue: lane = pixel nn, accumulator quad q = couts 32 mb + 8 q + 4 h .. + 3
+    // ---- final epilogue: lane = pixel 16 pt + i16, accumulator = couts 16 cb + 4 kq .. + 3
 #pragma unroll
-    for (int mb = 0; mb < 2; ++mb)
+    for (int pt = 0; pt < 2; ++pt)
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int co = 32 * mb + 8 * q + 4 * h;
-        const f32x4 bf = *reinterpret_cast<const f32x4*>(Bf + co);
-        f32x4 v;
+      for (int cb = 0; cb < 4; ++cb) {
+        f32x4 v = acc2[pt][cb];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = wn_silu(acc2[mb][4 * q + e] + bf[e]);
+        for (int e = 0; e < 4; ++e) v[e] = wn_silu(v[e]);
         if (AVG) {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = (v[e] + r2v[mb][q][e]) * p.postf;
+          for (int e = 0; e < 4; ++e) v[e] = (v[e] + r2v[pt][cb][e]) * p.postf;
         }
-        const unsigned off = okp ? (unsigned)((mp * p.out_ld + p.out_off + co) * 4) : 0x80000000u;
+        const unsigned off = okp[pt] ? (unsigned)((mp[pt] * p.out_ld + p.out_off + 16 * cb + 4 * kq) * 4) : 0x80000000u;
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), orsrc, off, 0, 0);
       }
   }
@@ -321,15 +338,16 @@ __global__ __launch_bounds__(256, 2) void wino_csp_tail_kernel(const TailArgs p)
 
 size_t csp_tail_frag_floats() { return (size_t)CT_WF_FLOATS; }
 
-// packed: the final conv's folded fp32 weights [64][Kpad = 64] (K index = ci).  out[((mb * 8 + G) * 64 + l) * 4 + e] =
-// W[co = 32 mb + (l & 31)][ci = 8 G + 4 (l >> 5) + e]: one 16-byte LDS read per lane = the A operands of 4 MFMA steps.
+// packed: the final conv's folded fp32 weights [64][Kpad = 64] (K index = ci).  out[((cb * 4 + g) * 64 + l) * 4 + e] =
+// W[co = 16 cb + (l & 15)][ci = 16 g + 4 (l >> 4) + e]: pw_resident_kernel's weight image - one 16-byte LDS read per lane =
+// the A operands of 4 MFMA steps.
 int csp_tail_pack_frags(const float* packed, float* out) {
   ST_REQUIRE(packed && out, "csp_tail_pack_frags: null pointer");
-  for (int mb = 0; mb < 2; ++mb)
-    for (int G = 0; G < 8; ++G)
+  for (int cb = 0; cb < 4; ++cb)
+    for (int g = 0; g < 4; ++g)
       for (int l = 0; l < 64; ++l)
         for (int e = 0; e < 4; ++e)
-          out[((mb * 8 + G) * 64 + l) * 4 + e] = packed[(size_t)(32 * mb + (l & 31)) * 64 + 8 * G + 4 * (l >> 5) + e];
+          out[((cb * 4 + g) * 64 + l) * 4 + e] = packed[(size_t)(16 * cb + (l & 15)) * 64 + 16 * g + 4 * (l >> 4) + e];
   return ST_OK;
 }
 

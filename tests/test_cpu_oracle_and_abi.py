@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol(stlib):
     for n in names:
         assert hasattr(stlib, n), f'{n} declared in include/stereotrack.h but not exported'
         assert n in _lib._PROTOS, f'{n} has no ctypes prototype'
-    assert stlib.st_version() == 420      # ST_VERSION of include/stereotrack.h (also keys the tuning cache)
+    assert stlib.st_version() == 430      # ST_VERSION of include/stereotrack.h (also keys the tuning cache)
 
 
 @pytest.mark.parametrize('nc,multi_label', [(3, False), (6, True), (6, False), (80, False)])
