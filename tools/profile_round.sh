@@ -1,9 +1,10 @@
 #!/bin/bash
 # Round profile on the GPU box (run through gpurun): kernel durations (serialized and with the in-flight contexts),
-# MFMA-pipe utilisation and HBM traffic per kernel.  Outputs under gpurun_out/prof_$1; summaries are then copied to
+# MFMA-pipe utilisation and HBM traffic per kernel.  Since round 6 bench.py's default run includes the full-resolution and 3-D
+# aggregation legs, so the kernel-stats passes below hold every kernel of DESIGN.md 4 of the shipped binary.  Outputs under gpurun_out/prof_$1; summaries are then copied to
 # profiles/ by hand.  rocprofv3 gets the program itself after `--` (no wrapper), counters in their own passes.
 set -e
-TAG=${1:-r05}
+TAG=${1:-r06}
 OUT=gpurun_out/prof_$TAG
 rm -rf $OUT      # stale traces of an earlier call must not be picked up below
 mkdir -p $OUT
@@ -15,10 +16,13 @@ cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$OUT/stats_inflight1 -- python3 $R/bench.py $COMMON --inflight 1 > $R/$OUT/bench_rocprof_inflight1.json 2> $R/$OUT/rocprof1.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$OUT/stats_inflight -- python3 $R/bench.py $COMMON > $R/$OUT/bench_rocprof_inflight.json 2> $R/$OUT/rocprof3.err
-PM="--steps 4 --warmup 2 --no-cpu-baseline --no-test-step --sustain-seconds 0 --inflight 1"
+# counter passes: the headline loop only (no secondary legs) - except FETCH / WRITE, which also cover the stereo module's
+# full-resolution and 3-D legs (cv_agg3d_kernel, vol_agg3d_kernel, softargmin_reg_kernel, feat_upsample_kernel)
+PM="--steps 4 --warmup 2 --no-cpu-baseline --no-test-step --sustain-seconds 0 --inflight 1 --no-secondary-legs"
+PMLEGS="--steps 4 --warmup 2 --no-cpu-baseline --no-test-step --sustain-seconds 0 --inflight 1"
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CU_CYCLES --kernel-trace --output-format csv -d $R/$OUT/pmc_mfma -- python3 $R/bench.py $PM > /dev/null 2> $R/$OUT/pmc_mfma.err
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $R/$OUT/pmc_fetch -- python3 $R/bench.py $PM > /dev/null 2> $R/$OUT/pmc_fetch.err
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $R/$OUT/pmc_write -- python3 $R/bench.py $PM > /dev/null 2> $R/$OUT/pmc_write.err
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $R/$OUT/pmc_fetch -- python3 $R/bench.py $PMLEGS > /dev/null 2> $R/$OUT/pmc_fetch.err
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $R/$OUT/pmc_write -- python3 $R/bench.py $PMLEGS > /dev/null 2> $R/$OUT/pmc_write.err
 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_SALU GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $R/$OUT/pmc_valu1 -- python3 $R/bench.py $PM > /dev/null 2> $R/$OUT/pmc_valu1.err
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_VALU_MFMA_COEXEC_CYCLES SQ_ACTIVE_INST_VALU --kernel-trace --output-format csv -d $R/$OUT/pmc_valu2 -- python3 $R/bench.py $PM > /dev/null 2> $R/$OUT/pmc_valu2.err
 cd $R
