@@ -597,9 +597,20 @@ def fullres_leg(args, inputs, batch_cpu, headline, plan, dev):
         cv_b = vol_bytes + 2 * 4.0 * B * H * W * 8
         def hbm(ms, nbytes):
             return dict(ms=round(ms, 3), bytes=int(nbytes), frac_of_8TBs=round(nbytes / (ms * 1e-3) / 8e12, 4))
-        kern = dict(softargmin_pack=hbm(stages['softargmin_pack'], vol_bytes),
-                    features_reduce_upsample_ms=round(stages['features_reduce_upsample'], 3))
-        if 'cost_volume_agg3d_first' in stages:     # one pass: features in, aggregated volume out (st_costvolume_agg3d)
+        kern = dict(features_reduce_upsample_ms=round(stages['features_reduce_upsample'], 3))
+        if 'softargmin_pack' in stages:
+            kern['softargmin_pack'] = hbm(stages['softargmin_pack'], vol_bytes)
+        if 'cost_volume_agg3d_softargmin' in stages:
+            # round 6: cost volume + the 3-D layer + soft-argmin in ONE kernel (st_costvolume_agg3d_softargmin): features in,
+            # disparity out; the D-level volume is neither written nor read back.  `bytes` keeps the algorithmic traffic of the
+            # materialised form it replaces (volume written once + read once) so the fraction compares with earlier rounds;
+            # `bytes_moved` is what this kernel itself must move (features + disparity)
+            fb = 2 * 4.0 * B * H * W * 8 + 4.0 * B * H * W
+            kern['cost_volume_agg3d_softargmin_fused'] = dict(
+                hbm(stages['cost_volume_agg3d_softargmin'], cv_b + vol_bytes), bytes_moved=int(fb),
+                valu_tflops=round(2.0 * (27 + 8) * B * H * W * D / (stages['cost_volume_agg3d_softargmin'] * 1e-3) / 1e12, 1))
+            kern['pack_ms'] = round(stages['pack'], 3)
+        elif 'cost_volume_agg3d_first' in stages:     # one pass: features in, aggregated volume out (st_costvolume_agg3d)
             kern['cost_volume_agg3d_fused'] = dict(hbm(stages['cost_volume_agg3d_first'], cv_b),
                                                    valu_tflops=round(2.0 * (27 + 8) * B * H * W * D / (stages['cost_volume_agg3d_first'] * 1e-3) / 1e12, 1))
         else:
@@ -607,14 +618,19 @@ def fullres_leg(args, inputs, batch_cpu, headline, plan, dev):
             kern['agg3d'] = hbm(stages['agg3d'], 2 * vol_bytes)
         # the leg's roofline object: its dominant kernel = the fused cost volume + first 3-D layer (features read once,
         # aggregated volume written once); the other kernels of the stage listed beside it with their own fractions
-        dom_name = 'cost_volume_agg3d_fused' if 'cost_volume_agg3d_fused' in kern else 'cost_volume'
+        dom_name = ('cost_volume_agg3d_softargmin_fused' if 'cost_volume_agg3d_softargmin_fused' in kern else
+                    'cost_volume_agg3d_fused' if 'cost_volume_agg3d_fused' in kern else 'cost_volume')
         dom = kern[dom_name]
-        leg_roof = dict(bound='hbm', kernel='st::cv_agg3d_kernel' if dom_name == 'cost_volume_agg3d_fused' else 'st::costvolume_tiled_kernel',
+        leg_roof = dict(bound='hbm', kernel='st::cv_agg3d_kernel<..., SA>' if dom_name == 'cost_volume_agg3d_softargmin_fused' else
+                        'st::cv_agg3d_kernel' if dom_name == 'cost_volume_agg3d_fused' else 'st::costvolume_tiled_kernel',
                         unit='GB/s', peak=8000.0, bytes_per_launch=dom['bytes'], avg_launch_us=round(dom['ms'] * 1e3, 1),
                         achieved=round(dom['bytes'] / (dom['ms'] * 1e-3) / 1e9, 1), frac=dom['frac_of_8TBs'],
                         valu_tflops=dom.get('valu_tflops'),
                         note='VALU-bound by its counters (35 fp32 FMAs per cell, vector ALU busy 0.86): the HBM fraction is the '
-                             'contract\'s figure, not its bound',
+                             'contract\'s figure, not its bound; for the single-kernel form `bytes_per_launch` is the algorithmic '
+                             'traffic of the materialised form it replaces (features + volume written + volume read), kept for '
+                             'comparison across rounds - the kernel itself moves `bytes_moved`',
+                        bytes_moved=dom.get('bytes_moved'),
                         stage_bytes_per_step=int(cv_b + vol_bytes),
                         stage_ms_per_step=round(sum(v['ms'] if isinstance(v, dict) else v for v in kern.values()), 3),
                         definition='one serialized pass of the stereo stage on one context, HIP events on the launch stream '

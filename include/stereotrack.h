@@ -394,6 +394,15 @@ int st_volume_agg3d(const float* vol_in_dev, float* vol_out_dev, int N, int Hf, 
 int st_costvolume_agg3d_supported(int C, int D);
 int st_costvolume_agg3d(const float* featL_dev, const float* featR_dev, int N, int H, int W, int C, int feat_ld, int D,
                         const float* weight27_host, float bias, int act, float* vol_out_dev, st_stream_t stream);
+/* Round 6: the same pass with the SOFT-ARGMIN of the aggregated volume taken inside the kernel - for a stereo module whose
+ * only 3-D layer this is (StereoCostVolume(full_res=True, agg3d_layers=1)): the D-level volume (4 D bytes per pixel, 5.8 GB
+ * per 8 pairs at D = 192 x 736 x 1280) is neither written nor read back.  disp_out_dev [N][H][W] px (float), as
+ * st_softargmin writes it; bit-equal to st_costvolume_agg3d followed by st_softargmin (specification
+ * oracle_costvolume -> oracle_agg3d -> oracle_softargmin).  Needs st_costvolume_agg3d_supported(C, D) and D in {48, 96, 192}
+ * (ST_ERR_INVALID otherwise: the caller takes st_costvolume_agg3d + st_softargmin, same results). */
+int st_costvolume_agg3d_softargmin(const float* featL_dev, const float* featR_dev, int N, int H, int W, int C, int feat_ld,
+                                   int D, const float* weight27_host, float bias, int act, float temperature,
+                                   float* disp_out_dev, st_stream_t stream);
 /* soft-argmin only, on an (aggregated) volume [N][Hf][Wf][D] */
 int st_softargmin(const float* cost_dev, int N, int Hf, int Wf, int D, float temperature,
                   float* out_disp_dev, st_stream_t stream);

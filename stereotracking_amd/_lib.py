@@ -144,6 +144,7 @@ _PROTOS = {
     'st_feat_upsample': (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     'st_costvolume_agg3d_supported': (_i, [_i, _i]),
     'st_costvolume_agg3d': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _f, _i, _vp, _vp]),
+    'st_costvolume_agg3d_softargmin': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _f, _i, _f, _vp, _vp]),
     'st_box_depth_workspace_bytes': (_sz, [_i, _i, _i, _i]),
     'st_pack_records': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     'st_box_depth': (_i, [_vp, _sz, _i, _i, _i, _vp, _vp, _i, _f, _f, _vp, _sz, _vp, _vp, _vp, _vp]),

@@ -170,6 +170,8 @@ struct CvAggArgs {
   float w[27];
   float bias;
   int act;
+  float temperature;          // SA form (st_costvolume_agg3d_softargmin): the soft-argmin of every aggregated row is taken
+  float* disp;                // in the kernel, [N][H][W] px; `out` is not written
 };
 
 
@@ -179,10 +181,12 @@ struct CvAggArgs {
 // the (w, w) pairs of those taps), tap i = 1 (odd pairs) as four scalar FMAs - per output the oracle's order j, k, i.  The
 // four pixels advance together: eight independent chains for the issue slots.  16-byte stores through `orsrc` (pixels
 // beyond the descriptor are dropped).  NOSTORE: tools only (the results stay alive, nothing is stored).
-template <bool NOSTORE>
+// LDSOUT: the four 16-byte results go to `ldsout + pi * ldspx` (an LDS row of the workgroup) instead of memory.
+template <bool NOSTORE, bool LDSOUT = false>
 __device__ __forceinline__ void a3_stencil_row(const f32x2 (&ra)[6][3], const f32x2 (&rb)[6][3], const f32x2 (&rc)[6][3],
                                                const f32x2 (&wp)[2][3][3], const float (&w)[27], float bias, int act,
-                                               __amdgpu_buffer_rsrc_t orsrc, int voff0, int pxbytes) {
+                                               __amdgpu_buffer_rsrc_t orsrc, int voff0, int pxbytes,
+                                               float* ldsout = nullptr, int ldspx = 0) {
   f32x2 p0[4], p1[4];
 #pragma unroll
   for (int pi = 0; pi < 4; ++pi) p0[pi] = p1[pi] = f32x2{bias, bias};
@@ -227,6 +231,7 @@ __device__ __forceinline__ void a3_stencil_row(const f32x2 (&ra)[6][3], const f3
 #pragma unroll
     for (int e = 0; e < 4; ++e) o[e] = act ? acc[e] / (1.0f + a3_expf(-acc[e])) : acc[e];
     if (NOSTORE) asm volatile("" ::"v"(o));
+    else if (LDSOUT) *reinterpret_cast<f32x4*>(ldsout + pi * ldspx) = o;
     else __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), orsrc, voff0 + pi * pxbytes, 0, 0);
   }
 }
@@ -246,7 +251,13 @@ __device__ __forceinline__ void a3_weight_pairs(const float (&w)[27], f32x2 (&wp
 }
 
 // DFIX: D == DMAX, known at compile time (every offset an immediate)
-template <int TW, int C, int DMAX, bool DFIX, int MODE = 0>   // MODE: timing-only ablations of the tools build (0 in the product)
+// SA (round 6, st_costvolume_agg3d_softargmin): the aggregated row does not leave the chip - the stencil's results go to an
+// LDS row [TW][D + 4], and behind the iteration's barrier the workgroup takes its soft-argmin: thread (pixel tid % TW, part
+// tid / TW) scales its 16 levels by the temperature and publishes their maximum, (barrier) takes the pixel's maximum and
+// replaces the levels by exp(T c - m) (the oracle's polynomial), (barrier) and one lane per pixel runs the oracle's two
+// running sums over the D exponentials IN ORDER (s += e; t = fmaf(d, e, t)) and stores t / s.  Bit-equal to
+// st_costvolume_agg3d followed by st_softargmin; the 4 D bytes per pixel of volume are neither written nor read back.
+template <int TW, int C, int DMAX, bool DFIX, int MODE = 0, bool SA = false>   // MODE: timing-only ablations of the tools build (0 in the product)
 __global__ __launch_bounds__(192) __attribute__((amdgpu_waves_per_eu(3))) void cv_agg3d_kernel(const CvAggArgs a) {
   constexpr int NT = 192, CQ = C / 4, NG = TW / 4, FLW = TW + 8;
   extern __shared__ float4 a3_smem4[];
@@ -259,6 +270,9 @@ __global__ __launch_bounds__(192) __attribute__((amdgpu_waves_per_eu(3))) void c
   float* costrow = lds;
   float* frs = costrow + (TW + 2) * DS;          // [C][FRW]: right-image pixels x0 - D .. x0 + TW + 3
   float* fls = frs + C * FRW;                    // [C][FLW]: left-image pixels x0 - 4 .. x0 + TW + 3
+  const int DSA = D + 4;                         // SA: aggregated row [TW][DSA] (16-byte rows, pixel stride off the banks)
+  float* aggrow = fls + C * FLW;
+  float* pmax = aggrow + TW * DSA;               // SA: [D / 16][TW] partial maxima
   // Workgroup -> (pair, band, strip).  Neighbouring strips share 196 of the 212 right-image pixels they stage per row;
   // workgroups are dealt to the 8 XCDs (own L2 each) round-robin, so in launch order every XCD ends up fetching the whole
   // feature row.  Order 1 gives each XCD a CONTIGUOUS range of the (pair, band, strip) sequence: neighbours share an L2.
@@ -400,10 +414,64 @@ __global__ __launch_bounds__(192) __attribute__((amdgpu_waves_per_eu(3))) void c
       // the strip's output row as a buffer: pixels beyond the image fall outside the descriptor and are dropped
       const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(
           a.out + (((size_t)n * a.H + y) * a.W + x0) * D, 0, min(TW, a.W - x0) * D * 4, 0x00020000);
-      a3_stencil_row<(MODE & 1) != 0>(ra, rb, rc, wp, a.w, a.bias, a.act, orsrc, ((4 * g) * D + 4 * q) * 4, D * 4);
+      a3_stencil_row<(MODE & 1) != 0, SA>(ra, rb, rc, wp, a.w, a.bias, a.act, orsrc, ((4 * g) * D + 4 * q) * 4, D * 4,
+                                          aggrow + (4 * g) * DSA + 4 * q, DSA);
     }
     if (r + 1 <= y1) store_feat();
     __syncthreads();
+    if (SA && OUT) {                             // soft-argmin of output row y (uniform branch)
+      const int spx = tid % TW, part = tid / TW;
+      const bool has = part < (D >> 4);
+      float* lv = aggrow + spx * DSA + 16 * part;
+      if (has) {
+        float m = -__builtin_inff();
+#pragma unroll
+        for (int i4 = 0; i4 < 4; ++i4) {
+          const f32x4 v = *reinterpret_cast<const f32x4*>(lv + 4 * i4);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) m = fmaxf(m, a.temperature * v[e]);
+        }
+        pmax[part * TW + spx] = m;
+      }
+      __syncthreads();
+      if (has) {   // (the levels are read again rather than kept: the three register rows of the stencil stay live across this)
+        float m = pmax[spx];
+        for (int pp = 1; pp < (D >> 4); ++pp) m = fmaxf(m, pmax[pp * TW + spx]);
+#pragma unroll
+        for (int i4 = 0; i4 < 4; ++i4) {
+          const f32x4 v = *reinterpret_cast<const f32x4*>(lv + 4 * i4);
+          f32x4 ev;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) ev[e] = a3_expf(a.temperature * v[e] - m);
+          *reinterpret_cast<f32x4*>(lv + 4 * i4) = ev;
+        }
+      }
+      __syncthreads();
+      if (tid < TW && x0 + tid < a.W) {          // one lane per pixel: the oracle's sums, in its order
+        // (the LDS reads run four quads ahead of the sums: a dependent chain of 2 D operations with a read latency in front of
+        // every fourth one is what this lane would otherwise spend its time on)
+        const f32x4* ep = reinterpret_cast<const f32x4*>(aggrow + tid * DSA);
+        float ssum = 0.0f, tsum = 0.0f, df = 0.0f;
+        f32x4 pre[4] = {ep[0], ep[1], ep[2], ep[3]};          // D >= 48: at least 12 quads
+#pragma unroll 1
+        for (int d4 = 0; d4 < DQ; d4 += 4) {
+          f32x4 cur[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) cur[u] = pre[u];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) pre[u] = ep[min(d4 + 4 + u, DQ - 1)];
+#pragma unroll
+          for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              ssum += cur[u][e];
+              tsum = fmaf(df, cur[u][e], tsum);
+              df += 1.0f;                                      // exact: level indices stay far below 2^24
+            }
+        }
+        a.disp[((size_t)n * a.H + y) * a.W + x0 + tid] = tsum / ssum;
+      }
+    }
   };
 
   f32x2 r0[6][3], r1[6][3], r2[6][3];
@@ -669,21 +737,25 @@ extern "C" int st_costvolume_agg3d_supported(int C, int D) {
   return (C == 4 || C == 8 || C == 16) && D >= 4 && D % 4 == 0 && D <= 192;
 }
 
-extern "C" int st_costvolume_agg3d(const float* featL_dev, const float* featR_dev, int N, int H, int W, int C, int ld,
-                                   int D, const float* weight27_host, float bias, int act, float* vol_out_dev,
-                                   st_stream_t stream_) {
+static int cva_launch(const char* who, const float* featL_dev, const float* featR_dev, int N, int H, int W, int C, int ld,
+                      int D, const float* weight27_host, float bias, int act, float* vol_out_dev, float temperature,
+                      float* disp_out_dev, st_stream_t stream_) {
   using namespace st;
-  ST_REQUIRE(featL_dev && featR_dev && vol_out_dev && weight27_host, "st_costvolume_agg3d: bad pointer");
-  ST_REQUIRE(N > 0 && H > 0 && W > 0, "st_costvolume_agg3d: bad shape");
+  const bool sa = disp_out_dev != nullptr;
+  ST_REQUIRE(featL_dev && featR_dev && (vol_out_dev || sa) && weight27_host, "%s: bad pointer", who);
+  ST_REQUIRE(N > 0 && H > 0 && W > 0, "%s: bad shape", who);
   ST_REQUIRE(st_costvolume_agg3d_supported(C, D),
-             "st_costvolume_agg3d: needs C in {4, 8, 16} and D a multiple of 4 in [4, 192] (got C = %d, D = %d)", C, D);
-  ST_REQUIRE(ld >= C && ld % 4 == 0, "st_costvolume_agg3d: ld must be a multiple of 4 and >= C");
+             "%s: needs C in {4, 8, 16} and D a multiple of 4 in [4, 192] (got C = %d, D = %d)", who, C, D);
+  ST_REQUIRE(!sa || D == 48 || D == 96 || D == 192,
+             "%s: the fused soft-argmin is built for D = 48, 96 or 192 levels (got %d); other volumes take st_costvolume_agg3d + "
+             "st_softargmin", who, D);
+  ST_REQUIRE(ld >= C && ld % 4 == 0, "%s: ld must be a multiple of 4 and >= C", who);
   ST_REQUIRE(((reinterpret_cast<uintptr_t>(featL_dev) | reinterpret_cast<uintptr_t>(featR_dev) |
-               reinterpret_cast<uintptr_t>(vol_out_dev)) & 15) == 0, "st_costvolume_agg3d: buffers must be 16-byte aligned");
-  ST_REQUIRE(H < 65536 && N < 65536, "st_costvolume_agg3d: grid too large");
+               reinterpret_cast<uintptr_t>(vol_out_dev)) & 15) == 0, "%s: buffers must be 16-byte aligned", who);
+  ST_REQUIRE(H < 65536 && N < 65536, "%s: grid too large", who);
   // 32-bit buffer offsets inside one image row: feature rows (W x ld floats) and volume rows (W x D floats) below 2 GiB
   ST_REQUIRE((long long)W * ld * 4 < (1ll << 31) && (long long)W * D * 4 < (1ll << 31),
-             "st_costvolume_agg3d: an image row of W x ld (features) / W x D (volume) floats must be < 2 GiB");
+             "%s: an image row of W x ld (features) / W x D (volume) floats must be < 2 GiB", who);
   int cus = 0;
   ST_CHECK(a3_cu_count(&cus));
   CvAggArgs a;
@@ -691,10 +763,12 @@ extern "C" int st_costvolume_agg3d(const float* featL_dev, const float* featR_de
   a.N = N; a.H = H; a.W = W; a.ld = ld; a.D = D;
   for (int i = 0; i < 27; ++i) a.w[i] = weight27_host[i];
   a.bias = bias; a.act = act;
+  a.temperature = temperature; a.disp = disp_out_dev;
   // strip width: TW x D / 16 threads (<= 192) each own a 4 pixel x 4 level tile
   const int TW = D <= 48 ? 64 : (D <= 96 ? 32 : 16);
   const int strips = ceil_div(W, TW);
-  const int lds = ((TW + 2) * (D + 4) + C * (D + TW + 4) + C * (TW + 8)) * (int)sizeof(float);
+  // SA: + the aggregated row [TW][D + 4] and the partial maxima [D / 16][TW]
+  const int lds = ((TW + 2) * (D + 4) + C * (D + TW + 4) + C * (TW + 8) + (sa ? TW * (D + 4) + (D / 16) * TW : 0)) * (int)sizeof(float);
   // band count: whole launch rounds over the device's CUs x 4 workgroups (register-bound), two produce-only rows per band
   const long long slots = (long long)cus * 4;
   int best_b = 1;
@@ -708,21 +782,28 @@ extern "C" int st_costvolume_agg3d(const float* featL_dev, const float* featR_de
   }
   a.RY = std::min(H, ceil_div(H, best_b));
   const int bands = ceil_div(H, a.RY);
-  ST_REQUIRE(bands < 65536, "st_costvolume_agg3d: grid too large");
+  ST_REQUIRE(bands < 65536, "%s: grid too large", who);
   a.strips = strips; a.bands = bands;
   a.order = 1;
 #ifdef ST_ABLATION
   if (const char* o = getenv("ST_CVA_ORDER")) a.order = atoi(o);     // tools: 0 = launch order
 #endif
-  ST_REQUIRE((long long)N * strips * bands < (1ll << 31), "st_costvolume_agg3d: grid too large");
+  ST_REQUIRE((long long)N * strips * bands < (1ll << 31), "%s: grid too large", who);
   const dim3 grid((unsigned)(N * strips * bands));
   hipStream_t stream = static_cast<hipStream_t>(stream_);
 #define ST_CVA_LAUNCH(TWV, CV, DMAXV)                                                                \
   do {                                                                                               \
-    auto kern = D == DMAXV ? cv_agg3d_kernel<TWV, CV, DMAXV, true> : cv_agg3d_kernel<TWV, CV, DMAXV, false>; \
-    static int lds_set = 0;                                                                          \
-    ST_ENSURE_DYNAMIC_LDS(kern, lds, lds_set);                                                       \
-    hipLaunchKernelGGL(kern, grid, dim3(192), lds, stream, a);                                       \
+    if (sa) {                                                                                        \
+      auto kern = cv_agg3d_kernel<TWV, CV, DMAXV, true, 0, true>;   /* D == DMAXV: required above */   \
+      static int lds_set = 0;                                                                        \
+      ST_ENSURE_DYNAMIC_LDS(kern, lds, lds_set);                                                     \
+      hipLaunchKernelGGL(kern, grid, dim3(192), lds, stream, a);                                     \
+    } else {                                                                                         \
+      auto kern = D == DMAXV ? cv_agg3d_kernel<TWV, CV, DMAXV, true> : cv_agg3d_kernel<TWV, CV, DMAXV, false>; \
+      static int lds_set = 0;                                                                        \
+      ST_ENSURE_DYNAMIC_LDS(kern, lds, lds_set);                                                     \
+      hipLaunchKernelGGL(kern, grid, dim3(192), lds, stream, a);                                     \
+    }                                                                                                \
   } while (0)
 #define ST_CVA_BY_C(TWV, DMAXV)                                                                      \
   do {                                                                                               \
@@ -731,7 +812,7 @@ extern "C" int st_costvolume_agg3d(const float* featL_dev, const float* featR_de
     else ST_CVA_LAUNCH(TWV, 16, DMAXV);                                                              \
   } while (0)
 #ifdef ST_ABLATION
-  if (const char* m = getenv("ST_CVA_MODE")) {     // tools: timing-only ablations at the full-resolution shape
+  if (const char* m = sa ? nullptr : getenv("ST_CVA_MODE")) {     // tools: timing-only ablations at the full-resolution shape
     const int mode = atoi(m);
     if (mode > 0 && D == 192 && C == 8) {
       auto launch = [&](auto kern) -> int {
@@ -756,4 +837,20 @@ extern "C" int st_costvolume_agg3d(const float* featL_dev, const float* featR_de
 #undef ST_CVA_LAUNCH
   ST_CHECK_HIP(hipGetLastError());
   return ST_OK;
+}
+
+extern "C" int st_costvolume_agg3d(const float* featL_dev, const float* featR_dev, int N, int H, int W, int C, int ld,
+                                   int D, const float* weight27_host, float bias, int act, float* vol_out_dev,
+                                   st_stream_t stream_) {
+  ST_REQUIRE(vol_out_dev, "st_costvolume_agg3d: bad pointer");
+  return cva_launch("st_costvolume_agg3d", featL_dev, featR_dev, N, H, W, C, ld, D, weight27_host, bias, act, vol_out_dev, 0.0f,
+                    nullptr, stream_);
+}
+
+extern "C" int st_costvolume_agg3d_softargmin(const float* featL_dev, const float* featR_dev, int N, int H, int W, int C,
+                                              int ld, int D, const float* weight27_host, float bias, int act,
+                                              float temperature, float* disp_out_dev, st_stream_t stream_) {
+  ST_REQUIRE(disp_out_dev, "st_costvolume_agg3d_softargmin: bad pointer");
+  return cva_launch("st_costvolume_agg3d_softargmin", featL_dev, featR_dev, N, H, W, C, ld, D, weight27_host, bias, act, nullptr,
+                    temperature, disp_out_dev, stream_);
 }

@@ -102,6 +102,11 @@ class StereoCostVolume(nn.Module):
         self._red = None       # (device, weights version, packed reduce weights, bias)
         self._fr = None        # full-resolution buffers: reduced features, upsampled features, two volumes, disparity
         self.fuse_first_layer = True   # full-resolution mode: cost volume + first 3-D layer in one kernel (tools may clear it)
+        # ... and, when that is the ONLY 3-D layer, optionally the soft-argmin in the same kernel (st_costvolume_agg3d_softargmin):
+        # bit-equal, and the (N,H,W,D) volume - 5.8 GB per context at the bench size - is never allocated; OFF by default
+        # because it is SLOWER on MI355X (3.9-4.0 ms against 2.14 + 1.09 ms per 8 pairs, profiles/r06_fullres_single_kernel_ab.txt:
+        # the oracle's in-order sums are a serial chain of 2 D dependent operations that only TW = 16 lanes of a workgroup can run)
+        self.fuse_softargmin = False
         self._fr_fused = False
         self._taps3d = None    # (weights version, [(27 host floats as a ctypes array, bias)])
         self._vol = None
@@ -310,7 +315,7 @@ class StereoCostVolume(nn.Module):
         self._red = (dev, ver, wp.to(dev), bp.to(dev))
         return self._red[2], self._red[3]
 
-    def full_res_buffers(self, dev, N, Hf, Wf):
+    def full_res_buffers(self, dev, N, Hf, Wf, need_volume=True):
         """Persistent buffers of the full-resolution mode: reduced features (2N,Hf,Wf,Cr), upsampled features
         (2N,H,W,Cr), two volumes (N,H,W,D) (cost / aggregation ping-pong) and the disparity (N,H,W)."""
         Cr, D, s = self.reduce.out_channels, self.levels, self.feat_stride
@@ -322,12 +327,16 @@ class StereoCostVolume(nn.Module):
         if fr is None or fr['red'].shape != (2 * N, Hf, Wf, Cr):
             f32 = dict(dtype=torch.float32, device=dev)
             fr = self._fr[k] = dict(red=torch.empty(2 * N, Hf, Wf, Cr, **f32), up=torch.empty(2 * N, H, W, Cr, **f32),
-                                    va=torch.empty(N, H, W, D, **f32), disp=torch.empty(N, H, W, **f32))
+                                    va=None, disp=torch.empty(N, H, W, **f32))
             fr['vb'] = None
+        # first volume (N,H,W,D: 5.8 GB at the bench size): not needed at all when cost volume, the only 3-D layer and the
+        # soft-argmin run as one kernel; allocated on first need (`need_volume`)
+        if need_volume and fr['va'] is None:
+            fr['va'] = torch.empty(N, H, W, D, dtype=torch.float32, device=dev)
         # second volume: only where a layer runs volume -> volume (the first layer fused with the cost volume writes straight
         # into `va`); allocated on first need (a tool may switch `fuse_first_layer` off on a live module)
         fused = self.fuse_first_layer and self.lib.st_costvolume_agg3d_supported(Cr, D) == 1
-        if fr['vb'] is None and self.agg3d_layers > (1 if fused else 0):
+        if need_volume and fr['vb'] is None and self.agg3d_layers > (1 if fused else 0):
             fr['vb'] = torch.empty(N, H, W, D, dtype=torch.float32, device=dev)
         return fr
 
@@ -336,7 +345,9 @@ class StereoCostVolume(nn.Module):
             raise ValueError(f'full_res: the detector\'s stage-1 features have {Cf} channels, the module was built for '
                              f'feat_channels={self.reduce.in_channels}')
         s, D, Cr = self.feat_stride, self.levels, self.reduce.out_channels
-        b = self.full_res_buffers(dev, N, Hf, Wf)
+        single_kernel = (self.agg3d_layers == 1 and cost_out is None and self.fuse_first_layer and self.fuse_softargmin and
+                         D in (48, 96, 192) and self.lib.st_costvolume_agg3d_supported(Cr, D) == 1)
+        b = self.full_res_buffers(dev, N, Hf, Wf, need_volume=not single_kernel)
         wp, bp = self._pack_reduce(dev)
         ev = []
 
@@ -362,6 +373,24 @@ class StereoCostVolume(nn.Module):
         # cost volume and the first 3-D layer in one pass when the kernel takes the shape (the volume between them - 6.3 GB
         # per 8 pairs at D = 192 - then never reaches memory); the two-call form otherwise.  Same bits either way.
         fused = bool(layers) and self.fuse_first_layer and self.lib.st_costvolume_agg3d_supported(Cr, D) == 1
+        # ONE 3-D layer, nobody asks for the volume and `fuse_softargmin` is set (opt-in, see __init__): the soft-argmin is taken
+        # inside that kernel too (round 6, st_costvolume_agg3d_softargmin: the 4 D bytes per pixel of aggregated volume are
+        # neither allocated, written nor read back; bit-equal to the calls below)
+        single = single_kernel and fused and len(layers) == 1
+        if single:
+            w27, b3 = layers[0]
+            check(self.lib.st_costvolume_agg3d_softargmin(C.c_void_p(gl), C.c_void_p(gr), N, H, W, Cr, Cr, D, w27, b3, 0,
+                                                          self.temperature, ptr(b['disp']), stream),
+                  'st_costvolume_agg3d_softargmin')
+            mark()
+            mark()
+            check(self.lib.st_disp_upsample_pack(ptr(b['disp']), N, H, W, 1, H, W, int(valid_hw[0]), int(valid_hw[1]),
+                                                 ptr(disp_postp), stream), 'st_disp_upsample_pack')
+            mark()
+            if self.timing:
+                self._fr_events = ev
+                self._fr_fused = 'softargmin'
+            return disp_postp
         if fused:
             w27, b3 = layers[0]
             check(self.lib.st_costvolume_agg3d(C.c_void_p(gl), C.c_void_p(gr), N, H, W, Cr, Cr, D, w27, b3,
@@ -395,6 +424,9 @@ class StereoCostVolume(nn.Module):
         if not ev:
             return None
         ev[-1].synchronize()
+        if self._fr_fused == 'softargmin':     # features | cost volume + 3-D layer + soft-argmin in ONE kernel | - | pack
+            names = ('features_reduce_upsample', 'cost_volume_agg3d_softargmin', 'agg3d_rest', 'pack')
+            return {n: ev[i].elapsed_time(ev[i + 1]) for i, n in enumerate(names)}
         names = (('features_reduce_upsample', 'cost_volume_agg3d_first', 'agg3d_rest', 'softargmin_pack') if self._fr_fused
                  else ('features_reduce_upsample', 'cost_volume', 'agg3d', 'softargmin_pack'))
         return {n: ev[i].elapsed_time(ev[i + 1]) for i, n in enumerate(names)}

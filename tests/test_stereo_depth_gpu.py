@@ -417,6 +417,44 @@ def test_costvolume_agg3d_fused_bit_exact(N, H, W, Cc, ld, D, act, cuda):
     assert lib.st_costvolume_agg3d(ptr(gl), ptr(gr), N, H, W, 5, ld, D, w27, bias, act, ptr(out), current_stream()) != 0
 
 
+@pytest.mark.parametrize('N,H,W,Cc,ld,D,act', [
+    (2, 9, 37, 8, 8, 192, 0),       # the benched level count: 16-column strips, ragged last strip
+    (1, 23, 70, 8, 12, 192, 1),     # several bands' worth of rows, padding channels, SiLU in the 3-D layer
+    (2, 7, 80, 16, 16, 96, 0),      # 32-column strips
+    (1, 12, 150, 4, 4, 48, 1),      # 64-column strips, ragged
+    (1, 1, 5, 8, 8, 48, 0),         # one row, narrower than a strip
+])
+def test_costvolume_agg3d_softargmin_single_kernel_bit_exact(N, H, W, Cc, ld, D, act, cuda):
+    """st_costvolume_agg3d_softargmin (round 6): cost volume + ONE 3-D layer + soft-argmin in one kernel - the aggregated
+    volume never exists.  BIT-EXACT against oracle_costvolume -> oracle_agg3d -> oracle_softargmin and against the two
+    launches st_costvolume_agg3d -> st_softargmin."""
+    lib = _lib.load()
+    rng = np.random.RandomState(D + 7 * W + H)
+    fl = rng.normal(0, 1.0, (N, H, W, ld)).astype(np.float32)
+    fr = rng.normal(0, 1.0, (N, H, W, ld)).astype(np.float32)
+    w = rng.normal(0, 0.4, (3, 3, 3)).astype(np.float32)
+    bias, T = 0.03125, 32.0
+    ref = c_oracle.softargmin(c_oracle.agg3d(c_oracle.costvolume(fl, fr, Cc, D), w, bias, act), T)
+    gl, gr = torch.from_numpy(fl).to(cuda), torch.from_numpy(fr).to(cuda)
+    w27 = (C.c_float * 27)(*w.reshape(-1).tolist())
+    disp = torch.full((N, H, W), float('nan'), device=cuda)
+    check(lib.st_costvolume_agg3d_softargmin(ptr(gl), ptr(gr), N, H, W, Cc, ld, D, w27, bias, act, T, ptr(disp),
+                                             current_stream()), 'st_costvolume_agg3d_softargmin')
+    torch.cuda.synchronize()
+    got = disp.cpu().numpy()
+    assert np.array_equal(got.view(np.uint32), ref.reshape(N, H, W).view(np.uint32)), np.abs(got - ref.reshape(N, H, W)).max()
+    vol = torch.empty(N, H, W, D, device=cuda)
+    disp2 = torch.full_like(disp, float('nan'))
+    check(lib.st_costvolume_agg3d(ptr(gl), ptr(gr), N, H, W, Cc, ld, D, w27, bias, act, ptr(vol), current_stream()))
+    check(lib.st_softargmin(ptr(vol), N, H, W, D, T, ptr(disp2), current_stream()))
+    torch.cuda.synchronize()
+    assert torch.equal(disp, disp2)
+    # level counts the single-kernel form is not built for are refused (the caller takes the two calls), never approximated
+    assert lib.st_costvolume_agg3d_softargmin(ptr(gl), ptr(gr), N, H, W, Cc, ld, 64, w27, bias, act, T, ptr(disp),
+                                              current_stream()) != 0
+    assert 'D = 48, 96 or 192' in lib.st_last_error().decode()
+
+
 def test_costvolume_agg3d_fused_equals_two_call_form_on_random_shapes(cuda):
     """Seeded sweep over 40 shapes (every D multiple of 4 up to 192, widths below / across / beyond a strip, heights from 1 row,
     C in {4, 8, 16} with and without padding channels, both activations): the fused kernel equals the two-call form bit for
@@ -658,6 +696,15 @@ def test_stereo_full_resolution_mode_matches_oracle(agg3d_layers, cuda):
     torch.cuda.synchronize()
     stages = sm.pop_full_res_times()
     assert ('cost_volume_agg3d_first' in stages) == (agg3d_layers > 0) and torch.equal(out2, out)
+    if agg3d_layers == 1:
+        # opt-in (round 6): cost volume + the ONE 3-D layer + soft-argmin as ONE launch (st_costvolume_agg3d_softargmin: the
+        # volume is never allocated, written or read back) - the same bits; off by default because it is slower
+        sm.fuse_softargmin = True
+        out4 = torch.full_like(out, float('nan'))
+        sm.compute(pipe.det, img, right, (H, W), None, out4)
+        torch.cuda.synchronize()
+        assert 'cost_volume_agg3d_softargmin' in sm.pop_full_res_times() and torch.equal(out4, out)
+        sm.fuse_softargmin = False
     sm.fuse_first_layer = False
     out3 = torch.full_like(out, float('nan'))
     sm.compute(pipe.det, img, right, (H, W), None, out3)
