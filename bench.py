@@ -205,7 +205,7 @@ def conv_roofline(pipe, img, right, steps):
         e['instances'].append(name)
     # Durations: raw HIP-event times carry the event-pair overhead (two barrier packets, measured above on this stream:
     # `event_pair_overhead_us`); rocprofv3's kernel durations do not.  The overhead is subtracted per launch so that
-    # `achieved` / `avg_launch_us` reproduce from profiles/r05_kernel_stats_inflight1.csv (the raw figures are kept
+    # `achieved` / `avg_launch_us` reproduce from profiles/r06_kernel_stats_inflight1.csv (the raw figures are kept
     # next to them).  `frac` is a fraction of the INSTRUCTION peak: flops the matrix pipes execute / time / 157.3 - for
     # the Winograd family that is the direct-convolution count / 2.25 (F(2x2,3x3) issues 16 of every 36 multiplies),
     # which goes into `algorithmic_speedup`, never into `frac`.
@@ -232,7 +232,7 @@ def conv_roofline(pipe, img, right, steps):
     conv_fl = 2.0 * float(macs[kind == 1].sum() + agg_macs * sum(a[0] for a in agg.values()) / steps)
     conv_exec = sum(e['executed_gflop_per_step'] for e in fam.values()) * 1e9
     # HBM bytes per launch of the dominant family from this round's rocprofv3 PMC passes of this command (FETCH_SIZE x2
-    # gfx950 correction + WRITE_SIZE, separate passes; tools/profile_round.sh writes profiles/r05_hbm_traffic.json from
+    # gfx950 correction + WRITE_SIZE, separate passes; tools/profile_round.sh writes profiles/r06_hbm_traffic.json from
     # the SAME commit's library).  null when that file is absent: never a number from another round.
     traffic, traffic_src = None, None
     tpath = os.path.join(ROOT, 'profiles', TRAFFIC_ROUND + '_hbm_traffic.json')
@@ -262,7 +262,7 @@ def conv_roofline(pipe, img, right, steps):
                            '/ summed kernel duration of the family in a serialized pass (HIP events on the launch '
                            'stream minus the measured event-pair overhead; an event-bracketed launch also carries its '
                            'dispatch latency, so these durations read ~4 % above the rocprofv3 kernel-trace durations '
-                           'of the same launches in profiles/r05_kernel_stats_inflight1.csv: `achieved` is a lower '
+                           'of the same launches in profiles/r06_kernel_stats_inflight1.csv: `achieved` is a lower '
                            'bound); frac = achieved / peak <= 1',
                 families=fam,
                 all_mfma_kernels=dict(ms_per_step=round(conv_ms, 4),
@@ -438,7 +438,7 @@ def split_leg(args, sd, img, right, headline):
 
 def parity_records():
     """The parity truth, read from the COMMITTED records of this round's GPU tests (tests/test_config2_oracle_gpu.py writes
-    them; profiles/r05_config2_oracle_<sequence>_<thresholds>.json): configs[2] end to end through model.test_step against
+    them; profiles/r06_config2_oracle_<sequence>_<thresholds>.json): configs[2] end to end through model.test_step against
     the CPU fp32 oracle pipeline AND a float64 evaluation of the same arithmetic.  north_star asks for floats within 1e-3
     of the CPU path and bit-exact indices: per sequence the line says whether that literal bar holds
     (`within_1e3_of_cpu_path`) and what was measured where it does not.  null when the records are absent."""
