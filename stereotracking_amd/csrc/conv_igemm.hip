@@ -841,6 +841,7 @@ bool dc_conv_applicable(const StConvDesc& d);          // direct_conv.hip (tile 
 int dc_conv_launch(const StConvDesc& d, hipStream_t stream);
 bool wino_conv_applicable(const StConvDesc& d);        // wino_conv.hip (tile variant 43)
 int wino_conv_launch(const StConvDesc& d, hipStream_t stream, bool narrow);
+int wino_persist_launch(const StConvDesc& d, hipStream_t stream);   // wino_conv.hip (tile variant 57)
 
 int conv2d_launch(const StConvDesc& d, hipStream_t stream, int force_variant, int* picked_variant) {
   ST_REQUIRE(d.in_dev && d.wgt_dev && d.bias_dev && d.out1_dev, "conv: null pointer");
@@ -860,6 +861,12 @@ int conv2d_launch(const StConvDesc& d, hipStream_t stream, int force_variant, in
     if (picked_variant) *picked_variant = force_variant;
     return wino_conv_launch(d, stream, force_variant == 44);
   }
+#ifdef ST_ABLATION
+  if (force_variant == 57) {   // tools build: persistent Winograd kernel (bit-identical to 43, not faster: wino_conv.hip)
+    if (picked_variant) *picked_variant = 57;
+    return wino_persist_launch(d, stream);
+  }
+#endif
   ST_REQUIRE(d.Cin % 4 == 0 && d.in_ld % 4 == 0 && d.in_off % 4 == 0,
              "conv: Cin/in_ld/in_off must be multiples of 4 (got %d/%d/%d)", d.Cin, d.in_ld,
              d.in_off);

@@ -337,6 +337,248 @@ __global__ __launch_bounds__(256, 2) void wino_conv3x3_group_kernel(const WinoGr
   wino_conv3x3_body<CBN, LCBN, false, false>(g.p[k], (int)b);
 }
 
+
+#ifdef ST_ABLATION
+// ---- PERSISTENT form of the same convolution (tile variant 57, round 6; TOOLS BUILD ONLY) -------------------------------
+// Measured (tools/wino_persist_bench.py, profiles/r06_wino_persist_ab.txt): bit-identical to variant 43 and NOT faster - 0.975 to
+// 1.035 x on the path's eight layer shapes.  The per-workgroup prologue is therefore not what holds these launches at an
+// MFMA-pipe busy of 0.44-0.53; what the tail kernel removed and this form keeps is the transformed-weight stream (1 KB per
+// 4 MFMAs and wave from L2, a wait per step).  Kept as the yardstick of that statement, not shipped.
+// What the counters said about every non-head Winograd launch (MFMA-pipe busy 0.44-0.53, profiles/r06_mfma_busy.txt): a
+// workgroup runs two to four K-chunks between a prologue (index set-up, the first window and weight fetch, exposed) and an
+// epilogue, and dies.  Here two workgroups per CU LOOP over the tile blocks: the NEXT block's first window is requested by
+// LDS-DMA at the top of the current block's LAST K-chunk (into the window buffer that chunk does not read) and its first
+// weight fragment in front of the output transform, so a block starts with its operands in place.  For that the transform
+// exchange cannot alias the window buffers any more: it has 32 KB of its own and the 64-cout workgroup transforms its two
+// cout blocks one after the other (two more barriers per block).  LDS 2 x 23.5 + 32 = 79 KB: still two workgroups per CU.
+// Per accumulator the MFMA sequence, and per output the transform's additions, are those of wino_conv3x3_body: the results
+// are BIT-IDENTICAL to tile variant 43 (tests/test_conv_gpu.py).
+constexpr int wnp_lds_floats() { return 2 * WN_WIN_FLOATS + 4 * 2 * 32 * 32; }
+
+template <int CBN, int LCBN, bool RES, bool KTAIL>
+__global__ __launch_bounds__(256, 2) void wino_conv3x3_persist_kernel(const WinoArgs p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  constexpr int WN_FRAG_FLOATS = LCBN * 64 * 4;
+  constexpr int SPLIT = LCBN / CBN;
+  extern __shared__ float4 wn_smem4[];
+  float* smem = reinterpret_cast<float*>(wn_smem4);
+  float* Rb = smem + 2 * WN_WIN_FLOATS;          // [a][j][tile][32]: one cout block of 32 at a time
+  const int tid = threadIdx.x, lane = tid & 63, a = tid >> 6;
+  const int i = lane & 31, h = lane >> 5;
+  const int tyi = i >> 3, txi = i & 7;
+  const __amdgpu_buffer_rsrc_t irsrc =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in), 0, (int)p.in_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t wrsrc =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.wino), 0, (int)p.wino_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, (int)p.out_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rrsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(RES ? p.res : p.in), 0, (int)(RES ? p.res_bytes : 0u), 0x00020000);
+  constexpr int NPW = (WN_PIECES + 3) / 4;
+
+  // window geometry of a block: byte offsets of this lane's DMA pieces (as wino_conv3x3_body)
+  auto block_of = [&](unsigned b, int& cb, int& bx, int& by, int& n) {
+    cb = (int)(b % (unsigned)p.ncb); b /= (unsigned)p.ncb;
+    bx = (int)(b % (unsigned)p.tbx); b /= (unsigned)p.tbx;
+    by = (int)(b % (unsigned)p.tby);
+    n = (int)(b / (unsigned)p.tby);
+  };
+  unsigned tail_ok = 0;
+#pragma unroll
+  for (int k = 0; k < NPW; ++k) {
+    const int j = a + 4 * k;
+    const int q = 8 * j + (lane >> 3), sl = lane & 7;
+    const int quad = sl ^ ((q >> 1) & 7);
+    if ((p.nkc - 1) * 32 + 4 * quad < p.Cin) tail_ok |= 1u << k;
+  }
+  auto window_offsets = [&](int bx, int by, int n, unsigned (&poff)[NPW]) {
+    const int wy0 = by * (2 * WN_TY) - 1, wx0 = bx * (2 * WN_TX) - 1;
+#pragma unroll
+    for (int k = 0; k < NPW; ++k) {
+      const int j = a + 4 * k;
+      const int q = 8 * j + (lane >> 3), sl = lane & 7;
+      const int wr = q / WN_WW, wc = q - wr * WN_WW;
+      const int y = wy0 + wr, x = wx0 + wc;
+      const bool ok = j < WN_PIECES && q < WN_PIX && y >= 0 && y < p.H && x >= 0 && x < p.W;
+      const int quad = sl ^ ((q >> 1) & 7);
+      poff[k] = ok ? (unsigned)((((n * p.H + y) * p.W + x) * p.in_ld + p.in_off + 4 * quad) * 4) : 0x80000000u;
+    }
+  };
+  auto dma_window = [&](const unsigned (&poff)[NPW], int kc, int buf) {
+    const bool last = kc == p.nkc - 1;
+#pragma unroll
+    for (int k = 0; k < NPW; ++k) {
+      const int j = a + 4 * k;
+      const unsigned off = (last && !((tail_ok >> k) & 1u)) ? 0x80000000u : poff[k];
+      if (j < WN_PIECES)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(
+            irsrc, (__attribute__((address_space(3))) void*)(smem + buf * WN_WIN_FLOATS + j * 256), 16, off, kc * 128, 0, 0);
+    }
+  };
+  const int r0 = a == 0 ? 0 : (a == 2 ? 2 : 1);
+  const int r1 = a == 0 ? 2 : (a == 1 ? 2 : (a == 2 ? 1 : 3));
+  const f32x2 sgn = a == 1 ? f32x2{1.0f, 1.0f} : f32x2{-1.0f, -1.0f};
+  // patch pixel (row r, column c) of tile (tyi, txi): window pixel q = (2 tyi + r) * 18 + 2 txi + c, float offset 32 q, channel
+  // slot (2g + h) ^ ((q >> 1) & 7); q(c = 0) is even, so columns (0, 1) and (2, 3) share a swizzle term and
+  // (2g + h) ^ sw = 2g ^ (h ^ sw): two row bases + four terms instead of 8 + 8 registers held through the block loop
+  const int qb0 = (2 * tyi + r0) * WN_WW + 2 * txi, qb1 = (2 * tyi + r1) * WN_WW + 2 * txi;
+  const int hs00 = (h ^ ((qb0 >> 1) & 7)) << 2, hs01 = (h ^ (((qb0 >> 1) + 1) & 7)) << 2;
+  const int hs10 = (h ^ ((qb1 >> 1) & 7)) << 2, hs11 = (h ^ (((qb1 >> 1) + 1) & 7)) << 2;
+  const int last_step = p.nkc * 16 - 1;
+  auto wbase_of = [&](int cb) {
+    return (unsigned)(((((cb / SPLIT) * 4 + a) * p.nkc) * 16) * WN_FRAG_FLOATS + (cb % SPLIT) * CBN * 256 + lane * 4) * 4u;
+  };
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+  unsigned blk = blockIdx.x;
+  if (blk >= p.nblocks) return;
+  int cb, bx, by, n;
+  block_of(blk, cb, bx, by, n);
+  unsigned poff[NPW];
+  window_offsets(bx, by, n, poff);
+  unsigned wbase = wbase_of(cb);
+  int b0 = 0;                                  // window buffer of the current block's chunk 0
+  dma_window(poff, 0, 0);
+  f32x4 fe[CBN], fo[CBN];
+  auto load_frag = [&](unsigned wb, int step, f32x4 (&f)[CBN]) {
+    const int soff = (step < last_step ? step : last_step) * (WN_FRAG_FLOATS * 4);
+#pragma unroll
+    for (int nb = 0; nb < CBN; ++nb)
+      f[nb] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, wb, soff + 1024 * nb, 0));
+  };
+  load_frag(wbase, 0, fe);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  for (;;) {
+    const unsigned nxt = blk + gridDim.x;
+    const bool has_next = nxt < p.nblocks;     // uniform
+    int cbn = 0, bxn = 0, byn = 0, nn = 0;
+    f32x16 acc[4][CBN];
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+#pragma unroll
+      for (int nb = 0; nb < CBN; ++nb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[b][nb][r] = 0.f;
+
+    for (int kc = 0; kc < p.nkc; ++kc) {
+      const int buf = (kc + b0) & 1;
+      if (kc + 1 < p.nkc) {
+        dma_window(poff, kc + 1, buf ^ 1);
+      } else if (has_next) {                   // the next block's first window: lands during this block's last chunk
+        block_of(nxt, cbn, bxn, byn, nn);
+        unsigned poffn[NPW];                   // (not kept: the block recomputes its offsets when it starts)
+        window_offsets(bxn, byn, nn, poffn);
+        dma_window(poffn, 0, buf ^ 1);
+      }
+      const float* win = smem + buf * WN_WIN_FLOATS;
+      const int gn = (KTAIL && kc == p.nkc - 1) ? p.g_last : 4;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        if (KTAIL && g >= gn) continue;
+        f32x4 d[8];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          d[c] = *reinterpret_cast<const f32x4*>(win + qb0 * 32 + 32 * c + ((8 * g) ^ (c < 2 ? hs00 : hs01)));
+          d[4 + c] = *reinterpret_cast<const f32x4*>(win + qb1 * 32 + 32 * c + ((8 * g) ^ (c < 2 ? hs10 : hs11)));
+        }
+        f32x4 P[4], V[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) P[c] = wn_addsgn(d[c], sgn, d[4 + c]);
+        V[0] = wn_sub_mfma(P[0], P[2]);
+        V[1] = wn_add_mfma(P[1], P[2]);
+        V[2] = wn_sub_mfma(P[2], P[1]);
+        V[3] = wn_sub_mfma(P[1], P[3]);
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+          const int step = (kc * 4 + g) * 4 + b;
+          if (b & 1) load_frag(wbase, step + 1, fe); else load_frag(wbase, step + 1, fo);
+#pragma unroll
+          for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int nb = 0; nb < CBN; ++nb)
+              acc[b][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[b][s], (b & 1) ? fo[nb][s] : fe[nb][s], acc[b][nb],
+                                                                0, 0, 0);
+        }
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+    }
+    // the next block's first weight fragment travels under the output transform
+    unsigned wbasen = wbase;
+    if (has_next) {
+      wbasen = wbase_of(cbn);
+      load_frag(wbasen, 0, fe);
+    }
+
+    // ---- output transform, one cout block of 32 at a time
+    const int c4 = (lane & 7) * 4, txo = lane >> 3;
+    const int t = a * 8 + txo;
+    const int oy0 = by * (2 * WN_TY) + 2 * a, ox0 = bx * (2 * WN_TX) + 2 * txo;
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_nop 15\n\ts_nop 3" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int nb = 0; nb < CBN; ++nb) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (r & 1) continue;
+        const f32x2 a0{acc[0][nb][r], acc[0][nb][r + 1]}, a1{acc[1][nb][r], acc[1][nb][r + 1]};
+        const f32x2 a2{acc[2][nb][r], acc[2][nb][r + 1]}, a3{acc[3][nb][r], acc[3][nb][r + 1]};
+        const f32x2 R0 = wn_pk_add(wn_pk_add(a0, a1), a2);
+        const f32x2 R1 = wn_pk_sub(wn_pk_sub(a1, a2), a3);
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          Rb[((a * 2 + 0) * 32 + m + e) * 32 + i] = R0[e];
+          Rb[((a * 2 + 1) * 32 + m + e) * 32 + i] = R1[e];
+        }
+      }
+      __syncthreads();
+      const int co = cb * (32 * CBN) + nb * 32 + c4;
+      const f32x4 bias4 = *reinterpret_cast<const f32x4*>(p.bias + co);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const f32x4 q0 = *reinterpret_cast<const f32x4*>(Rb + ((0 * 2 + j) * 32 + t) * 32 + c4);
+        const f32x4 q1 = *reinterpret_cast<const f32x4*>(Rb + ((1 * 2 + j) * 32 + t) * 32 + c4);
+        const f32x4 q2 = *reinterpret_cast<const f32x4*>(Rb + ((2 * 2 + j) * 32 + t) * 32 + c4);
+        const f32x4 q3 = *reinterpret_cast<const f32x4*>(Rb + ((3 * 2 + j) * 32 + t) * 32 + c4);
+        const f32x4 y[2] = {wn_add(wn_add(q0, q1), q2), wn_sub(wn_sub(q1, q2), q3)};
+#pragma unroll
+        for (int ii = 0; ii < 2; ++ii) {
+          const int oy = oy0 + ii, ox = ox0 + j;
+          const bool ok = oy < p.H && ox < p.W && co < p.Cout;
+          const int m = (n * p.H + oy) * p.W + ox;
+          f32x4 v = wn_add(y[ii], bias4);
+          if (p.act) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = wn_silu(v[e]);
+          }
+          if (RES) {
+            const unsigned roff = ok ? (unsigned)((m * p.res_ld + p.res_off + co) * 4) : 0x80000000u;
+            const f32x4 rv = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rrsrc, roff, 0, 0));
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = (v[e] + rv[e]) * p.post_scale;
+          }
+          const unsigned off = ok ? (unsigned)((m * p.out_ld + p.out_off + co) * 4) : 0x80000000u;
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), orsrc, off, 0, 0);
+        }
+      }
+      if (nb + 1 < CBN) __syncthreads();       // the next cout block's exchange overwrites Rb
+    }
+    if (!has_next) break;
+    blk = nxt; cb = cbn; bx = bxn; by = byn; n = nn;
+    if (p.nkc > 1) window_offsets(bx, by, n, poff);   // for the chunks 1.. of the block (uniform)
+    wbase = wbasen;
+    b0 = (b0 + p.nkc) & 1;
+    // (the next block's exchange writes come behind its K loop's barriers; its first window was published by the barrier
+    // that closed this block's last chunk)
+  }
+#endif
+}
+
+#endif  // ST_ABLATION
+
 }  // namespace
 
 // cout blocks of 32 per workgroup for a layer: 2 (64 couts) when Cout is a multiple of 64 or fits one padded block of
@@ -464,6 +706,47 @@ int wino_conv_launch(const StConvDesc& d, hipStream_t stream, bool narrow) {
   ST_CHECK_HIP(hipGetLastError());
   return ST_OK;
 }
+
+
+#ifdef ST_ABLATION
+// tile variant 57: the persistent form (64-cout layout only: Cout % 64 == 0 or one padded block of 64)
+bool wino_persist_applicable(const StConvDesc& d) { return wino_conv_applicable(d) && wino_cbn(d.Cout) == 2; }
+
+template <int CBN, int LCBN, bool RES, bool KTAIL>
+static int wino_persist_instance(const WinoArgs& a, unsigned grid, hipStream_t stream) {
+  constexpr int lds = wnp_lds_floats() * (int)sizeof(float);
+  static int lds_set = 0;
+  auto kern = wino_conv3x3_persist_kernel<CBN, LCBN, RES, KTAIL>;
+  ST_ENSURE_DYNAMIC_LDS(kern, lds, lds_set);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, stream, a);
+  return ST_OK;
+}
+
+int wino_persist_launch(const StConvDesc& d, hipStream_t stream) {
+  ST_REQUIRE(wino_persist_applicable(d), "winograd conv (persistent): needs a Winograd layer with the 64-cout layout");
+  WinoArgs a;
+  long long blocks = 0;
+  ST_CHECK(wino_fill_args(d, false, a, &blocks));
+  static int cus = 0;
+  if (cus == 0) {
+    int dev = 0, n = 0;
+    ST_CHECK_HIP(hipGetDevice(&dev));
+    ST_CHECK_HIP(hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev));
+    cus = std::max(1, n);
+  }
+  const unsigned grid = (unsigned)std::min<long long>(blocks, 2ll * cus);
+  const bool ktail = a.g_last < 4;
+  int rc;
+  if (ktail) rc = d.res_dev ? wino_persist_instance<2, 2, true, true>(a, grid, stream)
+                            : wino_persist_instance<2, 2, false, true>(a, grid, stream);
+  else rc = d.res_dev ? wino_persist_instance<2, 2, true, false>(a, grid, stream)
+                      : wino_persist_instance<2, 2, false, false>(a, grid, stream);
+  ST_CHECK(rc);
+  ST_CHECK_HIP(hipGetLastError());
+  return ST_OK;
+}
+
+#endif  // ST_ABLATION
 
 // Can these layers share one grouped launch?  The wide instance <2, 2>, no residual, no K tail, at most WN_GROUP_MAX.
 bool wino_group_applicable(const StConvDesc* d, int n) {

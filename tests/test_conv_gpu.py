@@ -5,6 +5,7 @@ torch fp32/fp64 reference: tolerance 1e-4 relative to the fp64 result's scale â€
 summation orders of K <= 4608 products differ by ~sqrt(K)*2^-24.
 """
 import ctypes as C
+import os
 
 import pytest
 import torch
@@ -46,7 +47,7 @@ def run_conv(x_nchw, w, bias, stride, pad, act, dev, variant=-1, res=None, post_
     d.wgt_dev = wp.data_ptr(); d.bias_dev = bp.data_ptr()
     d.Cout, d.KH, d.KW, d.stride, d.pad = Cout, KH, KW, stride, pad
     wino = None
-    if variant in (43, 44):   # Winograd instances: the same folded weights in transformed, fragment-ordered form
+    if variant in (43, 44, 57):   # Winograd instances: the same folded weights in transformed, fragment-ordered form
         wino = torch.empty(lib.st_wino_packed_floats(Cout, Cin), dtype=torch.float32)
         wp_host = wp.cpu()   # keep alive: ptr() does not hold a reference
         check(lib.st_wino_pack_weights(ptr(wp_host), Cout, Cin, ptr(wino)), 'st_wino_pack_weights')
@@ -512,6 +513,13 @@ def test_winograd_conv_matches_direct_convolution(cin, cout, res, act, shape, in
     base, _ = run_conv(x, w, b, 1, 1, act, cuda, variant=4, res=r, post_scale=0.5 if res else 1.0, in_ld=in_ld,
                        in_off=in_off)
     assert_close(got, base.double(), tol=2e-5)
+    if (cout % 64 == 0 or 32 < cout < 64) and 'ablation' in os.path.basename(os.environ.get('ST_LIBRARY', '')):
+        # (tools build only) variant 57: the PERSISTENT form (workgroups loop over the tile blocks, the next
+        # block's first window and weight fragment prefetched, the two cout blocks transformed one after the other): the same
+        # MFMA sequence per accumulator and the same transform additions per output - bit-identical to variant 43
+        pers, _ = run_conv(x, w, b, 1, 1, act, cuda, variant=57, res=r, post_scale=0.5 if res else 1.0, in_ld=in_ld,
+                           in_off=in_off)
+        assert torch.equal(pers, got)
     if cout % 64 == 0:   # variant 44: the same layout computed by 32-cout workgroups - bit-identical to variant 43
         narrow, _ = run_conv(x, w, b, 1, 1, act, cuda, variant=44, res=r, post_scale=0.5 if res else 1.0, in_ld=in_ld,
                              in_off=in_off)
