@@ -438,14 +438,16 @@ __global__ __launch_bounds__(256, 2) void wino_conv3x3_persist_kernel(const Wino
   unsigned wbase = wbase_of(cb);
   int b0 = 0;                                  // window buffer of the current block's chunk 0
   dma_window(poff, 0, 0);
-  f32x4 fe[CBN], fo[CBN];
+  f32x4 fr[4][CBN];                            // fragment ring: step s lives in slot s & 3, requested three steps ahead
   auto load_frag = [&](unsigned wb, int step, f32x4 (&f)[CBN]) {
     const int soff = (step < last_step ? step : last_step) * (WN_FRAG_FLOATS * 4);
 #pragma unroll
     for (int nb = 0; nb < CBN; ++nb)
       f[nb] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, wb, soff + 1024 * nb, 0));
   };
-  load_frag(wbase, 0, fe);
+  load_frag(wbase, 0, fr[0]);
+  load_frag(wbase, 1, fr[1]);
+  load_frag(wbase, 2, fr[2]);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
@@ -492,13 +494,12 @@ __global__ __launch_bounds__(256, 2) void wino_conv3x3_persist_kernel(const Wino
 #pragma unroll
         for (int b = 0; b < 4; ++b) {
           const int step = (kc * 4 + g) * 4 + b;
-          if (b & 1) load_frag(wbase, step + 1, fe); else load_frag(wbase, step + 1, fo);
+          load_frag(wbase, step + 3, fr[(b + 3) & 3]);      // (16 steps per chunk: the slot of a step is b & 3)
 #pragma unroll
           for (int s = 0; s < 4; ++s)
 #pragma unroll
             for (int nb = 0; nb < CBN; ++nb)
-              acc[b][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[b][s], (b & 1) ? fo[nb][s] : fe[nb][s], acc[b][nb],
-                                                                0, 0, 0);
+              acc[b][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[b][s], fr[b & 3][nb][s], acc[b][nb], 0, 0, 0);
         }
       }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -508,7 +509,9 @@ __global__ __launch_bounds__(256, 2) void wino_conv3x3_persist_kernel(const Wino
     unsigned wbasen = wbase;
     if (has_next) {
       wbasen = wbase_of(cbn);
-      load_frag(wbasen, 0, fe);
+      load_frag(wbasen, 0, fr[0]);
+      load_frag(wbasen, 1, fr[1]);
+      load_frag(wbasen, 2, fr[2]);
     }
 
     // ---- output transform, one cout block of 32 at a time
