@@ -431,12 +431,16 @@ int StDetector::build() {
 #endif
   if (sbatch <= 0 || N % sbatch != 0) sbatch = N;  // one group covering the whole batch
   TRef s1 = new_tensor(NB, H4, W4, c2);  // stage1 features of every (left | right) image: kept for the stereo module
-  begin_group(sbatch, NB);
+  int sb0 = sbatch;                      // phase 0 runs left | right as two sub-batches of N (shared intermediates)
+#ifdef ST_ABLATION
+  if (getenv("ST_MERGE_LR")) sb0 = NB;   // tools: one launch over all 2N images (A/B, profiles/r06_merge_lr_ab.txt)
+#endif
+  begin_group(sb0, NB);
   {
-    TRef stem = fused_stem ? window(stem_rgb, sbatch)
-                           : convmodule("backbone.stem.conv", window(packed_rgb, sbatch), c1, 3, 1);
+    TRef stem = fused_stem ? window(stem_rgb, sb0)
+                           : convmodule("backbone.stem.conv", window(packed_rgb, sb0), c1, 3, 1);
     TRef s1c = convmodule("backbone.stage1.0", stem, c2, 3, 2);
-    csp_layer("backbone.stage1.1", s1c, c2, n1, true, window(s1, sbatch));
+    csp_layer("backbone.stage1.1", s1c, c2, n1, true, window(s1, sb0));
   }
   end_group();
   taps["stage1_rgb"] = s1;
